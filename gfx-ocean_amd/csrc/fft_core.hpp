@@ -1,0 +1,257 @@
+// fft_core.hpp -- register-resident mixed-radix Stockham line FFT for gfx950 (wave64).
+//
+// Computes, per line, the reference's transform (shader/fft_row.comp:25-63):
+//     X[n] = sum_m x[m] * e^{+2 pi i m n / N}      (unnormalised inverse DFT, natural order)
+// but not with the reference's radix-2 / one-butterfly-per-thread schedule: each thread keeps
+// E elements of a line in VGPRs, does radix-R butterflies (R <= E) entirely in registers and
+// only crosses threads through LDS between passes (2 exchanges for N = 4096 instead of the
+// reference's 12 barrier-separated LDS round trips).  Twiddles come from one fp64-computed table
+// lookup per thread per pass (w), the powers w^2..w^(R-1) by a depth<=4 product tree, instead of
+// the reference's cos/sin per butterfly (fft_row.comp:32-33).
+//
+// Index algebra (verified against numpy in oracle prototype, see DESIGN.md "FFT schedule"):
+//   T = N/E threads per line; at the start of every pass thread j holds x[j + e*T], e in [0,E).
+//   Pass with radix R and Ns = product of earlier radices; for u in [0, E/R):
+//     jv = j + u*T;  k = jv % Ns;  inputs a_t = reg[u + t*E/R] * w^{t}, w = e^{+2 pi i k/(Ns*R)}
+//     b = DFT_R(a);  b_s goes to position (jv/Ns)*Ns*R + k + s*Ns.
+//   The last pass' positions are again j + e'*T, so global stores stay lane-contiguous.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <ocean_device_intrinsics.hpp>
+
+namespace ocean {
+
+typedef float2 c32;
+
+__device__ __forceinline__ c32 cadd(c32 a, c32 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ c32 csub(c32 a, c32 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ c32 cmul(c32 a, c32 b) {
+    return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
+}
+
+// e^{+2 pi i s / 32}, s in [0,32): exact trivial entries, others rounded from fp64.
+template <int S32> struct W32 {};
+#define OCEAN_W32(S, C, SN) \
+    template <> struct W32<S> { static constexpr float c = C; static constexpr float s = SN; };
+OCEAN_W32(0, 1.0f, 0.0f)
+OCEAN_W32(1, 0.9807852804032304f, 0.19509032201612825f)
+OCEAN_W32(2, 0.9238795325112867f, 0.3826834323650898f)
+OCEAN_W32(3, 0.8314696123025452f, 0.5555702330196022f)
+OCEAN_W32(4, 0.7071067811865476f, 0.7071067811865476f)
+OCEAN_W32(5, 0.5555702330196022f, 0.8314696123025452f)
+OCEAN_W32(6, 0.3826834323650898f, 0.9238795325112867f)
+OCEAN_W32(7, 0.19509032201612825f, 0.9807852804032304f)
+OCEAN_W32(8, 0.0f, 1.0f)
+OCEAN_W32(9, -0.19509032201612825f, 0.9807852804032304f)
+OCEAN_W32(10, -0.3826834323650898f, 0.9238795325112867f)
+OCEAN_W32(11, -0.5555702330196022f, 0.8314696123025452f)
+OCEAN_W32(12, -0.7071067811865476f, 0.7071067811865476f)
+OCEAN_W32(13, -0.8314696123025452f, 0.5555702330196022f)
+OCEAN_W32(14, -0.9238795325112867f, 0.3826834323650898f)
+OCEAN_W32(15, -0.9807852804032304f, 0.19509032201612825f)
+#undef OCEAN_W32
+
+// a * e^{+2 pi i S / R}  for compile-time S in [0, R/2), R in {2,4,8,16,32}
+template <int R, int S>
+__device__ __forceinline__ c32 mul_wconst(c32 a) {
+    constexpr int s32 = S * (32 / R);
+    if constexpr (s32 == 0) return a;
+    else if constexpr (s32 == 8) return make_float2(-a.y, a.x);              // * i
+    else if constexpr (s32 == 4) {                                            // * (1+i)/sqrt2
+        constexpr float h = 0.7071067811865476f;
+        return make_float2((a.x - a.y) * h, (a.x + a.y) * h);
+    } else if constexpr (s32 == 12) {                                         // * (-1+i)/sqrt2
+        constexpr float h = 0.7071067811865476f;
+        return make_float2(-(a.x + a.y) * h, (a.x - a.y) * h);
+    } else {
+        return cmul(a, make_float2(W32<s32>::c, W32<s32>::s));
+    }
+}
+
+// In-register R-point unnormalised inverse DFT, natural order in and out (DIT recursion).
+template <int R> struct Dft;
+template <> struct Dft<1> {
+    static __device__ __forceinline__ void run(const c32 (&in)[1], c32 (&out)[1]) { out[0] = in[0]; }
+};
+template <> struct Dft<2> {
+    static __device__ __forceinline__ void run(const c32 (&in)[2], c32 (&out)[2]) {
+        out[0] = cadd(in[0], in[1]);
+        out[1] = csub(in[0], in[1]);
+    }
+};
+template <> struct Dft<4> {
+    static __device__ __forceinline__ void run(const c32 (&in)[4], c32 (&out)[4]) {
+        const c32 t0 = cadd(in[0], in[2]), t1 = csub(in[0], in[2]);
+        const c32 t2 = cadd(in[1], in[3]), t3 = csub(in[1], in[3]);
+        const c32 it3 = make_float2(-t3.y, t3.x);                              // i * t3
+        out[0] = cadd(t0, t2);
+        out[2] = csub(t0, t2);
+        out[1] = cadd(t1, it3);
+        out[3] = csub(t1, it3);
+    }
+};
+template <int R, int S> struct Combine {
+    static __device__ __forceinline__ void run(const c32 (&ev)[R / 2], const c32 (&od)[R / 2], c32 (&out)[R]) {
+        const c32 t = mul_wconst<R, S>(od[S]);
+        out[S] = cadd(ev[S], t);
+        out[S + R / 2] = csub(ev[S], t);
+        if constexpr (S + 1 < R / 2) Combine<R, S + 1>::run(ev, od, out);
+    }
+};
+template <int R> struct Dft {
+    static __device__ __forceinline__ void run(const c32 (&in)[R], c32 (&out)[R]) {
+        c32 e[R / 2], o[R / 2], ev[R / 2], od[R / 2];
+#pragma unroll
+        for (int t = 0; t < R / 2; ++t) { e[t] = in[2 * t]; o[t] = in[2 * t + 1]; }
+        Dft<R / 2>::run(e, ev);
+        Dft<R / 2>::run(o, od);
+        Combine<R, 0>::run(ev, od, out);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Compile-time plan: radices = [N / E^q (if > 1), E, E, ...]   (small radix first: no twiddles)
+// ---------------------------------------------------------------------------------------------
+template <int N, int E> struct Plan {
+    static constexpr int full_passes() { int n = N, c = 0; while (n >= E && n % E == 0) { n /= E; ++c; } return c; }
+    static constexpr int first_radix() { int n = N; while (n >= E && n % E == 0) n /= E; return n; }  // 1 if none
+    static constexpr int T = N / E;
+    static_assert(N % E == 0, "N must be a multiple of E");
+};
+
+// LDS padding: one element per 16 keeps every pass' scatter conflict-free for ds_write_b64
+// (16-lane groups, 32 banks) -- see DESIGN.md "LDS exchange".
+__device__ __forceinline__ int lds_pad(int i) { return i + (i >> 4); }
+template <int N> struct LdsLine { static constexpr int elems = N + (N >> 4); };
+
+// w^0..w^(R-1) from w by a shallow product tree (depth <= 4 for R = 16, <= 5 for 32).
+template <int R>
+__device__ __forceinline__ void twiddle_powers(c32 w, c32 (&p)[R]) {
+    p[0] = make_float2(1.0f, 0.0f);
+    if constexpr (R > 1) p[1] = w;
+#pragma unroll
+    for (int t = 2; t < R; ++t) {
+        // t = hi + lo with hi the largest power of two <= t (hi itself = (hi/2)+(hi/2))
+        int hi = 1;
+        while (hi * 2 <= t) hi *= 2;
+        const int lo = t - hi;
+        p[t] = (lo == 0) ? cmul(p[hi / 2], p[hi / 2]) : cmul(p[hi], p[lo]);
+    }
+}
+
+// One pass of radix R over the E registers of thread j.  `emit(pos, padded_pos, value, slot)`
+// receives every output with its line position, its padded LDS index and the register slot it
+// would occupy after the exchange of the last pass.
+template <int N, int E, int R, int NS, class Emit>
+__device__ __forceinline__ void fft_pass(c32 (&reg)[E], int j, const c32* __restrict__ tw, Emit&& emit) {
+    constexpr int T = N / E;
+    constexpr int U = E / R;
+    c32 pw[R];
+    if constexpr (NS > 1 && U == 1) {
+        const int k = j & (NS - 1);
+        twiddle_powers<R>(tw[k * (N / (NS * R))], pw);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int jv = j + u * T;
+        const int k = jv & (NS - 1);
+        if constexpr (NS > 1 && U > 1) twiddle_powers<R>(tw[k * (N / (NS * R))], pw);
+        c32 a[R], b[R];
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            a[t] = reg[u + t * U];
+            if constexpr (NS > 1) { if (t > 0) a[t] = cmul(a[t], pw[t]); }
+        }
+        Dft<R>::run(a, b);
+        const int base = (jv / NS) * (NS * R) + k;
+        // lds_pad(base + s*NS) == lds_pad(base) + s*NS + ((s*NS) >> 4) for power-of-two NS, R
+        // (one base VGPR + immediates instead of R address registers)
+        const int pbase = lds_pad(base);
+#pragma unroll
+        for (int s = 0; s < R; ++s) emit(base + s * NS, pbase + s * NS + ((s * NS) >> 4), b[s], u + s * U);
+    }
+}
+
+// Exchange through one padded LDS line buffer: scatter `reg` outputs of a pass, then gather
+// positions j + e*T.  `bar()` is the workgroup barrier (all threads of the WG call it).
+template <int N, int E, int R, int NS>
+__device__ __forceinline__ void fft_pass_exchange(c32 (&reg)[E], int j, const c32* __restrict__ tw, c32* lds_line) {
+    constexpr int T = N / E;
+    fft_pass<N, E, R, NS>(reg, j, tw, [&](int, int ppos, c32 v, int) { lds_line[ppos] = v; });
+    __syncthreads();
+    // lds_pad(j + e*T) == lds_pad(j) + e*(T + T/16)   (T is a multiple of 16)
+    const c32* g = lds_line + lds_pad(j);
+#pragma unroll
+    for (int e = 0; e < E; ++e) reg[e] = g[e * (T + T / 16)];
+}
+
+// Whole line transform.  On entry reg[e] = x[j + e*T]; on exit reg[e] = X[j + e*T].
+// lds_line: LdsLine<N>::elems c32 owned by this line.  Every thread of the workgroup must call
+// this the same number of times (it contains __syncthreads()).
+template <int N, int E>
+__device__ __forceinline__ void fft_line(c32 (&reg)[E], int j, const c32* __restrict__ tw, c32* lds_line) {
+    constexpr int R0 = Plan<N, E>::first_radix();
+    constexpr int Q = Plan<N, E>::full_passes();
+    static_assert(Q >= 1 && Q <= 3, "unsupported N/E combination");
+    int ns = 1;
+    (void)ns;
+    if constexpr (R0 > 1) {
+        fft_pass_exchange<N, E, R0, 1>(reg, j, tw, lds_line);
+        __syncthreads();   // WAR: next scatter reuses the buffer
+    }
+    constexpr int NS1 = R0;                  // after the optional small pass
+    if constexpr (Q == 1) {
+        c32 out[E];
+        fft_pass<N, E, E, NS1>(reg, j, tw, [&](int, int, c32 v, int slot) { out[slot] = v; });
+#pragma unroll
+        for (int e = 0; e < E; ++e) reg[e] = out[e];
+    } else {
+        fft_pass_exchange<N, E, E, NS1>(reg, j, tw, lds_line);
+        constexpr int NS2 = NS1 * E;
+        if constexpr (Q == 2) {
+            c32 out[E];
+            fft_pass<N, E, E, NS2>(reg, j, tw, [&](int, int, c32 v, int slot) { out[slot] = v; });
+#pragma unroll
+            for (int e = 0; e < E; ++e) reg[e] = out[e];
+        } else {
+            __syncthreads();
+            fft_pass_exchange<N, E, E, NS2>(reg, j, tw, lds_line);
+            constexpr int NS3 = NS2 * E;
+            c32 out[E];
+            fft_pass<N, E, E, NS3>(reg, j, tw, [&](int, int, c32 v, int slot) { out[slot] = v; });
+#pragma unroll
+            for (int e = 0; e < E; ++e) reg[e] = out[e];
+        }
+    }
+}
+
+// Same transform, but the final pass scatters into the LDS line (padded positions) and the
+// function returns after a barrier: lds_line[lds_pad(n)] = X[n] for the whole line.  Used when
+// the global store wants a different thread->element mapping than the FFT's (chunked layouts).
+template <int N, int E>
+__device__ __forceinline__ void fft_line_to_lds(c32 (&reg)[E], int j, const c32* __restrict__ tw, c32* lds_line) {
+    constexpr int R0 = Plan<N, E>::first_radix();
+    constexpr int Q = Plan<N, E>::full_passes();
+    static_assert(Q >= 2 && Q <= 3, "unsupported N/E combination");
+    if constexpr (R0 > 1) {
+        fft_pass_exchange<N, E, R0, 1>(reg, j, tw, lds_line);
+        __syncthreads();
+    }
+    constexpr int NS1 = R0;
+    fft_pass_exchange<N, E, E, NS1>(reg, j, tw, lds_line);
+    __syncthreads();
+    constexpr int NS2 = NS1 * E;
+    if constexpr (Q == 2) {
+        fft_pass<N, E, E, NS2>(reg, j, tw, [&](int, int ppos, c32 v, int) { lds_line[ppos] = v; });
+    } else {
+        fft_pass_exchange<N, E, E, NS2>(reg, j, tw, lds_line);
+        __syncthreads();
+        constexpr int NS3 = NS2 * E;
+        fft_pass<N, E, E, NS3>(reg, j, tw, [&](int, int ppos, c32 v, int) { lds_line[ppos] = v; });
+    }
+    __syncthreads();
+}
+
+}  // namespace ocean

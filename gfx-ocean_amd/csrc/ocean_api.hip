@@ -1,0 +1,461 @@
+// ocean_api.hip -- C ABI (include/ocean_hip.h) over the gfx950 kernels.
+//
+// Replaces, for the compute path only, what `Renderer::new` / `Renderer::render` do in the
+// reference: buffer allocation (src/render.rs:607-670), staging upload (:742-924), descriptor
+// wiring (:933-988) and the 8 dispatches + 4 barriers per frame (:1122-1310).  Barriers become
+// stream order; descriptor sets become plain device pointers held by the context.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/ocean_hip.h"
+#include "ocean_kernels.hpp"
+
+using namespace ocean;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+constexpr uint32_t MAGIC_CTX = 0x4F43454E;   // 'OCEN'
+constexpr uint32_t MAGIC_FFT = 0x4F464654;
+constexpr uint32_t MAGIC_PRO = 0x4F50524F;
+constexpr uint32_t MAGIC_COR = 0x4F434F52;
+
+bool supported_n(int n) { return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096 || n == 8192; }
+
+}  // namespace
+
+struct OceanContext {
+    uint32_t magic = MAGIC_CTX;
+    int device = 0;
+    int n = 0;
+    hipStream_t stream = nullptr;
+    // natural-layout buffers of the staged path (src/render.rs:608-670)
+    c32* h0 = nullptr;          // initial_spec
+    float* omega = nullptr;     // omega_buffer
+    c32* field[3] = {nullptr, nullptr, nullptr};   // dx_spec, dy_spec, dz_spec
+    // fused path: transposed static inputs + chunked intermediate
+    c32* h0T = nullptr;
+    float* omegaT = nullptr;
+    c32* inter = nullptr;
+    size_t slab = 0, field_stride = 0;
+    int P = 0;
+    c32* tw = nullptr;          // e^{+2 pi i k/N}
+    float4* out_own = nullptr;  // displacement map (src/render.rs:820-869), linear RGBA32F
+    float4* out = nullptr;      // = out_own or the caller's buffer (ocean_bind_displacement)
+    bool uploaded = false;
+    float default_domain = 1000.0f;   // src/render.rs:46
+    std::string err;
+};
+struct OceanFft { uint32_t magic = MAGIC_FFT; OceanContext* ctx = nullptr; };
+struct OceanPropagation { uint32_t magic = MAGIC_PRO; OceanContext* ctx = nullptr; };
+struct OceanCorrection { uint32_t magic = MAGIC_COR; OceanContext* ctx = nullptr; };
+
+namespace {
+
+int32_t fail(OceanContext* ctx, int32_t code, const std::string& msg) {
+    if (ctx) ctx->err = msg; else g_create_error = msg;
+    return code;
+}
+int32_t hip_fail(OceanContext* ctx, hipError_t e, const char* what) {
+    const int32_t code = (e == hipErrorOutOfMemory) ? OCEAN_E_OOM : OCEAN_E_HIP;
+    return fail(ctx, code, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(ctx, expr)                                              \
+    do {                                                                \
+        hipError_t e_ = (expr);                                         \
+        if (e_ != hipSuccess) return hip_fail((ctx), e_, #expr);        \
+    } while (0)
+
+bool valid(const OceanContext* c) { return c && c->magic == MAGIC_CTX; }
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) { (void)hipGetDevice(&prev); if (prev != dev) (void)hipSetDevice(dev); else prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+// ---- per-N launchers ------------------------------------------------------------------------
+template <int N> struct Launch {
+    using G = Geo<N>;
+    static hipError_t prepare() {
+        hipError_t e;
+        e = hipFuncSetAttribute((const void*)k_fft_lines<N, G::E, G::ROW_LPW, false>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, G::row_lds);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)k_fft_lines<N, G::E, G::COL_LPW, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, G::col_lds);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)k_frame_pass1<N, G::E, G::P>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, G::frame_lds);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)k_frame_pass2<N, G::E, G::P>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, G::frame_lds);
+        return e;
+    }
+    static void rows(OceanContext* c, c32* data, hipStream_t s) {
+        hipLaunchKernelGGL((k_fft_lines<N, G::E, G::ROW_LPW, false>), dim3(G::row_grid), dim3(G::row_threads),
+                           G::row_lds, s, data, c->tw);
+    }
+    static void cols(OceanContext* c, c32* data, hipStream_t s) {
+        hipLaunchKernelGGL((k_fft_lines<N, G::E, G::COL_LPW, true>), dim3(G::col_grid), dim3(G::col_threads),
+                           G::col_lds, s, data, c->tw);
+    }
+    static void pass1(OceanContext* c, float time, float domain, hipStream_t s) {
+        hipLaunchKernelGGL((k_frame_pass1<N, G::E, G::P>), dim3(G::frame_grid), dim3(G::frame_threads),
+                           G::frame_lds, s, c->h0T, c->omegaT, c->inter, c->tw, c->slab, c->field_stride, time, domain);
+    }
+    static void pass2(OceanContext* c, hipStream_t s) {
+        hipLaunchKernelGGL((k_frame_pass2<N, G::E, G::P>), dim3(G::frame_grid), dim3(G::frame_threads),
+                           G::frame_lds, s, c->inter, c->out, c->tw, c->slab, c->field_stride);
+    }
+};
+
+#define OCEAN_DISPATCH(n, STMT)                           \
+    switch (n) {                                          \
+        case 256: { using L = Launch<256>; STMT; } break;   \
+        case 512: { using L = Launch<512>; STMT; } break;   \
+        case 1024: { using L = Launch<1024>; STMT; } break; \
+        case 2048: { using L = Launch<2048>; STMT; } break; \
+        case 4096: { using L = Launch<4096>; STMT; } break; \
+        case 8192: { using L = Launch<8192>; STMT; } break; \
+        default: break;                                   \
+    }
+
+int frame_p(int n) { int p = 0; OCEAN_DISPATCH(n, p = L::G::P); return p; }
+
+hipStream_t pick(OceanContext* c, void* stream) { return stream ? (hipStream_t)stream : c->stream; }
+
+void launch_propagate(OceanContext* c, float time, float domain, hipStream_t s) {
+    const unsigned grid = (unsigned)(((size_t)c->n * c->n / 2 + 255) / 256);
+    hipLaunchKernelGGL(k_propagate, dim3(grid), dim3(256), 0, s, c->h0, c->omega, c->field[OCEAN_FIELD_DY],
+                       c->field[OCEAN_FIELD_DX], c->field[OCEAN_FIELD_DZ], c->n, time, domain);
+}
+void launch_correct(OceanContext* c, hipStream_t s) {
+    const unsigned grid = (unsigned)(((size_t)c->n * c->n / 2 + 255) / 256);
+    hipLaunchKernelGGL(k_correct, dim3(grid), dim3(256), 0, s, c->field[OCEAN_FIELD_DY], c->field[OCEAN_FIELD_DX],
+                       c->field[OCEAN_FIELD_DZ], c->out, c->n);
+}
+void launch_rows(OceanContext* c, int f, hipStream_t s) { OCEAN_DISPATCH(c->n, L::rows(c, c->field[f], s)); }
+void launch_cols(OceanContext* c, int f, hipStream_t s) { OCEAN_DISPATCH(c->n, L::cols(c, c->field[f], s)); }
+void launch_frame(OceanContext* c, float time, float domain, hipStream_t s) {
+    OCEAN_DISPATCH(c->n, { L::pass1(c, time, domain, s); L::pass2(c, s); });
+}
+
+int32_t check_launch(OceanContext* c, const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(c, e, what);
+    return OCEAN_OK;
+}
+
+void free_all(OceanContext* c) {
+    auto f = [](void* p) { if (p) (void)hipFree(p); };
+    f(c->h0); f(c->omega); f(c->field[0]); f(c->field[1]); f(c->field[2]);
+    f(c->h0T); f(c->omegaT); f(c->inter); f(c->tw); f(c->out_own);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t ocean_abi_version(void) { return OCEAN_ABI_VERSION; }
+
+int32_t ocean_context_create(int32_t device, int32_t resolution, OceanContext** out_ctx) {
+    if (!out_ctx) return fail(nullptr, OCEAN_E_INVALID_ARG, "out_ctx is NULL");
+    *out_ctx = nullptr;
+    if (!supported_n(resolution))
+        return fail(nullptr, OCEAN_E_UNSUPPORTED_N, "resolution must be a power of two in [256, 8192]");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess) return hip_fail(nullptr, e, "hipGetDeviceCount");
+    if (device < 0 || device >= count) return fail(nullptr, OCEAN_E_INVALID_ARG, "no such HIP device");
+    OceanContext* c = new (std::nothrow) OceanContext();
+    if (!c) return fail(nullptr, OCEAN_E_OOM, "host allocation failed");
+    c->device = device;
+    c->n = resolution;
+    DeviceGuard guard(device);
+    const size_t n2 = (size_t)resolution * resolution;
+    c->P = frame_p(resolution);
+    // slab = one x-group of the intermediate (N rows x P columns); +32 elements (256 B) so that
+    // consecutive slabs do not start on the same channel for the strided chunk reads of pass 2
+    c->slab = (size_t)resolution * c->P + 32;
+    c->field_stride = c->slab * (size_t)(resolution / c->P);
+    auto bail = [&](hipError_t err, const char* what) {
+        const int32_t code = hip_fail(nullptr, err, what);
+        free_all(c);
+        delete c;
+        return code;
+    };
+#define CTX_TRY(expr) do { hipError_t e2_ = (expr); if (e2_ != hipSuccess) return bail(e2_, #expr); } while (0)
+    CTX_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CTX_TRY(hipMalloc((void**)&c->h0, n2 * sizeof(c32)));
+    CTX_TRY(hipMalloc((void**)&c->omega, n2 * sizeof(float)));
+    for (int f = 0; f < 3; ++f) CTX_TRY(hipMalloc((void**)&c->field[f], n2 * sizeof(c32)));
+    CTX_TRY(hipMalloc((void**)&c->h0T, n2 * sizeof(c32)));
+    CTX_TRY(hipMalloc((void**)&c->omegaT, n2 * sizeof(float)));
+    CTX_TRY(hipMalloc((void**)&c->inter, 3 * c->field_stride * sizeof(c32)));
+    CTX_TRY(hipMalloc((void**)&c->out_own, n2 * sizeof(float4)));
+    CTX_TRY(hipMalloc((void**)&c->tw, (size_t)resolution * sizeof(c32)));
+    c->out = c->out_own;
+    {
+        std::vector<c32> tw((size_t)resolution);
+        for (int i = 0; i < resolution; ++i) {
+            const double a = 2.0 * M_PI * (double)i / (double)resolution;
+            tw[(size_t)i] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+        CTX_TRY(hipMemcpy(c->tw, tw.data(), tw.size() * sizeof(c32), hipMemcpyHostToDevice));
+    }
+    {
+        hipError_t pe = hipSuccess;
+        OCEAN_DISPATCH(resolution, pe = L::prepare());
+        if (pe != hipSuccess) return bail(pe, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    }
+#undef CTX_TRY
+    *out_ctx = c;
+    return OCEAN_OK;
+}
+
+void ocean_context_destroy(OceanContext* ctx) {
+    if (!valid(ctx)) return;
+    DeviceGuard guard(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    free_all(ctx);
+    ctx->magic = 0;
+    delete ctx;
+}
+
+const char* ocean_last_error(const OceanContext* ctx) {
+    if (valid(ctx)) return ctx->err.c_str();
+    return g_create_error.c_str();
+}
+
+int32_t ocean_resolution(const OceanContext* ctx) { return valid(ctx) ? ctx->n : OCEAN_E_INVALID_ARG; }
+
+int32_t ocean_upload_spectrum(OceanContext* ctx, const float* h0_re_im, const float* omega) {
+    if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    if (!h0_re_im || !omega) return fail(ctx, OCEAN_E_INVALID_ARG, "NULL input");
+    DeviceGuard guard(ctx->device);
+    const size_t n = (size_t)ctx->n, n2 = n * n;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(ctx->h0, h0_re_im, n2 * sizeof(c32), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->omega, omega, n2 * sizeof(float), hipMemcpyHostToDevice));
+    // one-time re-layout for the fused path: h0T[x][y] = h0[y][x] (blocked host transpose)
+    std::vector<c32> tT;
+    std::vector<float> oT;
+    try { tT.resize(n2); oT.resize(n2); } catch (...) { return fail(ctx, OCEAN_E_OOM, "host staging allocation failed"); }
+    const c32* src = reinterpret_cast<const c32*>(h0_re_im);
+    constexpr size_t B = 32;
+    for (size_t y0 = 0; y0 < n; y0 += B)
+        for (size_t x0 = 0; x0 < n; x0 += B)
+            for (size_t y = y0; y < y0 + B; ++y)
+                for (size_t x = x0; x < x0 + B; ++x) {
+                    tT[x * n + y] = src[y * n + x];
+                    oT[x * n + y] = omega[y * n + x];
+                }
+    HIP_TRY(ctx, hipMemcpy(ctx->h0T, tT.data(), n2 * sizeof(c32), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->omegaT, oT.data(), n2 * sizeof(float), hipMemcpyHostToDevice));
+    ctx->uploaded = true;
+    return OCEAN_OK;
+}
+
+// ---- stage objects ----------------------------------------------------------------------------
+int32_t ocean_fft_init(OceanContext* ctx, OceanFft** out) {
+    if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    if (!out) return fail(ctx, OCEAN_E_INVALID_ARG, "out is NULL");
+    OceanFft* f = new (std::nothrow) OceanFft();
+    if (!f) return fail(ctx, OCEAN_E_OOM, "host allocation failed");
+    f->ctx = ctx;
+    *out = f;
+    return OCEAN_OK;
+}
+void ocean_fft_destroy(OceanFft* fft) { if (fft && fft->magic == MAGIC_FFT) { fft->magic = 0; delete fft; } }
+
+int32_t ocean_propagation_init(OceanContext* ctx, OceanPropagation** out) {
+    if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    if (!out) return fail(ctx, OCEAN_E_INVALID_ARG, "out is NULL");
+    OceanPropagation* p = new (std::nothrow) OceanPropagation();
+    if (!p) return fail(ctx, OCEAN_E_OOM, "host allocation failed");
+    p->ctx = ctx;
+    *out = p;
+    return OCEAN_OK;
+}
+void ocean_propagation_destroy(OceanPropagation* p) { if (p && p->magic == MAGIC_PRO) { p->magic = 0; delete p; } }
+
+int32_t ocean_correction_init(OceanContext* ctx, OceanCorrection** out) {
+    if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    if (!out) return fail(ctx, OCEAN_E_INVALID_ARG, "out is NULL");
+    OceanCorrection* c = new (std::nothrow) OceanCorrection();
+    if (!c) return fail(ctx, OCEAN_E_OOM, "host allocation failed");
+    c->ctx = ctx;
+    *out = c;
+    return OCEAN_OK;
+}
+void ocean_correction_destroy(OceanCorrection* c) { if (c && c->magic == MAGIC_COR) { c->magic = 0; delete c; } }
+
+// ---- dispatches ---------------------------------------------------------------------------------
+int32_t ocean_propagate(OceanPropagation* p, const OceanPropagateLocals* locals, void* stream) {
+    if (!p || p->magic != MAGIC_PRO || !valid(p->ctx)) return OCEAN_E_INVALID_ARG;
+    OceanContext* c = p->ctx;
+    if (!locals) return fail(c, OCEAN_E_INVALID_ARG, "locals is NULL");
+    if (locals->resolution != c->n) return fail(c, OCEAN_E_INVALID_ARG, "PropagateLocals.resolution != context resolution");
+    if (!(locals->domain_size > 0.0f)) return fail(c, OCEAN_E_INVALID_ARG, "domain_size must be > 0");
+    if (!c->uploaded) return fail(c, OCEAN_E_STATE, "ocean_upload_spectrum has not been called");
+    DeviceGuard guard(c->device);
+    launch_propagate(c, locals->time, locals->domain_size, pick(c, stream));
+    return check_launch(c, "k_propagate launch");
+}
+
+static int32_t fft_pass_common(OceanFft* fft, int32_t field, void* stream, bool cols) {
+    if (!fft || fft->magic != MAGIC_FFT || !valid(fft->ctx)) return OCEAN_E_INVALID_ARG;
+    OceanContext* c = fft->ctx;
+    if (field != OCEAN_FIELD_ALL && (field < 0 || field > 2)) return fail(c, OCEAN_E_INVALID_ARG, "bad field selector");
+    DeviceGuard guard(c->device);
+    hipStream_t s = pick(c, stream);
+    // reference order of the three descriptor sets: dx, dy, dz (src/render.rs:1158-1179)
+    for (int f = 0; f < 3; ++f)
+        if (field == OCEAN_FIELD_ALL || field == f) { if (cols) launch_cols(c, f, s); else launch_rows(c, f, s); }
+    return check_launch(c, cols ? "k_fft_lines<COL> launch" : "k_fft_lines<ROW> launch");
+}
+int32_t ocean_fft_rows(OceanFft* fft, int32_t field, void* stream) { return fft_pass_common(fft, field, stream, false); }
+int32_t ocean_fft_cols(OceanFft* fft, int32_t field, void* stream) { return fft_pass_common(fft, field, stream, true); }
+
+int32_t ocean_correct(OceanCorrection* cor, const OceanCorrectionLocals* locals, void* stream) {
+    if (!cor || cor->magic != MAGIC_COR || !valid(cor->ctx)) return OCEAN_E_INVALID_ARG;
+    OceanContext* c = cor->ctx;
+    if (!locals) return fail(c, OCEAN_E_INVALID_ARG, "locals is NULL");
+    if (locals->resolution != (uint32_t)c->n) return fail(c, OCEAN_E_INVALID_ARG, "CorrectionLocals.resolution != context resolution");
+    DeviceGuard guard(c->device);
+    launch_correct(c, pick(c, stream));
+    return check_launch(c, "k_correct launch");
+}
+
+int32_t ocean_frame_ex(OceanContext* ctx, const OceanPropagateLocals* locals, void* stream) {
+    if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    if (!locals) return fail(ctx, OCEAN_E_INVALID_ARG, "locals is NULL");
+    if (locals->resolution != ctx->n) return fail(ctx, OCEAN_E_INVALID_ARG, "PropagateLocals.resolution != context resolution");
+    if (!(locals->domain_size > 0.0f)) return fail(ctx, OCEAN_E_INVALID_ARG, "domain_size must be > 0");
+    if (!ctx->uploaded) return fail(ctx, OCEAN_E_STATE, "ocean_upload_spectrum has not been called");
+    DeviceGuard guard(ctx->device);
+    launch_frame(ctx, locals->time, locals->domain_size, pick(ctx, stream));
+    return check_launch(ctx, "k_frame_pass1/2 launch");
+}
+int32_t ocean_frame(OceanContext* ctx, float time, void* stream) {
+    if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    OceanPropagateLocals l{time, ctx->n, ctx->default_domain};
+    return ocean_frame_ex(ctx, &l, stream);
+}
+
+int32_t ocean_sync(OceanContext* ctx) {
+    if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return OCEAN_OK;
+}
+
+// ---- readback / injection ---------------------------------------------------------------------
+int32_t ocean_read_displacement(OceanContext* ctx, float* host_rgba) {
+    if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    if (!host_rgba) return fail(ctx, OCEAN_E_INVALID_ARG, "NULL output");
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(host_rgba, ctx->out, (size_t)ctx->n * ctx->n * sizeof(float4), hipMemcpyDeviceToHost));
+    return OCEAN_OK;
+}
+int32_t ocean_read_field(OceanContext* ctx, int32_t field, float* host_re_im) {
+    if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    if (!host_re_im || field < 0 || field > 2) return fail(ctx, OCEAN_E_INVALID_ARG, "bad field or NULL output");
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(host_re_im, ctx->field[field], (size_t)ctx->n * ctx->n * sizeof(c32), hipMemcpyDeviceToHost));
+    return OCEAN_OK;
+}
+int32_t ocean_write_field(OceanContext* ctx, int32_t field, const float* host_re_im) {
+    if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    if (!host_re_im || field < 0 || field > 2) return fail(ctx, OCEAN_E_INVALID_ARG, "bad field or NULL input");
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(ctx->field[field], host_re_im, (size_t)ctx->n * ctx->n * sizeof(c32), hipMemcpyHostToDevice));
+    return OCEAN_OK;
+}
+
+void* ocean_displacement_device_ptr(OceanContext* ctx) { return valid(ctx) ? (void*)ctx->out : nullptr; }
+int32_t ocean_bind_displacement(OceanContext* ctx, void* device_rgba) {
+    if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    if (device_rgba && (reinterpret_cast<uintptr_t>(device_rgba) & 15u))
+        return fail(ctx, OCEAN_E_INVALID_ARG, "displacement buffer must be 16-byte aligned");
+    ctx->out = device_rgba ? (float4*)device_rgba : ctx->out_own;
+    return OCEAN_OK;
+}
+void* ocean_stream(OceanContext* ctx) { return valid(ctx) ? (void*)ctx->stream : nullptr; }
+
+// ---- measurement ----------------------------------------------------------------------------------
+int32_t ocean_time_frames(OceanContext* ctx, int32_t frames, float t0, float dt, float* out_ms) {
+    if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    if (frames <= 0 || !out_ms) return fail(ctx, OCEAN_E_INVALID_ARG, "frames must be > 0 and out_ms non-NULL");
+    if (!ctx->uploaded) return fail(ctx, OCEAN_E_STATE, "ocean_upload_spectrum has not been called");
+    DeviceGuard guard(ctx->device);
+    hipEvent_t a, b;
+    HIP_TRY(ctx, hipEventCreate(&a));
+    HIP_TRY(ctx, hipEventCreate(&b));
+    HIP_TRY(ctx, hipEventRecord(a, ctx->stream));
+    for (int i = 0; i < frames; ++i) launch_frame(ctx, t0 + dt * (float)i, ctx->default_domain, ctx->stream);
+    HIP_TRY(ctx, hipEventRecord(b, ctx->stream));
+    HIP_TRY(ctx, hipEventSynchronize(b));
+    HIP_TRY(ctx, hipEventElapsedTime(out_ms, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    return check_launch(ctx, "ocean_time_frames");
+}
+
+static int32_t profile_common(OceanContext* ctx, float time, int32_t cap, const char** names, float* ms,
+                              int32_t* out_n, bool staged) {
+    if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    if (!names || !ms || !out_n) return fail(ctx, OCEAN_E_INVALID_ARG, "NULL output");
+    if (!ctx->uploaded) return fail(ctx, OCEAN_E_STATE, "ocean_upload_spectrum has not been called");
+    static const char* kStaged[8] = {"k_propagate", "k_fft_lines<ROW> dx", "k_fft_lines<ROW> dy", "k_fft_lines<ROW> dz",
+                                     "k_fft_lines<COL> dx", "k_fft_lines<COL> dy", "k_fft_lines<COL> dz", "k_correct"};
+    static const char* kFused[2] = {"k_frame_pass1", "k_frame_pass2"};
+    const int count = staged ? 8 : 2;
+    if (cap < count) return fail(ctx, OCEAN_E_INVALID_ARG, "capacity too small");
+    DeviceGuard guard(ctx->device);
+    hipStream_t s = ctx->stream;
+    hipEvent_t ev[9];
+    for (int i = 0; i <= count; ++i) HIP_TRY(ctx, hipEventCreate(&ev[i]));
+    HIP_TRY(ctx, hipEventRecord(ev[0], s));
+    if (staged) {
+        launch_propagate(ctx, time, ctx->default_domain, s);
+        HIP_TRY(ctx, hipEventRecord(ev[1], s));
+        for (int f = 0; f < 3; ++f) { launch_rows(ctx, f, s); HIP_TRY(ctx, hipEventRecord(ev[2 + f], s)); }
+        for (int f = 0; f < 3; ++f) { launch_cols(ctx, f, s); HIP_TRY(ctx, hipEventRecord(ev[5 + f], s)); }
+        launch_correct(ctx, s);
+        HIP_TRY(ctx, hipEventRecord(ev[8], s));
+    } else {
+        OCEAN_DISPATCH(ctx->n, L::pass1(ctx, time, ctx->default_domain, s));
+        HIP_TRY(ctx, hipEventRecord(ev[1], s));
+        OCEAN_DISPATCH(ctx->n, L::pass2(ctx, s));
+        HIP_TRY(ctx, hipEventRecord(ev[2], s));
+    }
+    HIP_TRY(ctx, hipEventSynchronize(ev[count]));
+    for (int i = 0; i < count; ++i) {
+        names[i] = staged ? kStaged[i] : kFused[i];
+        HIP_TRY(ctx, hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
+    }
+    for (int i = 0; i <= count; ++i) (void)hipEventDestroy(ev[i]);
+    *out_n = count;
+    return check_launch(ctx, "profile");
+}
+int32_t ocean_profile_frame(OceanContext* ctx, float time, int32_t cap, const char** names, float* ms, int32_t* out_n) {
+    return profile_common(ctx, time, cap, names, ms, out_n, false);
+}
+int32_t ocean_profile_staged(OceanContext* ctx, float time, int32_t cap, const char** names, float* ms, int32_t* out_n) {
+    return profile_common(ctx, time, cap, names, ms, out_n, true);
+}
+
+}  // extern "C"

@@ -1,0 +1,310 @@
+// ocean_kernels.hpp -- the gfx950 kernels of the gfx-ocean hot path.
+//
+// Staged kernels (1:1 with the reference dispatches, natural layouts, in place):
+//   k_propagate      <- shader/propagate.comp:42-72
+//   k_fft_lines<ROW> <- shader/fft_row.comp:44-63
+//   k_fft_lines<COL> <- shader/fft_col.comp:44-63
+//   k_correct        <- shader/correction.comp:24-35
+// Fused frame (2 launches, 76 B/texel of HBM traffic instead of the reference's 172):
+//   k_frame_pass1: propagate + FFT along y for the three fields, reading the *transposed* static
+//                  inputs (h0T, omegaT; made once at upload) so every line is contiguous;
+//                  writes the intermediate in a [x/P][y][x%P] layout (P*P*8-byte chunks).
+//   k_frame_pass2: FFT along x of P rows per workgroup + sign correction + RGBA pack; full-row
+//                  contiguous float4 stores.
+// The column transform runs first in the fused path (a separable 2-D DFT commutes), so that the
+// pass that owns whole rows is the one that writes the row-major RGBA image.
+//
+// No launches in this header: it is also compiled by the host emulation harness
+// (tests/hipemu) that checks the index algebra on the CPU.
+#pragma once
+#include "fft_core.hpp"
+
+namespace ocean {
+
+// shader/propagate.comp:6 -- `const float pi = 3.1415926;` (fp32 0x40490FDA)
+#define OCEAN_PI_F 3.1415926f
+
+// Observed dispatch rule: block b runs on XCD b % 8.  Give each XCD a contiguous range of
+// logical work items so neighbours share an L2 (speed only; any mapping is correct).
+__device__ __forceinline__ int xcd_contiguous(int b, int nblocks) {
+    if ((nblocks & 7) != 0) return b;
+    return (b & 7) * (nblocks >> 3) + (b >> 3);
+}
+
+// Q1: float(uint(2*g - N - 1))  (shader/propagate.comp:45-46, wraps in uint32)
+__device__ __forceinline__ float wave_index_q1(uint32_t g, uint32_t n) {
+    return (float)(uint32_t)(2u * g - n - 1u);
+}
+
+// The per-texel math of propagate.comp:55-71, shared by the staged and the fused kernel.
+// h = h0 * e^{+i w t} + h0[index_neg] * e^{-i w t}   (:55-62; no conjugate, quirk Q2)
+__device__ __forceinline__ c32 propagate_height(c32 h0, c32 h0_neg, float omega, float time) {
+    const float disp = omega * time;                               // :55 (one fp32 multiply, as the shader)
+    // cos/sin of the fp32 phase, full range (phases reach 1e4..1e5 rad): reduce disp/(2 pi) to
+    // [-0.5, 0.5] in fp64 (exact to ~1e-12), then a pi-scaled sincos that needs no further
+    // reduction.  Abs error <= 2e-7; no Payne-Hanek slow path, a third of sincosf's registers.
+    const double rev = (double)disp * 0.15915494309189535;         // 1 / (2 pi)
+    const float half_turns = (float)(2.0 * (rev - rint(rev)));     // in [-1, 1]
+    float s, c;
+    sincospif(half_turns, &s, &c);
+    const c32 a = make_float2(h0.x * c - h0.y * s, h0.y * c + h0.x * s);                  // * (c, s)
+    const c32 b = make_float2(h0_neg.x * c + h0_neg.y * s, h0_neg.y * c - h0_neg.x * s);  // * (c,-s)
+    return make_float2(a.x + b.x, a.y + b.y);
+}
+// k_norm = k / length(k) if length(k) > 1e-10 else 0   (:64-67)
+__device__ __forceinline__ void k_normalised(float kx, float ky, float& knx, float& kny) {
+    const float len = sqrtf(kx * kx + ky * ky);
+    knx = 0.0f; kny = 0.0f;
+    if (len > 1.0e-10f) { knx = kx / len; kny = ky / len; }
+}
+// complex_mul(vec2(0, -kn), h) = (kn*h.y, -kn*h.x)   (:70-71)
+__device__ __forceinline__ c32 mul_minus_i_kn(float kn, c32 h) { return make_float2(kn * h.y, -kn * h.x); }
+
+// ---------------------------------------------------------------------------------------------
+// Staged kernels
+// ---------------------------------------------------------------------------------------------
+// One thread per 2 texels.  grid = N*N/2/256.
+__global__ void __launch_bounds__(256)
+k_propagate(const c32* __restrict__ h0, const float* __restrict__ omega, c32* __restrict__ height,
+            c32* __restrict__ disp_x, c32* __restrict__ disp_z, int n, float time, float domain_size) {
+    const uint32_t un = (uint32_t)n;
+    const uint32_t pair = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t total = un * un;
+    const uint32_t index = pair * 2u;
+    if (index >= total) return;
+    const uint32_t gx = index % un, gy = index / un;               // gx even, gx+1 same row
+    const float4 own = *reinterpret_cast<const float4*>(h0 + index);
+    // index_neg = N*N-1-index (:48); the pair (index, index+1) mirrors to (ineg, ineg-1)
+    const uint32_t ineg = total - 1u - index;
+    const float4 neg = *reinterpret_cast<const float4*>(h0 + (ineg - 1u));
+    const float2 om = *reinterpret_cast<const float2*>(omega + index);
+    const float ky = OCEAN_PI_F * wave_index_q1(gy, un) / domain_size;
+    const float kx0 = OCEAN_PI_F * wave_index_q1(gx, un) / domain_size;
+    const float kx1 = OCEAN_PI_F * wave_index_q1(gx + 1u, un) / domain_size;
+    const c32 h0v = propagate_height(make_float2(own.x, own.y), make_float2(neg.z, neg.w), om.x, time);
+    const c32 h1v = propagate_height(make_float2(own.z, own.w), make_float2(neg.x, neg.y), om.y, time);
+    float knx0, kny0, knx1, kny1;
+    k_normalised(kx0, ky, knx0, kny0);
+    k_normalised(kx1, ky, knx1, kny1);
+    const c32 dx0 = mul_minus_i_kn(knx0, h0v), dx1 = mul_minus_i_kn(knx1, h1v);
+    const c32 dz0 = mul_minus_i_kn(kny0, h0v), dz1 = mul_minus_i_kn(kny1, h1v);
+    *reinterpret_cast<float4*>(height + index) = make_float4(h0v.x, h0v.y, h1v.x, h1v.y);
+    *reinterpret_cast<float4*>(disp_x + index) = make_float4(dx0.x, dx0.y, dx1.x, dx1.y);
+    *reinterpret_cast<float4*>(disp_z + index) = make_float4(dz0.x, dz0.y, dz1.x, dz1.y);
+}
+
+// One thread per 2 texels.
+__global__ void __launch_bounds__(256)
+k_correct(const c32* __restrict__ height, const c32* __restrict__ disp_x, const c32* __restrict__ disp_z,
+          float4* __restrict__ out, int n) {
+    const uint32_t un = (uint32_t)n;
+    const uint32_t index = (blockIdx.x * 256u + threadIdx.x) * 2u;
+    if (index >= un * un) return;
+    const uint32_t x = index % un, y = index / un;
+    const float4 h = *reinterpret_cast<const float4*>(height + index);
+    const float4 dx = *reinterpret_cast<const float4*>(disp_x + index);
+    const float4 dz = *reinterpret_cast<const float4*>(disp_z + index);
+    const float s0 = (((x + y) & 1u) == 0u) ? -1.0f : 1.0f;        // correction.comp:29
+    const float s1 = -s0;
+    out[index] = make_float4(dx.x * s0, h.x * s0, dz.x * s0, 0.0f);
+    out[index + 1u] = make_float4(dx.z * s1, h.z * s1, dz.z * s1, 0.0f);
+}
+
+// LDS pitch of one line buffer: padded line + 4 elements so that P adjacent lines do not alias.
+template <int N> struct LinePitch { static constexpr int elems = LdsLine<N>::elems + 4; };
+
+// In-place line FFT on the natural layout.  LPW lines per workgroup (across threads).
+// ROW: line = row y, element pos at data[y*N + pos], threads of a line are contiguous lanes.
+// COL: line = column x, element pos at data[pos*N + x]; the LPW columns of a workgroup are
+//      adjacent and the line index is the fastest thread coordinate (8*LPW-byte pieces).
+template <int N, int E, int LPW, bool COL>
+__global__ void __launch_bounds__((N / E) * LPW)
+k_fft_lines(c32* __restrict__ data, const c32* __restrict__ tw) {
+    constexpr int T = N / E;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    c32* lds = reinterpret_cast<c32*>(smem);
+    const int tid = threadIdx.x;
+    const int ll = COL ? (tid % LPW) : ((T >= 64) ? wave_uniform(tid / T) : (tid / T));
+    const int j = COL ? (tid / LPW) : (tid % T);
+    const int group = COL ? xcd_contiguous(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int line = group * LPW + ll;
+    c32* lds_line = lds + ll * LinePitch<N>::elems;
+    c32 reg[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int pos = j + e * T;
+        reg[e] = COL ? data[(size_t)pos * N + line] : data[(size_t)line * N + pos];
+    }
+    fft_line<N, E>(reg, j, tw, lds_line);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int pos = j + e * T;
+        if (COL) data[(size_t)pos * N + line] = reg[e];
+        else data[(size_t)line * N + pos] = reg[e];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused frame
+// ---------------------------------------------------------------------------------------------
+// Intermediate layout of one field: inter[X * slab + y * P + c], X = x / P, c = x % P;
+// slab >= N*P elements (padded so that consecutive slabs do not start on the same HBM channel).
+// Field order in the intermediate: 0 = disp_x, 1 = height, 2 = disp_z (OCEAN_FIELD_*).
+
+// Map block -> x-group so that a group and its mirror (which read the same two h0T line sets)
+// run on the same XCD, 8 blocks apart.
+__device__ __forceinline__ int pass1_group(int b, int groups) {
+    if ((groups & 15) != 0) return b;
+    const int q = b >> 4, r = b & 15;
+    const int p = 8 * q + (r & 7);
+    return (r >> 3) ? (groups - 1 - p) : p;
+}
+
+template <int N, int E, int P>
+__global__ void __launch_bounds__((N / E) * P)
+k_frame_pass1(const c32* __restrict__ h0T, const float* __restrict__ omegaT, c32* __restrict__ inter,
+              const c32* __restrict__ tw, size_t slab, size_t field_stride, float time, float domain_size) {
+    constexpr int T = N / E;
+    constexpr int H2 = P / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    c32* lds = reinterpret_cast<c32*>(smem);
+    const int tid = threadIdx.x;
+    const int ll = (T >= 64) ? wave_uniform(tid / T) : (tid / T);   // a wave never straddles lines when T >= 64
+    const int j = tid % T;
+    const int X = pass1_group(blockIdx.x, gridDim.x);
+    const uint32_t x = (uint32_t)(X * P + ll);                     // gl_GlobalInvocationID.x
+    c32* lds_line = lds + ll * LinePitch<N>::elems;
+
+    // propagate.comp:42-72 along the transposed inputs: own line x, mirror line N-1-x reversed.
+    const c32* own = h0T + (size_t)x * N;
+    const c32* mir = h0T + (size_t)(N - 1 - x) * N;
+    const float* om = omegaT + (size_t)x * N;
+    const float kx = OCEAN_PI_F * wave_index_q1(x, N) / domain_size;
+    c32 hs[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int y = j + e * T;                                   // gl_GlobalInvocationID.y
+        hs[e] = propagate_height(own[y], mir[N - 1 - y], om[y], time);
+    }
+
+    c32* out_group = inter + (size_t)X * slab;
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+        c32 reg[E];
+        const int jf = opaque_lane(j);   // per-field copy of j: no CSE of twiddles / k_norm across fields
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (f == 1) reg[e] = hs[e];
+            else {
+                // k_norm is recomputed per field instead of kept: 2*E fewer live VGPRs
+                const float ky = OCEAN_PI_F * wave_index_q1((uint32_t)(jf + e * T), N) / domain_size;
+                float knx, kny;
+                k_normalised(kx, ky, knx, kny);
+                reg[e] = mul_minus_i_kn((f == 0) ? knx : kny, hs[e]);
+            }
+        }
+        if (f > 0) __syncthreads();                                // previous field's LDS reads done
+        fft_line_to_lds<N, E>(reg, jf, tw, lds_line);               // ends with data in LDS + barrier
+        // chunk-order store: thread -> (column pair h, position i + q*2T): 16-B lanes, contiguous
+        c32* dst = out_group + (size_t)f * field_stride;
+        const int h = tid % H2;
+        const int i = tid / H2;
+        const c32* l0 = lds + (2 * h) * LinePitch<N>::elems;
+        const c32* l1 = lds + (2 * h + 1) * LinePitch<N>::elems;
+#pragma unroll
+        for (int q = 0; q < E / 2; ++q) {
+            const int y = i + q * (2 * T);
+            const c32 v0 = l0[lds_pad(y)];
+            const c32 v1 = l1[lds_pad(y)];
+            *reinterpret_cast<float4*>(dst + (size_t)y * P + 2 * h) = make_float4(v0.x, v0.y, v1.x, v1.y);
+        }
+    }
+}
+
+template <int N, int E, int P>
+__global__ void __launch_bounds__((N / E) * P)
+k_frame_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32* __restrict__ tw,
+              size_t slab, size_t field_stride) {
+    constexpr int T = N / E;
+    constexpr int H2 = P / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    c32* lds = reinterpret_cast<c32*>(smem);
+    const int tid = threadIdx.x;
+    const int ll = (T >= 64) ? wave_uniform(tid / T) : (tid / T);
+    const int j = tid % T;
+    const int Y = blockIdx.x;
+    const int y = Y * P + ll;
+    c32* lds_line = lds + ll * LinePitch<N>::elems;
+
+    // chunk-order load coordinates: P*H2 consecutive threads read one P x P chunk (P*P*8 bytes)
+    const int h = tid % H2;
+    const int r = (tid / H2) % P;
+    const int xi = tid / (H2 * P);
+    constexpr int XSTEP = (2 * T) / P;       // chunks covered by the workgroup per iteration
+    c32* lds_r = lds + r * LinePitch<N>::elems;
+
+    float keep[2][E];
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+        const c32* src = inter + (size_t)f * field_stride + (size_t)(Y * P + r) * P + 2 * h;
+        float4 v[E / 2];
+#pragma unroll
+        for (int q = 0; q < E / 2; ++q) {
+            const int X = xi + q * XSTEP;
+            v[q] = *reinterpret_cast<const float4*>(src + (size_t)X * slab);
+        }
+        if (f > 0) __syncthreads();                                // previous field's LDS reads done
+#pragma unroll
+        for (int q = 0; q < E / 2; ++q) {
+            const int x0 = (xi + q * XSTEP) * P + 2 * h;
+            lds_r[lds_pad(x0)] = make_float2(v[q].x, v[q].y);
+            lds_r[lds_pad(x0 + 1)] = make_float2(v[q].z, v[q].w);
+        }
+        __syncthreads();
+        c32 reg[E];
+        const int jf = opaque_lane(j);                             // no twiddle CSE across fields
+        const c32* g = lds_line + lds_pad(jf);
+#pragma unroll
+        for (int e = 0; e < E; ++e) reg[e] = g[e * (T + T / 16)];  // = lds_pad(j + e*T)
+        __syncthreads();
+        fft_line<N, E>(reg, jf, tw, lds_line);
+        if (f < 2) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) keep[f][e] = reg[e].x;
+        } else {
+            float4* orow = out + (size_t)y * N;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int xo = j + e * T;
+                const float s = (((xo + y) & 1) == 0) ? -1.0f : 1.0f;   // correction.comp:29
+                orow[xo] = make_float4(keep[0][e] * s, keep[1][e] * s, reg[e].x * s, 0.0f);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Launch geometry per resolution -- the single source for the API (ocean_api.hip) and for the
+// host emulation harness (tests/hipemu).
+// ---------------------------------------------------------------------------------------------
+template <int N> struct Geo {
+    static constexpr int E = 16;                                   // elements per thread
+    static constexpr int T = N / E;                                // threads per line
+    static constexpr int ROW_LPW = (256 / T) > 1 ? (256 / T) : 1;  // rows per workgroup (staged)
+    static constexpr int COL_LPW = (N > 4096) ? 2 : ((256 / T) > 4 ? (256 / T) : 4);  // columns per workgroup (staged)
+    static constexpr int P = (N > 4096) ? 2 : 4;                   // lines per workgroup, fused passes
+    static constexpr int row_threads = T * ROW_LPW;
+    static constexpr int col_threads = T * COL_LPW;
+    static constexpr int frame_threads = T * P;
+    static constexpr int line_bytes = LinePitch<N>::elems * (int)sizeof(c32);
+    static constexpr int row_lds = ROW_LPW * line_bytes;
+    static constexpr int col_lds = COL_LPW * line_bytes;
+    static constexpr int frame_lds = P * line_bytes;
+    static constexpr int row_grid = N / ROW_LPW;
+    static constexpr int col_grid = N / COL_LPW;
+    static constexpr int frame_grid = N / P;
+    static_assert(row_threads <= 1024 && col_threads <= 1024 && frame_threads <= 1024, "workgroup too large");
+    static_assert(col_lds <= 160 * 1024 && frame_lds <= 160 * 1024, "LDS budget (gfx950: 160 KiB)");
+};
+
+}  // namespace ocean

@@ -1,0 +1,132 @@
+/*
+ * ocean_hip.h -- C ABI of the MI355X-native gfx-ocean compute path.
+ *
+ * Drop-in boundary for the reference's private `ocean` / `fft` modules
+ * (src/lib.rs:38-39) and for the 190-line dispatch block of `Renderer::render`
+ * (src/render.rs:1101-1310).  Plain pointers and sizes only: a Rust shim binds
+ * these with `extern "C"` (INTEGRATION.md shows the stub), Python binds them
+ * with ctypes (gfx-ocean_amd/_lib.py), C++ through host/ocean.hpp.
+ *
+ * Conventions
+ *   - Every call returns an int32_t status (OCEAN_OK = 0, negative = error) and
+ *     never throws or aborts; `ocean_last_error` gives the message.  The Rust
+ *     shim maps a non-zero status to `Err(Box<dyn Error>)` where the reference
+ *     returns `Result` (src/fft.rs:19, src/ocean.rs:25,194) and would `.unwrap()`.
+ *   - Complex fields are interleaved (re, im) fp32, row-major, index = x + N*y
+ *     (shader/propagate.comp:43).  The displacement map is linear RGBA32F,
+ *     out[(y*N + x)*4 + c] = (disp_x, height, disp_z, 0)  (shader/correction.comp:31-34),
+ *     replacing the reference's Rgba32Sfloat storage image (src/render.rs:820-869).
+ *   - `stream` is a `hipStream_t` passed as `void*`; NULL = the context's own
+ *     stream.  Stream order replaces the reference's pipeline barriers
+ *     (src/render.rs:1132-1156,1181-1208,1233-1278,1289-1310).
+ *   - A context is bound to one GPU and is not thread-safe (the reference is
+ *     single-threaded: winit loop, src/lib.rs:100-170).  One context per GPU for
+ *     tile-parallel runs.
+ */
+#ifndef OCEAN_HIP_H
+#define OCEAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OCEAN_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------------------------- */
+#define OCEAN_OK 0
+#define OCEAN_E_INVALID_ARG (-1)
+#define OCEAN_E_UNSUPPORTED_N (-2) /* resolution must be a power of two in [256, 8192] */
+#define OCEAN_E_HIP (-3)
+#define OCEAN_E_OOM (-4)
+#define OCEAN_E_STATE (-5) /* e.g. frame requested before ocean_upload_spectrum */
+
+/* ---- field selectors: Fft::desc_sets[0,1,2] -> dx_spec, dy_spec, dz_spec (src/render.rs:971-988) */
+#define OCEAN_FIELD_DX 0 /* disp_x spectrum  (propagate binding 4, src/render.rs:951-952) */
+#define OCEAN_FIELD_DY 1 /* height spectrum  (propagate binding 3, src/render.rs:949-950) */
+#define OCEAN_FIELD_DZ 2 /* disp_z spectrum  (propagate binding 5, src/render.rs:953-954) */
+#define OCEAN_FIELD_ALL (-1)
+
+/* ---- uniform blocks ----------------------------------------------------------------------- */
+/* src/ocean.rs:8-13 `PropagateLocals` / shader/propagate.comp:16-20 (std140 offsets 0/4/8).
+ * The reference struct has no #[repr(C)] (quirk Q6); this is the explicit layout. */
+typedef struct OceanPropagateLocals {
+    float time;
+    int32_t resolution;
+    float domain_size;
+} OceanPropagateLocals;
+
+/* src/ocean.rs:179-182 `CorrectionLocals` / shader/correction.comp:6-8.  The reference shader
+ * ignores it and hard-codes 512 (quirk Q4); here it must equal the context resolution. */
+typedef struct OceanCorrectionLocals {
+    uint32_t resolution;
+} OceanCorrectionLocals;
+
+/* ---- opaque handles ----------------------------------------------------------------------- */
+typedef struct OceanContext OceanContext;         /* device + buffers: the slice of `Renderer` (src/render.rs:72-101) the path needs */
+typedef struct OceanFft OceanFft;                 /* src/fft.rs:7-16   `Fft<B>` */
+typedef struct OceanPropagation OceanPropagation; /* src/ocean.rs:15-22 `Propagation<B>` */
+typedef struct OceanCorrection OceanCorrection;   /* src/ocean.rs:184-191 `Correction<B>` */
+
+/* ---- context: device open + buffer allocation (src/render.rs:118-172, 607-729, 820-869) ---- */
+int32_t ocean_abi_version(void);
+int32_t ocean_context_create(int32_t device_ordinal, int32_t resolution, OceanContext** out_ctx);
+void ocean_context_destroy(OceanContext* ctx);            /* NULL-safe; src/render.rs:1383-1438 */
+const char* ocean_last_error(const OceanContext* ctx);    /* ctx may be NULL: last error of a failed create */
+int32_t ocean_resolution(const OceanContext* ctx);
+
+/* Staging upload of the initial spectrum h0 (N*N complex) and dispersion omega (N*N real):
+ * src/render.rs:742-818 (decode + staging) and :872-924 (copy_buffer, submit, wait).  Synchronous. */
+int32_t ocean_upload_spectrum(OceanContext* ctx, const float* h0_re_im, const float* omega);
+
+/* ---- stage objects: init/destroy mirror the reference 1:1 -------------------------------- */
+int32_t ocean_fft_init(OceanContext* ctx, OceanFft** out);                  /* src/fft.rs:19-100 */
+void ocean_fft_destroy(OceanFft* fft);                                      /* src/fft.rs:102-110 */
+int32_t ocean_propagation_init(OceanContext* ctx, OceanPropagation** out);  /* src/ocean.rs:25-168 */
+void ocean_propagation_destroy(OceanPropagation* p);                        /* src/ocean.rs:170-176 */
+int32_t ocean_correction_init(OceanContext* ctx, OceanCorrection** out);    /* src/ocean.rs:194-319 */
+void ocean_correction_destroy(OceanCorrection* c);                          /* src/ocean.rs:321-327 */
+
+/* ---- dispatches: one call per reference `dispatch` ------------------------------------------ */
+/* bind propagate pipeline + dispatch [N/16, N/16, 1]: src/render.rs:1101-1130, shader/propagate.comp:42-72 */
+int32_t ocean_propagate(OceanPropagation* p, const OceanPropagateLocals* locals, void* stream);
+/* bind row_pass; dispatch [1, N, 1] per set: src/render.rs:1158-1179, shader/fft_row.comp:44-63 */
+int32_t ocean_fft_rows(OceanFft* fft, int32_t field, void* stream);
+/* bind col_pass; dispatch [1, N, 1] per set: src/render.rs:1210-1231, shader/fft_col.comp:44-63 */
+int32_t ocean_fft_cols(OceanFft* fft, int32_t field, void* stream);
+/* bind correction; dispatch [N/16, N/16, 1]: src/render.rs:1280-1287, shader/correction.comp:24-35 */
+int32_t ocean_correct(OceanCorrection* c, const OceanCorrectionLocals* locals, void* stream);
+
+/* Whole hot path of one frame (src/render.rs:1101-1310) with the default domain size 1000
+ * (src/render.rs:46) or the one given; fused kernels, same results as the four staged calls
+ * within fp32 re-association.  The staged field buffers are NOT updated by this call. */
+int32_t ocean_frame(OceanContext* ctx, float time, void* stream);
+int32_t ocean_frame_ex(OceanContext* ctx, const OceanPropagateLocals* locals, void* stream);
+
+int32_t ocean_sync(OceanContext* ctx); /* wait for the context stream (the reference never waits: src/render.rs:1068-1075) */
+
+/* ---- readback / injection (the reference has none; needed for parity checks) -------------- */
+int32_t ocean_read_displacement(OceanContext* ctx, float* host_rgba /* N*N*4 */);
+int32_t ocean_read_field(OceanContext* ctx, int32_t field, float* host_re_im /* N*N*2 */);
+int32_t ocean_write_field(OceanContext* ctx, int32_t field, const float* host_re_im);
+
+/* ---- zero-copy hooks for device-side consumers ----------------------------------------------- */
+void* ocean_displacement_device_ptr(OceanContext* ctx);           /* float4[N*N] in HBM */
+int32_t ocean_bind_displacement(OceanContext* ctx, void* device_rgba); /* write frames into caller memory (NULL = own) */
+void* ocean_stream(OceanContext* ctx);                            /* the context's hipStream_t */
+
+/* ---- measurement (HIP events on the stream the kernels run on) -------------------------------- */
+/* Runs `frames` frames (time = t0 + i*dt) on the context stream between two events; *out_ms = total. */
+int32_t ocean_time_frames(OceanContext* ctx, int32_t frames, float t0, float dt, float* out_ms);
+/* Per-kernel durations of ONE frame: names/ms arrays of capacity `cap`; returns count via *out_n. */
+int32_t ocean_profile_frame(OceanContext* ctx, float time, int32_t cap, const char** names, float* ms,
+                            int32_t* out_n);
+/* Same for the staged 8-dispatch path (propagate, 3 rows, 3 cols, correct). */
+int32_t ocean_profile_staged(OceanContext* ctx, float time, int32_t cap, const char** names, float* ms,
+                             int32_t* out_n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCEAN_HIP_H */

@@ -1,0 +1,87 @@
+"""ctypes driver of tests/hipemu/libocean_emu.so: the product kernels executed on the CPU."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_SO = os.path.join(_ROOT, "tests", "hipemu", "libocean_emu.so")
+_SRC = [os.path.join(_ROOT, "tests", "hipemu", "emu_kernels.cpp"),
+        os.path.join(_ROOT, "tests", "hipemu", "hip", "hip_runtime.h"),
+        os.path.join(_ROOT, "gfx-ocean_amd", "csrc", "ocean_kernels.hpp"),
+        os.path.join(_ROOT, "gfx-ocean_amd", "csrc", "fft_core.hpp")]
+_LIB = None
+
+
+def build(force=False):
+    stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in _SRC)
+    if force or stale:
+        subprocess.check_call([
+            "g++", "-std=c++20", "-O1", "-pthread", "-shared", "-fPIC",
+            "-I", os.path.join(_ROOT, "tests", "hipemu"), "-I", os.path.join(_ROOT, "gfx-ocean_amd", "csrc"),
+            _SRC[0], "-o", _SO])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        build()
+        _LIB = ctypes.CDLL(_SO)
+        _LIB.emu_frame_pass1.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_size_t] * 2 + [ctypes.c_float] * 2
+        _LIB.emu_frame_pass2.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_size_t] * 2
+        _LIB.emu_fft_lines.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        _LIB.emu_propagate.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_float] * 2
+        _LIB.emu_correct.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def twiddles(n):
+    i = np.arange(n, dtype=np.float64)
+    return np.exp(2j * np.pi * i / n).astype(np.complex64)
+
+
+def fft_lines(field, col):
+    f = np.ascontiguousarray(field, np.complex64).copy()
+    n = f.shape[0]
+    tw = twiddles(n)
+    assert lib().emu_fft_lines(n, int(col), _p(f), _p(tw)) == 0
+    return f
+
+
+def propagate(h0, omega, time, L=1000.0):
+    n = h0.shape[0]
+    h0 = np.ascontiguousarray(h0, np.complex64)
+    omega = np.ascontiguousarray(omega, np.float32)
+    outs = [np.empty((n, n), np.complex64) for _ in range(3)]
+    assert lib().emu_propagate(n, _p(h0), _p(omega), *map(_p, outs), time, L) == 0
+    return tuple(outs)
+
+
+def correct(h, dx, dz):
+    n = h.shape[0]
+    a = [np.ascontiguousarray(x, np.complex64) for x in (h, dx, dz)]
+    out = np.empty((n, n, 4), np.float32)
+    assert lib().emu_correct(n, *map(_p, a), _p(out)) == 0
+    return out
+
+
+def frame(h0, omega, time, L=1000.0, slab_pad=32, return_inter=False):
+    n = h0.shape[0]
+    P = lib().emu_frame_p(n)
+    h0T = np.ascontiguousarray(h0.T, np.complex64)
+    omT = np.ascontiguousarray(omega.T, np.float32)
+    slab = n * P + slab_pad
+    fstride = slab * (n // P)
+    inter = np.full(3 * fstride, np.nan + 1j * np.nan, np.complex64)
+    tw = twiddles(n)
+    assert lib().emu_frame_pass1(n, _p(h0T), _p(omT), _p(inter), _p(tw), slab, fstride, time, L) == 0
+    out = np.full((n, n, 4), np.nan, np.float32)
+    assert lib().emu_frame_pass2(n, _p(inter), _p(out), _p(tw), slab, fstride) == 0
+    if return_inter:
+        return out, inter, (P, slab, fstride)
+    return out

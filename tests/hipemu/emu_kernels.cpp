@@ -1,0 +1,108 @@
+// Runs the product's kernel templates on the CPU (one std::thread per GPU thread, std::barrier for
+// __syncthreads) so that the non-GPU test tier can check them against the oracle.
+// Build: g++ -std=c++20 -O1 -pthread -shared -fPIC -I tests/hipemu -I gfx-ocean_amd/csrc ...
+#include <barrier>
+#include <functional>
+#include <memory>
+#include <thread>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+thread_local emu_dim3 threadIdx;
+thread_local emu_dim3 blockIdx;
+emu_dim3 blockDim;
+emu_dim3 gridDim;
+static std::barrier<>* g_barrier = nullptr;
+void __syncthreads() { g_barrier->arrive_and_wait(); }
+
+namespace ocean { alignas(16) unsigned char smem[160 * 1024]; }
+
+#include "ocean_kernels.hpp"
+
+template <class F>
+static void emu_launch(int grid, int threads, F&& body) {
+    std::barrier<> bar(threads);
+    g_barrier = &bar;
+    gridDim.x = (unsigned)grid;
+    blockDim.x = (unsigned)threads;
+    std::vector<std::thread> pool;
+    pool.reserve(threads);
+    for (int t = 0; t < threads; ++t) {
+        pool.emplace_back([&, t] {
+            threadIdx.x = (unsigned)t;
+            for (int b = 0; b < grid; ++b) {
+                blockIdx.x = (unsigned)b;
+                body();
+                bar.arrive_and_wait();   // the next block reuses the LDS buffer
+            }
+        });
+    }
+    for (auto& th : pool) th.join();
+    g_barrier = nullptr;
+}
+
+using namespace ocean;
+
+template <int N> static int run_fft_lines(int col, c32* data, const c32* tw) {
+    using G = Geo<N>;
+    if (col) emu_launch(G::col_grid, G::col_threads, [&] { k_fft_lines<N, G::E, G::COL_LPW, true>(data, tw); });
+    else emu_launch(G::row_grid, G::row_threads, [&] { k_fft_lines<N, G::E, G::ROW_LPW, false>(data, tw); });
+    return 0;
+}
+template <int N> static int run_pass1(const c32* h0T, const float* omT, c32* inter, const c32* tw, size_t slab,
+                                      size_t fstride, float time, float L) {
+    using G = Geo<N>;
+    emu_launch(G::frame_grid, G::frame_threads,
+               [&] { k_frame_pass1<N, G::E, G::P>(h0T, omT, inter, tw, slab, fstride, time, L); });
+    return 0;
+}
+template <int N> static int run_pass2(const c32* inter, float4* out, const c32* tw, size_t slab, size_t fstride) {
+    using G = Geo<N>;
+    emu_launch(G::frame_grid, G::frame_threads, [&] { k_frame_pass2<N, G::E, G::P>(inter, out, tw, slab, fstride); });
+    return 0;
+}
+
+#define DISPATCH(n, CALL)                 \
+    switch (n) {                          \
+        case 256: return CALL(256);       \
+        case 512: return CALL(512);       \
+        case 1024: return CALL(1024);     \
+        case 2048: return CALL(2048);     \
+        case 4096: return CALL(4096);     \
+        default: return -2;               \
+    }
+
+extern "C" {
+int emu_frame_p(int n) {
+#define C_(N) Geo<N>::P
+    DISPATCH(n, C_)
+#undef C_
+}
+int emu_fft_lines(int n, int col, float* data, const float* tw) {
+#define C_(N) run_fft_lines<N>(col, (c32*)data, (const c32*)tw)
+    DISPATCH(n, C_)
+#undef C_
+}
+int emu_frame_pass1(int n, const float* h0T, const float* omT, float* inter, const float* tw, size_t slab,
+                    size_t fstride, float time, float L) {
+#define C_(N) run_pass1<N>((const c32*)h0T, omT, (c32*)inter, (const c32*)tw, slab, fstride, time, L)
+    DISPATCH(n, C_)
+#undef C_
+}
+int emu_frame_pass2(int n, const float* inter, float* out, const float* tw, size_t slab, size_t fstride) {
+#define C_(N) run_pass2<N>((const c32*)inter, (float4*)out, (const c32*)tw, slab, fstride)
+    DISPATCH(n, C_)
+#undef C_
+}
+int emu_propagate(int n, const float* h0, const float* omega, float* h, float* dx, float* dz, float time, float L) {
+    const int grid = (n * n / 2 + 255) / 256;
+    emu_launch(grid, 256, [&] { k_propagate((const c32*)h0, omega, (c32*)h, (c32*)dx, (c32*)dz, n, time, L); });
+    return 0;
+}
+int emu_correct(int n, const float* h, const float* dx, const float* dz, float* out) {
+    const int grid = (n * n / 2 + 255) / 256;
+    emu_launch(grid, 256, [&] { k_correct((const c32*)h, (const c32*)dx, (const c32*)dz, (float4*)out, n); });
+    return 0;
+}
+}

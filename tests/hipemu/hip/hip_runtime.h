@@ -1,0 +1,34 @@
+// Host emulation of the small slice of the HIP device language that
+// gfx-ocean_amd/csrc/{fft_core,ocean_kernels}.hpp use.  TEST INFRASTRUCTURE ONLY: it lets the
+// CPU test-suite execute the *unmodified* kernel sources (index algebra, LDS exchanges, barriers)
+// with one OS thread per GPU thread.  It is never part of the product build, which is hipcc/gfx950 only.
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+
+#define __global__
+#define __device__
+#define __host__
+#define __shared__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+
+struct float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+
+struct emu_dim3 { unsigned x = 1, y = 1, z = 1; };
+extern thread_local emu_dim3 threadIdx;
+extern thread_local emu_dim3 blockIdx;
+extern emu_dim3 blockDim;
+extern emu_dim3 gridDim;
+void __syncthreads();
+
+// ocml's sincospif (sin(pi x), cos(pi x)); host version evaluated in double.
+static inline void sincospif(float x, float* s, float* c) {
+    const double a = 3.14159265358979323846 * (double)x;
+    *s = (float)std::sin(a);
+    *c = (float)std::cos(a);
+}
