@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""bench.py -- ocean frames/sec + achieved HBM GB/s on N x N tiles, one tile per MI355X.
+
+A "step" is one frame of the hot path on one tile per GPU: spectrum propagate -> 2-D inverse FFT of
+the three fields -> sign correction + RGBA pack (the fused 2-launch path, `ocean_frame`), with h0 and
+omega already resident in HBM.  Tiles are independent, so N GPUs = N tiles per step
+and no data-path collective ("weak" scaling).  One JSON line on rank 0.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 4096]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+# Algorithmic bytes per texel of each fused kernel (DESIGN.md "Kernels"):
+#   pass1: read h0 8 + omega 4, write 3 complex fields 24            = 36
+#   pass2: read 3 complex fields 24, write RGBA32F 16                = 40   (frame total 76)
+KERNEL_BYTES_PER_TEXEL = {"k_frame_pass1": 36.0, "k_frame_pass2": 40.0}
+
+
+def aggregate(values_ms, n_gpus, steps):
+    """Whole-job throughput from per-rank wall times: tiles processed / slowest rank's time."""
+    worst_ms = max(values_ms)
+    ms_per_step = worst_ms / steps
+    return {"ms_per_step": ms_per_step, "value": n_gpus * 1000.0 / ms_per_step}
+
+
+def tile_seed(n, rank):
+    return n + rank     # tile r of a multi-GPU run uses seed N + r
+
+
+def cpu_baseline(n, h0, omega, budget_s=12.0, max_frames=12):
+    """The C restatement of the reference shaders (oracle/, kind "port") timed on this box's host
+    cores on a bounded sample of the same workload: whole frames of the same N until ~budget_s."""
+    from oracle import c_oracle as cc          # cpu_baseline leg: the oracle as the measured CPU path
+    cc.build()
+    runner = cc.FrameRunner(h0, omega)
+    runner.frame(0.0)                          # first-touch of the scratch buffers, not timed
+    frames, t0 = 0, time.perf_counter()
+    while frames < max_frames and (time.perf_counter() - t0) < budget_s:
+        runner.frame(frames / 60.0)
+        frames += 1
+    dt = time.perf_counter() - t0
+    return {"value": frames / dt, "unit": "frames/s", "cores": cc.max_threads(), "kind": "port",
+            "sample": f"{frames} whole frames at N={n} ({dt:.1f} s), OpenMP over lines, radix-2 Stockham "
+                      "with sincosf per butterfly as in the shaders"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--n", type=int, default=4096, help="tile edge (power of two, 256..8192)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-frames", type=int, default=20, help="frames averaged for the per-kernel durations")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        # torch first: libocean_hip.so then binds to the HIP runtime torch loaded (same soname)
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = world if world > 1 else 1
+    if args.gpus != n_gpus and rank == 0:
+        print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; using {n_gpus}", file=sys.stderr)
+
+    import gfx_ocean_amd as g
+    n = args.n
+    h0, omega = g.synth.make_inputs(n, seed=tile_seed(n, rank))
+    dev = g.OceanDevice(n, device_ordinal=local_rank)
+    dev.upload_spectrum(h0, omega)
+
+    def barrier():
+        dev.sync()
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for i in range(args.warmup):
+        dev.frame(i / 60.0)
+    barrier()
+    t0 = time.perf_counter()
+    event_ms = dev.time_frames(args.steps, t0=0.0, dt=1.0 / 60.0)   # K frames between two HIP events + sync
+    dev.sync()
+    wall_ms = (time.perf_counter() - t0) * 1000.0
+    barrier()
+
+    if dist is not None:
+        import torch
+        t = torch.tensor([wall_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_ms = [float(t.item())]
+    else:
+        all_ms = [wall_ms]
+    agg = aggregate(all_ms, n_gpus, args.steps)
+
+    # per-kernel durations, live, HIP events on the stream the kernels run on
+    acc = {}
+    for i in range(args.profile_frames):
+        for name, ms in dev.profile_frame(i / 60.0):
+            acc[name] = acc.get(name, 0.0) + ms
+    kernels = []
+    for name, total in acc.items():
+        avg_ms = total / args.profile_frames
+        b = KERNEL_BYTES_PER_TEXEL[name] * n * n
+        kernels.append({"name": name, "avg_ms": avg_ms, "algorithmic_bytes": b, "GBps": b / avg_ms / 1e6})
+    dom = max(kernels, key=lambda k: k["avg_ms"])
+    roofline = {"bound": "hbm", "kernel": dom["name"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": dom["algorithmic_bytes"], "avg_launch_ms": dom["avg_ms"],
+                "kernels": kernels,
+                "frame": {"algorithmic_bytes": 76.0 * n * n, "GBps": 76.0 * n * n / (event_ms / args.steps) / 1e6,
+                          "frac": 76.0 * n * n / (event_ms / args.steps) / 1e6 / HBM_PEAK_GBS}}
+
+    if rank == 0:
+        line = {
+            "metric": "ocean frames/sec (propagate + 3x 2-D iFFT + correction, one NxN tile per GPU)",
+            "value": agg["value"], "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": agg["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"N={n} tile per GPU, fused frame (k_frame_pass1 + k_frame_pass2), "
+                                   f"height+disp_x+disp_z (3 complex iFFTs/frame), seed N+rank",
+                       "n": n, "tiles": n_gpus, "parallelism": f"tile-parallel x{n_gpus}, no data-path collective",
+                       "gpu_event_ms_per_step": event_ms / args.steps},
+            "roofline": roofline,
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(n, h0, omega)
+        print(json.dumps(line))
+    dev.destroy()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,114 @@
+"""ctypes binding of libocean_hip.so (include/ocean_hip.h).  No fallback path."""
+from __future__ import annotations
+
+import ctypes
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libocean_hip.so")
+_CSRC = os.path.join(_HERE, "csrc")
+_LIB = None
+
+OCEAN_OK = 0
+STATUS_NAMES = {0: "OCEAN_OK", -1: "OCEAN_E_INVALID_ARG", -2: "OCEAN_E_UNSUPPORTED_N", -3: "OCEAN_E_HIP",
+                -4: "OCEAN_E_OOM", -5: "OCEAN_E_STATE"}
+
+# every symbol include/ocean_hip.h declares (tests/test_abi.py checks the header against this list)
+SYMBOLS = [
+    "ocean_abi_version", "ocean_context_create", "ocean_context_destroy", "ocean_last_error", "ocean_resolution",
+    "ocean_upload_spectrum", "ocean_fft_init", "ocean_fft_destroy", "ocean_propagation_init",
+    "ocean_propagation_destroy", "ocean_correction_init", "ocean_correction_destroy", "ocean_propagate",
+    "ocean_fft_rows", "ocean_fft_cols", "ocean_correct", "ocean_frame", "ocean_frame_ex", "ocean_sync",
+    "ocean_read_displacement", "ocean_read_field", "ocean_write_field", "ocean_displacement_device_ptr",
+    "ocean_bind_displacement", "ocean_stream", "ocean_time_frames", "ocean_profile_frame", "ocean_profile_staged",
+]
+
+
+class OceanError(RuntimeError):
+    """A non-zero status from the C ABI (the reference would `?`/`unwrap()` here)."""
+
+    def __init__(self, status: int, message: str):
+        self.status = status
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {message}")
+
+
+class PropagateLocalsC(ctypes.Structure):
+    _fields_ = [("time", ctypes.c_float), ("resolution", ctypes.c_int32), ("domain_size", ctypes.c_float)]
+
+
+class CorrectionLocalsC(ctypes.Structure):
+    _fields_ = [("resolution", ctypes.c_uint32)]
+
+
+def library_path() -> str:
+    return _SO
+
+
+def hipcc_command(out: str = _SO):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    return [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-I", _CSRC,
+            "-shared", "-fPIC", os.path.join(_CSRC, "ocean_api.hip"), "-o", out]
+
+
+def build_library(force: bool = False) -> str:
+    """Compile csrc/ for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC)] + [
+        os.path.join(os.path.dirname(_HERE), "include", "ocean_hip.h")]
+    stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    if force or stale:
+        subprocess.check_call(hipcc_command())
+    return _SO
+
+
+def load_library():
+    """dlopen libocean_hip.so.  Raises OceanError if it has not been built: there is no CPU path."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(_SO):
+        raise OceanError(-3, f"{_SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(the HIP extension is the only implementation; there is no CPU fallback)")
+    L = ctypes.CDLL(_SO)
+    vp, i32, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float
+    pp = ctypes.POINTER(vp)
+    sig = {
+        "ocean_abi_version": (i32, []),
+        "ocean_context_create": (i32, [i32, i32, pp]),
+        "ocean_context_destroy": (None, [vp]),
+        "ocean_last_error": (ctypes.c_char_p, [vp]),
+        "ocean_resolution": (i32, [vp]),
+        "ocean_upload_spectrum": (i32, [vp, vp, vp]),
+        "ocean_fft_init": (i32, [vp, pp]),
+        "ocean_fft_destroy": (None, [vp]),
+        "ocean_propagation_init": (i32, [vp, pp]),
+        "ocean_propagation_destroy": (None, [vp]),
+        "ocean_correction_init": (i32, [vp, pp]),
+        "ocean_correction_destroy": (None, [vp]),
+        "ocean_propagate": (i32, [vp, ctypes.POINTER(PropagateLocalsC), vp]),
+        "ocean_fft_rows": (i32, [vp, i32, vp]),
+        "ocean_fft_cols": (i32, [vp, i32, vp]),
+        "ocean_correct": (i32, [vp, ctypes.POINTER(CorrectionLocalsC), vp]),
+        "ocean_frame": (i32, [vp, f32, vp]),
+        "ocean_frame_ex": (i32, [vp, ctypes.POINTER(PropagateLocalsC), vp]),
+        "ocean_sync": (i32, [vp]),
+        "ocean_read_displacement": (i32, [vp, vp]),
+        "ocean_read_field": (i32, [vp, i32, vp]),
+        "ocean_write_field": (i32, [vp, i32, vp]),
+        "ocean_displacement_device_ptr": (vp, [vp]),
+        "ocean_bind_displacement": (i32, [vp, vp]),
+        "ocean_stream": (vp, [vp]),
+        "ocean_time_frames": (i32, [vp, i32, f32, f32, ctypes.POINTER(f32)]),
+        "ocean_profile_frame": (i32, [vp, f32, i32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(f32),
+                                      ctypes.POINTER(i32)]),
+        "ocean_profile_staged": (i32, [vp, f32, i32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(f32),
+                                       ctypes.POINTER(i32)]),
+    }
+    assert sorted(sig) == sorted(SYMBOLS)
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)   # AttributeError here = the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = L
+    return L

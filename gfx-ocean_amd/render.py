@@ -1,0 +1,149 @@
+"""The compute slice of the reference's `Renderer` (src/render.rs): device + buffers
+(`OceanDevice`) and the per-frame recorder (`OceanRenderer.render`, src/render.rs:1101-1310)."""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from ._lib import OCEAN_OK, OceanError, load_library
+from .fft import FIELD_ALL, FIELD_DX, FIELD_DY, FIELD_DZ, Fft
+from .ocean import DOMAIN_SIZE, Correction, CorrectionLocals, Propagation, PropagateLocals
+
+
+class OceanDevice:
+    """One GPU + the buffers of the path (initial_spec, omega, dx/dy/dz_spec, displacement map:
+    src/render.rs:607-670, 820-869)."""
+
+    def __init__(self, resolution: int, device_ordinal: int = 0):
+        lib = load_library()
+        ctx = ctypes.c_void_p()
+        st = lib.ocean_context_create(int(device_ordinal), int(resolution), ctypes.byref(ctx))
+        if st != OCEAN_OK:
+            raise OceanError(st, (lib.ocean_last_error(None) or b"").decode())
+        self._ctx = ctx
+        self.resolution = int(resolution)
+        self.device_ordinal = int(device_ordinal)
+
+    # -- plumbing -----------------------------------------------------------------------------
+    def _check(self, status: int):
+        if status != OCEAN_OK:
+            raise OceanError(status, (load_library().ocean_last_error(self._ctx) or b"").decode())
+
+    def destroy(self):
+        if self._ctx:
+            load_library().ocean_context_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    @property
+    def stream(self):
+        return load_library().ocean_stream(self._ctx)
+
+    def sync(self):
+        self._check(load_library().ocean_sync(self._ctx))
+
+    # -- upload (src/render.rs:742-924) ----------------------------------------------------------
+    def upload_spectrum(self, h0: np.ndarray, omega: np.ndarray):
+        n = self.resolution
+        h0 = np.ascontiguousarray(h0, dtype=np.complex64)
+        omega = np.ascontiguousarray(omega, dtype=np.float32)
+        if h0.shape != (n, n) or omega.shape != (n, n):
+            raise OceanError(-1, f"expected ({n},{n}) arrays, got {h0.shape} and {omega.shape}")
+        self._check(load_library().ocean_upload_spectrum(self._ctx, h0.ctypes.data, omega.ctypes.data))
+
+    # -- fused frame ---------------------------------------------------------------------------------
+    def frame(self, time: float, domain_size: float = DOMAIN_SIZE, stream=None):
+        loc = PropagateLocals(time, self.resolution, domain_size)._c()
+        self._check(load_library().ocean_frame_ex(self._ctx, ctypes.byref(loc), stream))
+
+    # -- readback / injection ----------------------------------------------------------------------
+    def read_displacement(self) -> np.ndarray:
+        n = self.resolution
+        out = np.empty((n, n, 4), dtype=np.float32)
+        self._check(load_library().ocean_read_displacement(self._ctx, out.ctypes.data))
+        return out
+
+    def read_field(self, field: int) -> np.ndarray:
+        n = self.resolution
+        out = np.empty((n, n), dtype=np.complex64)
+        self._check(load_library().ocean_read_field(self._ctx, int(field), out.ctypes.data))
+        return out
+
+    def write_field(self, field: int, data: np.ndarray):
+        n = self.resolution
+        data = np.ascontiguousarray(data, dtype=np.complex64)
+        if data.shape != (n, n):
+            raise OceanError(-1, f"expected ({n},{n}) array, got {data.shape}")
+        self._check(load_library().ocean_write_field(self._ctx, int(field), data.ctypes.data))
+
+    def displacement_device_ptr(self) -> int:
+        return int(load_library().ocean_displacement_device_ptr(self._ctx) or 0)
+
+    def bind_displacement(self, device_ptr):
+        self._check(load_library().ocean_bind_displacement(self._ctx, device_ptr))
+
+    # -- measurement ------------------------------------------------------------------------------------
+    def time_frames(self, frames: int, t0: float = 0.0, dt: float = 1.0 / 60.0) -> float:
+        """Total milliseconds (HIP events on the context stream) of `frames` fused frames."""
+        ms = ctypes.c_float()
+        self._check(load_library().ocean_time_frames(self._ctx, int(frames), float(t0), float(dt), ctypes.byref(ms)))
+        return float(ms.value)
+
+    def _profile(self, fn, time):
+        cap = 16
+        names = (ctypes.c_char_p * cap)()
+        ms = (ctypes.c_float * cap)()
+        n = ctypes.c_int32()
+        self._check(fn(self._ctx, float(time), cap, names, ms, ctypes.byref(n)))
+        return [(names[i].decode(), float(ms[i])) for i in range(n.value)]
+
+    def profile_frame(self, time: float = 0.0):
+        return self._profile(load_library().ocean_profile_frame, time)
+
+    def profile_staged(self, time: float = 0.0):
+        return self._profile(load_library().ocean_profile_staged, time)
+
+
+class OceanRenderer:
+    """`Renderer::new` + `Renderer::render` restricted to the compute path.
+
+    `render(time)` records exactly the reference's sequence (src/render.rs:1122-1310):
+    propagate -> row pass x {dx,dy,dz} -> col pass x {dx,dy,dz} -> correction, stream order
+    standing in for the four pipeline barriers.  `render_fused(time)` is the 2-launch path.
+    """
+
+    def __init__(self, resolution: int = 512, device_ordinal: int = 0, domain_size: float = DOMAIN_SIZE):
+        self.device = OceanDevice(resolution, device_ordinal)
+        self.fft = Fft.init(self.device)                  # src/render.rs:223
+        self.propagation = Propagation.init(self.device)  # src/render.rs:224
+        self.correction = Correction.init(self.device)    # src/render.rs:225
+        self.domain_size = float(domain_size)
+
+    def upload(self, h0, omega):
+        self.device.upload_spectrum(h0, omega)
+
+    def render(self, time: float, stream=None):
+        n = self.device.resolution
+        self.propagation.dispatch(PropagateLocals(time, n, self.domain_size), stream)   # :1101-1130
+        self.fft.row_pass(FIELD_ALL, stream)                                            # :1158-1179
+        self.fft.col_pass(FIELD_ALL, stream)                                            # :1210-1231
+        self.correction.dispatch(CorrectionLocals(n), stream)                           # :1280-1287
+
+    def render_fused(self, time: float, stream=None):
+        self.device.frame(time, self.domain_size, stream)
+
+    def displacement(self) -> np.ndarray:
+        return self.device.read_displacement()
+
+    def dispose(self):
+        """src/render.rs:1383-1438."""
+        self.fft.destroy()
+        self.propagation.destroy()
+        self.correction.destroy()
+        self.device.destroy()

@@ -1,0 +1,41 @@
+"""Deterministic synthetic inputs for N != 512 (the reference ships only 512x512 data).
+
+Closed forms fitted to data/spectrum.bin and data/omega.bin:
+  k(g) = pi (2g - N - 1) / L  (signed),  K = |k|
+  omega = sqrt(9.81 K tanh(100 K))                      (fits omega.bin to 9.1e-5 max abs)
+  h0    = (xi_r + i xi_i) sqrt(A D(theta) / 2) exp(-1 / (2 (K Lw)^2)) / K^2,
+          A = 5.8e-8, D = 1 + 0.7 cos(theta), Lw = 46 (Phillips low-k cut-off, fitted: the shipped
+          file has E|h0|^2 K^4 = 5.8e-8 for K > 0.1 and 4e-12 for K < 0.01),
+          xi ~ N(0,1) from PCG64(seed), zero on the 4 centre texels (indices N/2, N/2+1, where
+          the shipped file is exactly zero).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def dispersion(n: int, domain_size: float = 1000.0) -> np.ndarray:
+    g = np.arange(n, dtype=np.float64)
+    k1 = np.pi * (2.0 * g - n - 1.0) / domain_size
+    K = np.hypot(k1[None, :], k1[:, None])
+    return np.sqrt(9.81 * K * np.tanh(100.0 * K)).astype(np.float32)
+
+
+def spectrum(n: int, seed: int, domain_size: float = 1000.0) -> np.ndarray:
+    g = np.arange(n, dtype=np.float64)
+    k1 = np.pi * (2.0 * g - n - 1.0) / domain_size
+    kx, ky = k1[None, :], k1[:, None]
+    K = np.hypot(kx, ky)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    xi = rng.standard_normal((n, n, 2))          # row-major, re then im
+    amp = np.sqrt(5.8e-8 * (1.0 + 0.7 * np.cos(np.arctan2(ky, kx))) / 2.0) / (K * K)
+    amp = amp * np.exp(-0.5 / (K * 46.0) ** 2)
+    h0 = (xi[..., 0] + 1j * xi[..., 1]) * amp
+    c = n // 2
+    h0[c:c + 2, c:c + 2] = 0.0                   # 2g - N - 1 = -1, +1: the four smallest |k|
+    return h0.astype(np.complex64)
+
+
+def make_inputs(n: int, seed: int | None = None, domain_size: float = 1000.0):
+    """-> (h0, omega); seed defaults to N (tile r of a multi-GPU run uses N + r)."""
+    return spectrum(n, n if seed is None else seed, domain_size), dispersion(n, domain_size)

@@ -54,7 +54,7 @@ def load_reference_inputs(spectrum_path: str, omega_path: str):
     omega = read_bincode_f32(omega_path, 1)
     n = int(round(np.sqrt(omega.size)))
     assert n * n == omega.size == spec.shape[0]
-    h0 = (spec[:, 0] + 1j * spec[:, 1]).astype(np.complex64).reshape(n, n)
+    h0 = np.ascontiguousarray(spec, dtype=np.float32).view(np.complex64).reshape(n, n)
     return h0, omega.astype(np.float32).reshape(n, n)
 
 

@@ -1,0 +1,40 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def ref_inputs():
+    """The reference's own 512x512 inputs (data/spectrum.bin, data/omega.bin)."""
+    from oracle import ocean_oracle as oc
+    return oc.load_reference_inputs(os.path.join(GOLDEN, "spectrum.bin"), os.path.join(GOLDEN, "omega.bin"))
+
+
+@pytest.fixture(scope="session")
+def ref_inputs_256(ref_inputs):
+    from oracle import ocean_oracle as oc
+    h0, om = ref_inputs
+    return oc.centre_crop(h0, 256), oc.centre_crop(om, 256)
+
+
+def assert_parity(candidate, oracle_out, tol=1e-4, what=""):
+    """SURVEY 8d parity metric: per channel normalised-max and relative L2, both <= tol
+    (north_star: fp32 within 1e-4 of the reference; the tolerance is stated here)."""
+    from oracle import ocean_oracle as oc
+    nmax, rl2 = oc.parity_errors(candidate, oracle_out)
+    assert np.all(nmax <= tol), f"{what}: normalised max error {nmax} > {tol}"
+    assert np.all(rl2 <= tol), f"{what}: relative L2 error {rl2} > {tol}"
+    return nmax, rl2

@@ -1,0 +1,71 @@
+"""The product's kernel sources (gfx-ocean_amd/csrc/*.hpp) executed on the CPU by the host
+emulation harness (tests/hipemu) and compared with the oracle: index algebra, plans, LDS
+exchanges, chunked intermediate layout, quirks.  The GPU tier (-m gpu) repeats this on gfx950."""
+import numpy as np
+import pytest
+
+import emu
+from conftest import assert_parity
+from oracle import ocean_oracle as oc
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _build():
+    emu.build()
+
+
+def test_emu_propagate_matches_literal(ref_inputs_256):
+    h0, om = ref_inputs_256
+    for t in (0.0, 3.0, 1000.0):
+        ref = oc.propagate_literal(h0, om, t)
+        got = emu.propagate(h0, om, t)
+        for a, b in zip(got, ref):
+            assert oc.parity_errors(a, b)[0].max() <= 1e-6
+
+
+@pytest.mark.parametrize("n,col", [(256, 0), (256, 1), (512, 0), (512, 1), (1024, 0), (1024, 1)])
+def test_emu_fft_lines(n, col):
+    rng = np.random.default_rng(100 + n + col)
+    x = (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))).astype(np.complex64)
+    got = emu.fft_lines(x, col)
+    ref = oc.ifft_lines_f64(x.T if col else x)
+    ref = ref.T if col else ref
+    assert_parity(got, ref, 2e-6, f"emu fft n={n} col={col}")
+
+
+def test_emu_correct(ref_inputs_256):
+    h0, om = ref_inputs_256
+    h, dx, dz = oc.propagate_literal(h0, om, 1.0)
+    assert np.array_equal(emu.correct(h, dx, dz), oc.correction_literal(h, dx, dz))
+
+
+@pytest.mark.parametrize("t", [0.0, 1.0, 100.0])
+def test_emu_fused_frame_256(ref_inputs_256, t):
+    h0, om = ref_inputs_256
+    out, inter, _ = emu.frame(h0, om, t, return_inter=True)
+    assert not np.isnan(out).any()
+    assert_parity(out[..., :3], oc.frame_f64(h0, om, t)[..., :3], 5e-6, "emu fused frame")
+    assert np.all(out[..., 3] == 0.0)
+
+
+def test_emu_fused_frame_512(ref_inputs):
+    h0, om = ref_inputs
+    out = emu.frame(h0, om, 10.0)
+    assert_parity(out[..., :3], oc.frame_f64(h0, om, 10.0)[..., :3], 5e-6, "emu fused frame 512")
+
+
+def test_emu_intermediate_layout(ref_inputs_256):
+    """pass1 writes inter[f][X*slab + y*P + c] = column FFT of field f at (y, x = X*P + c)."""
+    h0, om = ref_inputs_256
+    n = 256
+    _, inter, (P, slab, fstride) = emu.frame(h0, om, 2.0, return_inter=True)
+    h, dx, dz = oc.propagate_f64(h0, om, 2.0)
+    for f, spec in ((0, dx), (1, h), (2, dz)):
+        ref = np.fft.ifft(spec, axis=0) * n          # transform along y only
+        got = np.empty((n, n), np.complex64)
+        for X in range(n // P):
+            blk = inter[f * fstride + X * slab: f * fstride + X * slab + n * P].reshape(n, P)
+            got[:, X * P:(X + 1) * P] = blk
+        assert_parity(got, ref, 5e-6, f"intermediate field {f}")
+    pad = inter[slab - 32 + 0: slab]                 # the slab padding is never written
+    assert np.isnan(pad.real).all()

@@ -1,0 +1,265 @@
+"""GPU tier: the HIP path, called through the C ABI, against the oracle.
+
+Tolerance: north_star states "within 1e-4 relative fp32"; measured per channel as normalised max
+and relative L2, both <= 1e-4 against the fp64 oracle.  Stage-level checks use the
+fp32 literal oracle where the comparison is elementwise.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import gfx_ocean_amd as g
+from conftest import GOLDEN, assert_parity
+from oracle import c_oracle as cc
+from oracle import ocean_oracle as oc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def r512(ref_inputs):
+    r = g.OceanRenderer(512)
+    r.upload(*ref_inputs)
+    yield r
+    r.dispose()
+
+
+@pytest.fixture(scope="module")
+def r256(ref_inputs_256):
+    r = g.OceanRenderer(256)
+    r.upload(*ref_inputs_256)
+    yield r
+    r.dispose()
+
+
+def test_native_library_is_loaded():
+    lib = g.load_library()
+    assert lib.ocean_abi_version() == 1
+    with open("/proc/self/maps") as f:
+        assert "libocean_hip.so" in f.read()
+
+
+@pytest.mark.parametrize("t", [0.0, 1.0, 10.0, 100.0])
+def test_staged_frame_reference_data_512(r512, ref_inputs, t):
+    """config 2: N=512, data/*.bin, the reference's 8-dispatch sequence."""
+    r512.render(t)
+    out = r512.displacement()
+    assert_parity(out[..., :3], oc.frame_f64(*ref_inputs, t)[..., :3], TOL, f"staged t={t}")
+    assert np.all(out[..., 3] == 0.0)
+
+
+@pytest.mark.parametrize("t", [0.0, 1.0, 10.0, 100.0, 1000.0])
+def test_fused_frame_reference_data_512(r512, ref_inputs, t):
+    r512.render_fused(t)
+    out = r512.displacement()
+    nmax, rl2 = assert_parity(out[..., :3], oc.frame_f64(*ref_inputs, t)[..., :3], TOL, f"fused t={t}")
+    assert nmax.max() < 1e-5          # fp32 headroom: expect ~1e-6
+    assert np.all(out[..., 3] == 0.0)
+
+
+def test_stage_by_stage_512(r512, ref_inputs):
+    """Each dispatch against the literal fp32 oracle of the same stage."""
+    h0, om = ref_inputs
+    t = 3.25
+    n = 512
+    dev = r512.device
+    r512.propagation.dispatch(g.PropagateLocals(t, n))
+    h, dx, dz = oc.propagate_literal(h0, om, t)
+    for f, ref in ((g.FIELD_DY, h), (g.FIELD_DX, dx), (g.FIELD_DZ, dz)):
+        assert_parity(dev.read_field(f), ref, 2e-6, f"propagate field {f}")
+    r512.fft.row_pass(g.FIELD_ALL)
+    rows = {f: oc.ifft_lines_f64(v) for f, v in ((g.FIELD_DY, h), (g.FIELD_DX, dx), (g.FIELD_DZ, dz))}
+    for f, ref in rows.items():
+        assert_parity(dev.read_field(f), ref, 5e-6, f"row pass field {f}")
+    r512.fft.col_pass(g.FIELD_DX)           # single-set dispatch, like one loop iteration of render.rs:1210-1231
+    got = dev.read_field(g.FIELD_DX)
+    ref = oc.ifft_lines_f64(rows[g.FIELD_DX].T).T
+    assert_parity(got, ref, 5e-6, "col pass dx")
+    assert_parity(dev.read_field(g.FIELD_DY), rows[g.FIELD_DY], 5e-6, "dy untouched by col_pass(dx)")
+    r512.fft.col_pass(g.FIELD_DY)
+    r512.fft.col_pass(g.FIELD_DZ)
+    r512.correction.dispatch(g.CorrectionLocals(n))
+    assert_parity(r512.displacement()[..., :3], oc.frame_f64(h0, om, t)[..., :3], TOL, "after correction")
+
+
+def test_config1_n256_centre_crop(r256, ref_inputs_256):
+    for t in (0.0, 1.0):
+        r256.render_fused(t)
+        fused = r256.displacement()
+        r256.render(t)
+        staged = r256.displacement()
+        ref = oc.frame_f64(*ref_inputs_256, t)
+        assert_parity(fused[..., :3], ref[..., :3], TOL, "N=256 fused")
+        assert_parity(staged[..., :3], ref[..., :3], TOL, "N=256 staged")
+
+
+@pytest.mark.parametrize("name,n,t", [("frame512_t0", 512, 0.0), ("frame512_t1", 512, 1.0),
+                                     ("frame512_t10", 512, 10.0), ("frame256_t1", 256, 1.0)])
+def test_committed_golden_vectors(r512, r256, name, n, t):
+    gold = np.load(os.path.join(GOLDEN, name + ".npz"))
+    r = r512 if n == 512 else r256
+    r.render_fused(t)
+    out = r.displacement()[..., :3]
+    assert np.abs(out[:64, :64] - gold["crop"]).max() <= TOL * gold["max"].max()
+    for (x, y), v in zip(gold["probes_xy"], gold["probes"]):
+        assert np.allclose(out[y, x], v, atol=TOL * gold["max"].max())
+    assert np.allclose(np.sqrt((out.astype(np.float64) ** 2).sum((0, 1))), gold["l2"], rtol=TOL)
+
+
+@pytest.mark.parametrize("n", [1024, 2048])
+def test_synthetic_against_c_oracle(n):
+    """config 3 (N=2048, three iFFTs per frame) and N=1024: synthetic inputs, C oracle + fp64."""
+    h0, om = g.synth.make_inputs(n)
+    r = g.OceanRenderer(n)
+    try:
+        r.upload(h0, om)
+        t = 2.5
+        ref64 = oc.frame_f64(h0, om, t)
+        refc = cc.FrameRunner(h0, om).frame(t)
+        r.render_fused(t)
+        fused = r.displacement()
+        r.render(t)
+        staged = r.displacement()
+        assert_parity(fused[..., :3], ref64[..., :3], TOL, f"N={n} fused vs fp64")
+        assert_parity(staged[..., :3], ref64[..., :3], TOL, f"N={n} staged vs fp64")
+        assert_parity(fused[..., :3], refc[..., :3], TOL, f"N={n} fused vs C oracle")
+    finally:
+        r.dispose()
+
+
+@pytest.mark.parametrize("n", [4096, 8192])
+def test_full_size_properties(n):
+    """BASELINE full sizes through size-independent properties (the oracle would take minutes):
+    fused == staged; impulse spectrum -> closed-form plane wave; linearity in h0; FFT of the
+    intermediate fields against fp64 on sampled lines."""
+    rng = np.random.default_rng(n)
+    h0, om = g.synth.make_inputs(n)
+    r = g.OceanRenderer(n)
+    try:
+        r.upload(h0, om)
+        t = 1.75
+        r.render_fused(t)
+        fused = r.displacement()
+        r.render(t)
+        staged = r.displacement()
+        assert_parity(fused[..., :3], staged[..., :3], 2e-5, f"N={n} fused vs staged")
+        assert np.all(fused[..., 3] == 0.0)
+        # sampled texels against a direct fp64 evaluation of the 2-D sum (O(N^2) per texel)
+        H, DX, DZ = oc.propagate_f64(h0, om, t)
+        k = np.arange(n)
+        scale = np.abs(fused[..., :3]).max((0, 1))
+        for (x, y) in [(0, 0), (1, n - 1), (n // 2 + 3, n // 3), (n - 1, n - 1)]:
+            ey, ex = np.exp(2j * np.pi * k * y / n), np.exp(2j * np.pi * k * x / n)
+            sgn = -1.0 if (x + y) % 2 == 0 else 1.0
+            ref = np.array([(ey @ (F @ ex)).real for F in (DX, H, DZ)]) * sgn
+            assert np.all(np.abs(fused[y, x, :3] - ref) <= TOL * scale), (x, y, fused[y, x, :3], ref)
+        # row pass of the staged path on random data, sampled lines vs fp64
+        a = (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))).astype(np.complex64)
+        r.device.write_field(g.FIELD_DZ, a)
+        r.fft.row_pass(g.FIELD_DZ)
+        rows = r.device.read_field(g.FIELD_DZ)
+        for yy in (0, 17, n - 1):
+            assert_parity(rows[yy], oc.ifft_lines_f64(a[yy][None])[0], 5e-6, f"row {yy}")
+        r.fft.col_pass(g.FIELD_DZ)
+        both = r.device.read_field(g.FIELD_DZ)
+        for xx in (0, 5, n - 1):
+            assert_parity(both[:, xx], oc.ifft_lines_f64(rows[:, xx][None])[0], 5e-6, f"col {xx}")
+        # Parseval over the whole 2-D transform
+        assert abs((np.abs(both.astype(np.complex128)) ** 2).sum() / (float(n) ** 2 * (np.abs(a.astype(np.complex128)) ** 2).sum()) - 1) < 1e-5
+    finally:
+        r.dispose()
+
+
+def test_linearity_and_impulse_1024():
+    n = 1024
+    om = g.synth.dispersion(n)
+    r = g.OceanRenderer(n)
+    try:
+        # a single non-zero h0 texel: output is a closed-form pair of plane waves
+        h0 = np.zeros((n, n), np.complex64)
+        h0[700, 650] = 1.0 + 0.5j
+        r.upload(h0, om)
+        r.render_fused(4.0)
+        out = r.displacement()
+        assert_parity(out[..., :3], oc.frame_f64(h0, om, 4.0)[..., :3], TOL, "impulse")
+        # linearity: frame(a + b) == frame(a) + frame(b)
+        a, _ = g.synth.make_inputs(n, seed=1)
+        b, _ = g.synth.make_inputs(n, seed=2)
+        outs = []
+        for h in (a, b, (a + b).astype(np.complex64)):
+            r.upload(h, om)
+            r.render_fused(0.5)
+            outs.append(r.displacement().astype(np.float64))
+        assert_parity((outs[0] + outs[1])[..., :3], outs[2][..., :3], 1e-5, "linearity")
+    finally:
+        r.dispose()
+
+
+def test_time_is_stateless(r512, ref_inputs):
+    """No state but `time` (SURVEY 5 checkpoint/resume): frames are reproducible in any order."""
+    r512.render_fused(5.0)
+    a = r512.displacement()
+    r512.render_fused(123.0)
+    r512.render_fused(5.0)
+    assert np.array_equal(a, r512.displacement())
+
+
+def test_error_behaviour():
+    with pytest.raises(g.OceanError) as e:
+        g.OceanDevice(500)
+    assert e.value.status == -2                      # OCEAN_E_UNSUPPORTED_N
+    with pytest.raises(g.OceanError):
+        g.OceanDevice(512, device_ordinal=99)
+    d = g.OceanDevice(256)
+    try:
+        with pytest.raises(g.OceanError) as e:
+            d.frame(0.0)                             # before upload
+        assert e.value.status == -5
+        with pytest.raises(g.OceanError):
+            d.upload_spectrum(np.zeros((128, 128), np.complex64), np.zeros((128, 128), np.float32))
+        p = g.Propagation.init(d)
+        d.upload_spectrum(np.zeros((256, 256), np.complex64), np.zeros((256, 256), np.float32))
+        with pytest.raises(g.OceanError):
+            p.dispatch(g.PropagateLocals(0.0, 512))  # resolution mismatch
+        p.destroy()
+        with pytest.raises(g.OceanError):
+            p.dispatch(g.PropagateLocals(0.0, 256))  # use after destroy
+    finally:
+        d.destroy()
+
+
+_TORCH_INTEROP = r"""
+import sys, numpy as np
+import torch                      # FIRST: libocean_hip.so then binds to the HIP runtime torch loaded
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import gfx_ocean_amd as g
+from oracle import ocean_oracle as oc
+h0, om = oc.load_reference_inputs(sys.argv[1] + "/tests/golden/spectrum.bin", sys.argv[1] + "/tests/golden/omega.bin")
+n = 512
+d = g.OceanDevice(n)
+d.upload_spectrum(h0, om)
+out = torch.zeros((n, n, 4), dtype=torch.float32, device="cuda:0")
+d.bind_displacement(out.data_ptr())
+s = torch.cuda.Stream()
+d.frame(1.0, stream=s.cuda_stream)
+s.synchronize()
+nmax, rl2 = oc.parity_errors(out.cpu().numpy()[..., :3], oc.frame_f64(h0, om, 1.0)[..., :3])
+assert nmax.max() <= 1e-4 and rl2.max() <= 1e-4, (nmax, rl2)
+d.bind_displacement(None)
+d.destroy()
+print("TORCH_INTEROP_OK", nmax.max())
+"""
+
+
+def test_torch_interop_stream_and_bound_output():
+    """The C ABI takes raw device pointers / hipStream_t: drive it from torch memory and a torch
+    stream.  Own process, torch imported first (one HIP runtime per process: torch bundles its own
+    libamdhip64 with the same soname, so whichever loads first serves both)."""
+    import subprocess
+    import sys
+    pytest.importorskip("torch")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", _TORCH_INTEROP, root], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "TORCH_INTEROP_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
