@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -50,6 +51,7 @@ struct OceanContext {
     float4* out_own = nullptr;  // displacement map (src/render.rs:820-869), linear RGBA32F
     float4* out = nullptr;      // = out_own or the caller's buffer (ocean_bind_displacement)
     bool uploaded = false;
+    bool pass2_thin = true;           // OCEAN_PASS2=fat selects the 1024-thread variant (A/B measurements)
     float default_domain = 1000.0f;   // src/render.rs:46
     std::string err;
 };
@@ -97,6 +99,9 @@ template <int N> struct Launch {
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute((const void*)k_frame_pass2<N, G::E, G::P>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, G::frame_lds);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)k_frame_pass2_thin<N, G::E, G::P, G::R2>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, G::thin_lds);
         return e;
     }
     static void rows(OceanContext* c, c32* data, hipStream_t s) {
@@ -112,8 +117,12 @@ template <int N> struct Launch {
                            G::frame_lds, s, c->h0T, c->omegaT, c->inter, c->tw, c->slab, c->field_stride, time, domain);
     }
     static void pass2(OceanContext* c, hipStream_t s) {
-        hipLaunchKernelGGL((k_frame_pass2<N, G::E, G::P>), dim3(G::frame_grid), dim3(G::frame_threads),
-                           G::frame_lds, s, c->inter, c->out, c->tw, c->slab, c->field_stride);
+        if (c->pass2_thin)
+            hipLaunchKernelGGL((k_frame_pass2_thin<N, G::E, G::P, G::R2>), dim3(G::thin_grid), dim3(G::thin_threads),
+                               G::thin_lds, s, c->inter, c->out, c->tw, c->slab, c->field_stride);
+        else
+            hipLaunchKernelGGL((k_frame_pass2<N, G::E, G::P>), dim3(G::frame_grid), dim3(G::frame_threads),
+                               G::frame_lds, s, c->inter, c->out, c->tw, c->slab, c->field_stride);
     }
 };
 
@@ -180,6 +189,7 @@ int32_t ocean_context_create(int32_t device, int32_t resolution, OceanContext** 
     if (!c) return fail(nullptr, OCEAN_E_OOM, "host allocation failed");
     c->device = device;
     c->n = resolution;
+    if (const char* v = std::getenv("OCEAN_PASS2")) c->pass2_thin = (std::strcmp(v, "fat") != 0);
     DeviceGuard guard(device);
     const size_t n2 = (size_t)resolution * resolution;
     c->P = frame_p(resolution);
@@ -421,7 +431,7 @@ static int32_t profile_common(OceanContext* ctx, float time, int32_t cap, const 
     if (!ctx->uploaded) return fail(ctx, OCEAN_E_STATE, "ocean_upload_spectrum has not been called");
     static const char* kStaged[8] = {"k_propagate", "k_fft_lines<ROW> dx", "k_fft_lines<ROW> dy", "k_fft_lines<ROW> dz",
                                      "k_fft_lines<COL> dx", "k_fft_lines<COL> dy", "k_fft_lines<COL> dz", "k_correct"};
-    static const char* kFused[2] = {"k_frame_pass1", "k_frame_pass2"};
+    static const char* kFused[2] = {"k_frame_pass1", "k_frame_pass2"};   // pass2 = fat or thin variant
     const int count = staged ? 8 : 2;
     if (cap < count) return fail(ctx, OCEAN_E_INVALID_ARG, "capacity too small");
     DeviceGuard guard(ctx->device);

@@ -57,6 +57,14 @@ __device__ __forceinline__ void k_normalised(float kx, float ky, float& knx, flo
     knx = 0.0f; kny = 0.0f;
     if (len > 1.0e-10f) { knx = kx / len; kny = ky / len; }
 }
+// Same value to <= 2 ulp with one v_rsq_f32 instead of a square root and two IEEE divisions
+// (used by the fused kernel, where pass 1 is VALU-limited): kn = k * rsqrt(|k|^2).
+__device__ __forceinline__ void k_normalised_fast(float kx, float ky, float& knx, float& kny) {
+    const float l2 = kx * kx + ky * ky;
+    const float r = (l2 > 1.0e-20f) ? rsqrtf(l2) : 0.0f;          // length(k) > 1e-10
+    knx = kx * r;
+    kny = ky * r;
+}
 // complex_mul(vec2(0, -kn), h) = (kn*h.y, -kn*h.x)   (:70-71)
 __device__ __forceinline__ c32 mul_minus_i_kn(float kn, c32 h) { return make_float2(kn * h.y, -kn * h.x); }
 
@@ -179,7 +187,8 @@ k_frame_pass1(const c32* __restrict__ h0T, const float* __restrict__ omegaT, c32
     const c32* own = h0T + (size_t)x * N;
     const c32* mir = h0T + (size_t)(N - 1 - x) * N;
     const float* om = omegaT + (size_t)x * N;
-    const float kx = OCEAN_PI_F * wave_index_q1(x, N) / domain_size;
+    const float kscale = OCEAN_PI_F / domain_size;                 // k = (pi * float(x)) / L to 1 ulp
+    const float kx = wave_index_q1(x, N) * kscale;
     c32 hs[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -197,9 +206,9 @@ k_frame_pass1(const c32* __restrict__ h0T, const float* __restrict__ omegaT, c32
             if (f == 1) reg[e] = hs[e];
             else {
                 // k_norm is recomputed per field instead of kept: 2*E fewer live VGPRs
-                const float ky = OCEAN_PI_F * wave_index_q1((uint32_t)(jf + e * T), N) / domain_size;
+                const float ky = wave_index_q1((uint32_t)(jf + e * T), N) * kscale;
                 float knx, kny;
-                k_normalised(kx, ky, knx, kny);
+                k_normalised_fast(kx, ky, knx, kny);
                 reg[e] = mul_minus_i_kn((f == 0) ? knx : kny, hs[e]);
             }
         }
@@ -283,6 +292,58 @@ k_frame_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32
     }
 }
 
+// Thin variant of pass 2: R2 rows per workgroup (R2 = 1 at N >= 4096: 256 threads, ~35 KiB LDS,
+// 4 workgroups per CU like k_fft_lines<ROW>), each thread gathering its own row straight from the
+// chunked intermediate (8*P1-byte row of a P1 x P1 chunk per 4 lanes).  The P1/R2 workgroups that
+// share a chunk run on the same XCD in adjacent dispatch slots, so the other rows of a 128-byte
+// line are L2 hits rather than HBM re-reads.  No LDS input exchange, no 1024-thread barriers.
+template <int N, int E, int P1, int R2>
+__global__ void __launch_bounds__((N / E) * R2)
+k_frame_pass2_thin(const c32* __restrict__ inter, float4* __restrict__ out, const c32* __restrict__ tw,
+                   size_t slab, size_t field_stride) {
+    constexpr int T = N / E;
+    static_assert(T % P1 == 0, "a thread's elements must keep the same column within a chunk");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    c32* lds = reinterpret_cast<c32*>(smem);
+    const int tid = threadIdx.x;
+    const int ll = (T >= 64) ? wave_uniform(tid / T) : (tid / T);
+    const int j = tid % T;
+    // block -> row block: sharers of a chunk = S consecutive slots of one XCD (b % 8)
+    constexpr int S = (P1 > R2) ? (P1 / R2) : 1;
+    int rb = blockIdx.x;
+    if (S > 1 && (gridDim.x % (8 * S)) == 0) {
+        const int xcd = rb & 7, slot = rb >> 3;
+        rb = ((slot / S) * 8 + xcd) * S + (slot % S);
+    }
+    const int y = rb * R2 + ll;
+    c32* lds_line = lds + ll * LinePitch<N>::elems;
+
+    float keep[2][E];
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+        const int jf = opaque_lane(j);                             // no twiddle CSE across fields
+        // element x = jf + e*T lives at (x / P1) * slab + y * P1 + x % P1; T % P1 == 0
+        const c32* src = inter + (size_t)f * field_stride + (size_t)(jf / P1) * slab + (size_t)y * P1 + (jf % P1);
+        c32 reg[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) reg[e] = src[(size_t)e * (T / P1) * slab];
+        if (f > 0) __syncthreads();                                // previous field's LDS reads done
+        fft_line<N, E>(reg, jf, tw, lds_line);
+        if (f < 2) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) keep[f][e] = reg[e].x;
+        } else {
+            float4* orow = out + (size_t)y * N;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int xo = j + e * T;
+                const float s = (((xo + y) & 1) == 0) ? -1.0f : 1.0f;   // correction.comp:29
+                orow[xo] = make_float4(keep[0][e] * s, keep[1][e] * s, reg[e].x * s, 0.0f);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Launch geometry per resolution -- the single source for the API (ocean_api.hip) and for the
 // host emulation harness (tests/hipemu).
@@ -303,6 +364,10 @@ template <int N> struct Geo {
     static constexpr int row_grid = N / ROW_LPW;
     static constexpr int col_grid = N / COL_LPW;
     static constexpr int frame_grid = N / P;
+    static constexpr int R2 = ROW_LPW;                             // rows per workgroup, thin pass 2
+    static constexpr int thin_threads = T * R2;
+    static constexpr int thin_lds = R2 * line_bytes;
+    static constexpr int thin_grid = N / R2;
     static_assert(row_threads <= 1024 && col_threads <= 1024 && frame_threads <= 1024, "workgroup too large");
     static_assert(col_lds <= 160 * 1024 && frame_lds <= 160 * 1024, "LDS budget (gfx950: 160 KiB)");
 };

@@ -4,17 +4,21 @@ TEST INFRASTRUCTURE ONLY.  Only ``tests/``, ``__graft_entry__.smoke()`` and
 ``bench.py``'s ``cpu_baseline`` leg may import this module; the product path
 (``gfx-ocean_amd/``) never does and fails loudly when its HIP library is missing.
 
-PARITY UNPINNED (by the reference's own tests): the reference has no tests, no
-golden outputs and no CPU path, and it cannot be built or run in the build
-container (Rust + gfx-hal + Vulkan are absent).  What pins this oracle instead:
+PARITY PINNING.  The reference has no tests, no golden outputs and no CPU path, and it cannot
+be built or run in the build container (Rust + gfx-hal + Vulkan are absent), so parity is
+UNPINNED BY THE REFERENCE'S OWN TESTS.  What pins this oracle instead:
   * the reference's two input files (tests/golden/{spectrum,omega}.bin, data);
-  * two independent formulations below that must agree to ~1e-6
+  * oracle/spirv_interp.py, which executes the reference's *shipped SPIR-V binaries*
+    (shader/spv/*.comp.spv, the code the reference actually runs) in the build container on those
+    inputs; its outputs are committed as tests/golden/spirv_frame512_t*.npz and the
+    ``*_literal`` functions below reproduce them BIT FOR BIT at every stage
+    (tests/test_oracle.py::test_literal_oracle_reproduces_the_shipped_spirv_bit_for_bit);
+  * two independent formulations that must agree to ~1e-6
     (``*_literal`` = fp32 restatement of the shaders instruction by instruction,
     ``frame_f64`` = closed-form fp64 with numpy's pocketfft);
-  * the survey-time KAT table (tests/golden/kat_survey.json);
-  * oracle/spirv_interp.py, which executes the reference's *shipped SPIR-V
-    binaries* on the same inputs in the build container and whose outputs are
-    committed as tests/golden/spirv_*.npz (see that file's header).
+  * the survey-time KAT table (tests/golden/kat_survey.json).
+Driver-defined precision (sin, cos, length, division, FMA contraction) is fixed to "correctly
+rounded fp32, no contraction"; the reference's own GPU result is implementation-defined at that level.
 
 Every function cites the reference file:line it restates.  Array convention:
 row-major, ``index = x + N*y`` with x = gl_GlobalInvocationID.x fastest

@@ -10,7 +10,8 @@ _SO = os.path.join(_ROOT, "tests", "hipemu", "libocean_emu.so")
 _SRC = [os.path.join(_ROOT, "tests", "hipemu", "emu_kernels.cpp"),
         os.path.join(_ROOT, "tests", "hipemu", "hip", "hip_runtime.h"),
         os.path.join(_ROOT, "gfx-ocean_amd", "csrc", "ocean_kernels.hpp"),
-        os.path.join(_ROOT, "gfx-ocean_amd", "csrc", "fft_core.hpp")]
+        os.path.join(_ROOT, "gfx-ocean_amd", "csrc", "fft_core.hpp"),
+        os.path.join(_ROOT, "tests", "hipemu", "ocean_device_intrinsics.hpp")]
 _LIB = None
 
 
@@ -30,6 +31,7 @@ def lib():
         _LIB = ctypes.CDLL(_SO)
         _LIB.emu_frame_pass1.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_size_t] * 2 + [ctypes.c_float] * 2
         _LIB.emu_frame_pass2.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_size_t] * 2
+        _LIB.emu_frame_pass2_thin.argtypes = _LIB.emu_frame_pass2.argtypes
         _LIB.emu_fft_lines.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         _LIB.emu_propagate.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_float] * 2
         _LIB.emu_correct.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4
@@ -70,7 +72,7 @@ def correct(h, dx, dz):
     return out
 
 
-def frame(h0, omega, time, L=1000.0, slab_pad=32, return_inter=False):
+def frame(h0, omega, time, L=1000.0, slab_pad=32, return_inter=False, thin=True):
     n = h0.shape[0]
     P = lib().emu_frame_p(n)
     h0T = np.ascontiguousarray(h0.T, np.complex64)
@@ -81,7 +83,8 @@ def frame(h0, omega, time, L=1000.0, slab_pad=32, return_inter=False):
     tw = twiddles(n)
     assert lib().emu_frame_pass1(n, _p(h0T), _p(omT), _p(inter), _p(tw), slab, fstride, time, L) == 0
     out = np.full((n, n, 4), np.nan, np.float32)
-    assert lib().emu_frame_pass2(n, _p(inter), _p(out), _p(tw), slab, fstride) == 0
+    p2 = lib().emu_frame_pass2_thin if thin else lib().emu_frame_pass2
+    assert p2(n, _p(inter), _p(out), _p(tw), slab, fstride) == 0
     if return_inter:
         return out, inter, (P, slab, fstride)
     return out

@@ -63,6 +63,13 @@ template <int N> static int run_pass2(const c32* inter, float4* out, const c32* 
     return 0;
 }
 
+template <int N> static int run_pass2_thin(const c32* inter, float4* out, const c32* tw, size_t slab, size_t fstride) {
+    using G = Geo<N>;
+    emu_launch(G::thin_grid, G::thin_threads,
+               [&] { k_frame_pass2_thin<N, G::E, G::P, G::R2>(inter, out, tw, slab, fstride); });
+    return 0;
+}
+
 #define DISPATCH(n, CALL)                 \
     switch (n) {                          \
         case 256: return CALL(256);       \
@@ -92,6 +99,11 @@ int emu_frame_pass1(int n, const float* h0T, const float* omT, float* inter, con
 }
 int emu_frame_pass2(int n, const float* inter, float* out, const float* tw, size_t slab, size_t fstride) {
 #define C_(N) run_pass2<N>((const c32*)inter, (float4*)out, (const c32*)tw, slab, fstride)
+    DISPATCH(n, C_)
+#undef C_
+}
+int emu_frame_pass2_thin(int n, const float* inter, float* out, const float* tw, size_t slab, size_t fstride) {
+#define C_(N) run_pass2_thin<N>((const c32*)inter, (float4*)out, (const c32*)tw, slab, fstride)
     DISPATCH(n, C_)
 #undef C_
 }

@@ -32,3 +32,5 @@ static inline void sincospif(float x, float* s, float* c) {
     *s = (float)std::sin(a);
     *c = (float)std::cos(a);
 }
+
+static inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }

@@ -39,18 +39,20 @@ def test_emu_correct(ref_inputs_256):
     assert np.array_equal(emu.correct(h, dx, dz), oc.correction_literal(h, dx, dz))
 
 
+@pytest.mark.parametrize("thin", [True, False])
 @pytest.mark.parametrize("t", [0.0, 1.0, 100.0])
-def test_emu_fused_frame_256(ref_inputs_256, t):
+def test_emu_fused_frame_256(ref_inputs_256, t, thin):
     h0, om = ref_inputs_256
-    out, inter, _ = emu.frame(h0, om, t, return_inter=True)
+    out, inter, _ = emu.frame(h0, om, t, return_inter=True, thin=thin)
     assert not np.isnan(out).any()
     assert_parity(out[..., :3], oc.frame_f64(h0, om, t)[..., :3], 5e-6, "emu fused frame")
     assert np.all(out[..., 3] == 0.0)
 
 
-def test_emu_fused_frame_512(ref_inputs):
+@pytest.mark.parametrize("thin", [True, False])
+def test_emu_fused_frame_512(ref_inputs, thin):
     h0, om = ref_inputs
-    out = emu.frame(h0, om, 10.0)
+    out = emu.frame(h0, om, 10.0, thin=thin)
     assert_parity(out[..., :3], oc.frame_f64(h0, om, 10.0)[..., :3], 5e-6, "emu fused frame 512")
 
 

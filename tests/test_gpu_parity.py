@@ -108,6 +108,21 @@ def test_committed_golden_vectors(r512, r256, name, n, t):
     assert np.allclose(np.sqrt((out.astype(np.float64) ** 2).sum((0, 1))), gold["l2"], rtol=TOL)
 
 
+@pytest.mark.parametrize("t", [0, 1, 10])
+def test_against_the_reference_spirv_outputs(r512, t):
+    """HIP (fused and staged) vs vectors obtained by executing the reference's shipped
+    shader/spv/*.comp.spv on data/*.bin (tests/golden/make_spirv_golden.py)."""
+    gold = np.load(os.path.join(GOLDEN, f"spirv_frame512_t{t}.npz"))
+    scale = gold["max"].max()
+    for mode in ("fused", "staged"):
+        (r512.render_fused if mode == "fused" else r512.render)(float(t))
+        out = r512.displacement()
+        assert np.abs(out[:64, :64] - gold["crop"]).max() <= TOL * scale, mode
+        assert np.abs(out[::8, ::8] - gold["sub8"]).max() <= TOL * scale, mode
+        ch = out[..., :3].astype(np.float64)
+        assert np.allclose(np.sqrt((ch ** 2).sum((0, 1))), gold["l2"], rtol=TOL), mode
+
+
 @pytest.mark.parametrize("n", [1024, 2048])
 def test_synthetic_against_c_oracle(n):
     """config 3 (N=2048, three iFFTs per frame) and N=1024: synthetic inputs, C oracle + fp64."""

@@ -125,3 +125,32 @@ def test_bincode_header(ref_inputs):
     assert h0.shape == (512, 512) and om.shape == (512, 512)
     with open(os.path.join(GOLDEN, "omega.bin"), "rb") as f:
         assert int.from_bytes(f.read(8), "little") == 262144
+
+
+@pytest.mark.parametrize("t", [0, 1, 10])
+def test_literal_oracle_reproduces_the_shipped_spirv_bit_for_bit(ref_inputs, t):
+    """tests/golden/spirv_frame512_t*.npz come from executing the reference's own
+    shader/spv/*.comp.spv (oracle/spirv_interp.py, generator tests/golden/make_spirv_golden.py).
+    The literal restatement must match them bit for bit, stage by stage."""
+    import zlib
+    h0, om = ref_inputs
+    g = np.load(os.path.join(GOLDEN, f"spirv_frame512_t{t}.npz"))
+    img, st = oc.frame_literal(h0, om, float(t), return_stages=True)
+    assert np.array_equal(img[:64, :64].view(np.uint32), g["crop"].view(np.uint32))
+    assert np.array_equal(img[::8, ::8].view(np.uint32), g["sub8"].view(np.uint32))
+    assert zlib.crc32(img.tobytes()) == int(g["crc_image"])
+    for key, name in (("propagate", "crc_propagate"), ("rows", "crc_fft_row"), ("cols", "crc_fft_col")):
+        for buf, crc in zip(st[key], g[name]):      # order: height, disp_x, disp_z
+            raw = np.ascontiguousarray(buf, np.complex64).view(np.float32).tobytes()
+            assert zlib.crc32(raw) == int(crc), (key, t)
+
+
+def test_spirv_interpreter_against_reference_binaries_when_present(ref_inputs):
+    """Build container only: re-run the interpreter on /root/reference's binaries."""
+    spv = "/root/reference/shader/spv"
+    if not os.path.isdir(spv):
+        pytest.skip("reference tree not present (GPU box)")
+    from oracle import spirv_interp as si
+    h0, om = ref_inputs
+    img = si.run_reference_frame(spv, h0, om, 2.5)
+    assert np.array_equal(img.view(np.uint32), oc.frame_literal(h0, om, 2.5).view(np.uint32))
