@@ -45,7 +45,7 @@ struct OceanContext {
     c32* h0T = nullptr;
     float* omegaT = nullptr;
     c32* inter = nullptr;
-    size_t slab = 0, field_stride = 0;
+    InterLayout lay{0, 0, 0};
     int P = 0;
     c32* tw = nullptr;          // e^{+2 pi i k/N}
     float4* out_own = nullptr;  // displacement map (src/render.rs:820-869), linear RGBA32F
@@ -114,15 +114,15 @@ template <int N> struct Launch {
     }
     static void pass1(OceanContext* c, float time, float domain, hipStream_t s) {
         hipLaunchKernelGGL((k_frame_pass1<N, G::E, G::P>), dim3(G::frame_grid), dim3(G::frame_threads),
-                           G::frame_lds, s, c->h0T, c->omegaT, c->inter, c->tw, c->slab, c->field_stride, time, domain);
+                           G::frame_lds, s, c->h0T, c->omegaT, c->inter, c->tw, c->lay, time, domain);
     }
     static void pass2(OceanContext* c, hipStream_t s) {
         if (c->pass2_thin)
             hipLaunchKernelGGL((k_frame_pass2_thin<N, G::E, G::P, G::R2>), dim3(G::thin_grid), dim3(G::thin_threads),
-                               G::thin_lds, s, c->inter, c->out, c->tw, c->slab, c->field_stride);
+                               G::thin_lds, s, c->inter, c->out, c->tw, c->lay);
         else
             hipLaunchKernelGGL((k_frame_pass2<N, G::E, G::P>), dim3(G::frame_grid), dim3(G::frame_threads),
-                               G::frame_lds, s, c->inter, c->out, c->tw, c->slab, c->field_stride);
+                               G::frame_lds, s, c->inter, c->out, c->tw, c->lay);
     }
 };
 
@@ -193,10 +193,25 @@ int32_t ocean_context_create(int32_t device, int32_t resolution, OceanContext** 
     DeviceGuard guard(device);
     const size_t n2 = (size_t)resolution * resolution;
     c->P = frame_p(resolution);
-    // slab = one x-group of the intermediate (N rows x P columns); +32 elements (256 B) so that
-    // consecutive slabs do not start on the same channel for the strided chunk reads of pass 2
-    c->slab = (size_t)resolution * c->P + 32;
-    c->field_stride = c->slab * (size_t)(resolution / c->P);
+    {
+        // chunk (X, Y) of the intermediate at X*sx + Y*sy; +32 elements (256 B) of padding per slab so
+        // that the strided side of the hand-off does not revisit one HBM channel
+        const size_t groups = (size_t)(resolution / c->P), chunk = (size_t)c->P * c->P;
+        // P = 4 (128-byte chunks): pass-2-contiguous is 25 us/frame faster at N = 4096.
+        // P = 2 (N = 8192, 32-byte chunk rows): scattering 64-byte chunks from pass 1 is 3x slower
+        // than gathering them in pass 2, so that size keeps the pass-1-contiguous layout.
+        const char* v = std::getenv("OCEAN_INTER_LAYOUT");
+        const bool p1 = v ? (std::strcmp(v, "p1") == 0) : (c->P < 4);
+        if (p1) {                                  // pass-1-contiguous
+            c->lay.sy = chunk;
+            c->lay.sx = groups * chunk + 32;
+            c->lay.fs = c->lay.sx * groups;
+        } else {                                   // pass-2-contiguous
+            c->lay.sx = chunk;
+            c->lay.sy = groups * chunk + 32;
+            c->lay.fs = c->lay.sy * groups;
+        }
+    }
     auto bail = [&](hipError_t err, const char* what) {
         const int32_t code = hip_fail(nullptr, err, what);
         free_all(c);
@@ -210,7 +225,7 @@ int32_t ocean_context_create(int32_t device, int32_t resolution, OceanContext** 
     for (int f = 0; f < 3; ++f) CTX_TRY(hipMalloc((void**)&c->field[f], n2 * sizeof(c32)));
     CTX_TRY(hipMalloc((void**)&c->h0T, n2 * sizeof(c32)));
     CTX_TRY(hipMalloc((void**)&c->omegaT, n2 * sizeof(float)));
-    CTX_TRY(hipMalloc((void**)&c->inter, 3 * c->field_stride * sizeof(c32)));
+    CTX_TRY(hipMalloc((void**)&c->inter, 3 * c->lay.fs * sizeof(c32)));
     CTX_TRY(hipMalloc((void**)&c->out_own, n2 * sizeof(float4)));
     CTX_TRY(hipMalloc((void**)&c->tw, (size_t)resolution * sizeof(c32)));
     c->out = c->out_own;

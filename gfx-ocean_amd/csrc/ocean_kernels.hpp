@@ -8,8 +8,8 @@
 // Fused frame (2 launches, 76 B/texel of HBM traffic instead of the reference's 172):
 //   k_frame_pass1: propagate + FFT along y for the three fields, reading the *transposed* static
 //                  inputs (h0T, omegaT; made once at upload) so every line is contiguous;
-//                  writes the intermediate in a [x/P][y][x%P] layout (P*P*8-byte chunks).
-//   k_frame_pass2: FFT along x of P rows per workgroup + sign correction + RGBA pack; full-row
+//                  writes the intermediate as P x P chunks (128 bytes).
+//   k_frame_pass2_thin (or k_frame_pass2): FFT along x + sign correction + RGBA pack; full-row
 //                  contiguous float4 stores.
 // The column transform runs first in the fused path (a separable 2-D DFT commutes), so that the
 // pass that owns whole rows is the one that writes the row-major RGBA image.
@@ -155,9 +155,15 @@ k_fft_lines(c32* __restrict__ data, const c32* __restrict__ tw) {
 // ---------------------------------------------------------------------------------------------
 // Fused frame
 // ---------------------------------------------------------------------------------------------
-// Intermediate layout of one field: inter[X * slab + y * P + c], X = x / P, c = x % P;
-// slab >= N*P elements (padded so that consecutive slabs do not start on the same HBM channel).
+// Intermediate (between the two passes): P x P chunks of c32 (128 bytes for P = 4).  Chunk (X, Y)
+// holds columns x = X*P + c and rows y = Y*P + r at offset r*P + c.  Its address is
+//     field * fs + X * sx + Y * sy          (elements)
+// The shipped layout is "pass-2-contiguous": sx = P*P, sy = (N/P)*P*P + pad, i.e. the chunks of one
+// row group are adjacent, so pass 2 streams 128 KiB contiguous per row group while pass 1 scatters
+// 128-byte chunks with a 128 KiB stride (measured 25 us/frame faster at N = 4096 than the
+// opposite choice; both are selectable at context creation for A/B runs).
 // Field order in the intermediate: 0 = disp_x, 1 = height, 2 = disp_z (OCEAN_FIELD_*).
+struct InterLayout { size_t sx, sy, fs; };
 
 // Map block -> x-group so that a group and its mirror (which read the same two h0T line sets)
 // run on the same XCD, 8 blocks apart.
@@ -168,20 +174,26 @@ __device__ __forceinline__ int pass1_group(int b, int groups) {
     return (r >> 3) ? (groups - 1 - p) : p;
 }
 
+// Pass 1: propagate + FFT along y of P adjacent columns x = X*P + c for the three fields, reading
+// the transposed static inputs (every line contiguous).  Thread = (c = tid / T, j = tid % T): a
+// wave stays inside one line, so the h0T / omegaT loads are 512-byte contiguous per instruction.
+// The last FFT pass scatters into LDS and the chunks are assembled from there (16-byte lanes,
+// 8 lanes per 128-byte chunk).  [A "column index fastest" mapping that stores chunks straight from
+// registers was measured 10 us slower at N = 4096: 8-byte lanes, 4 lines per wave on the loads.]
 template <int N, int E, int P>
 __global__ void __launch_bounds__((N / E) * P)
 k_frame_pass1(const c32* __restrict__ h0T, const float* __restrict__ omegaT, c32* __restrict__ inter,
-              const c32* __restrict__ tw, size_t slab, size_t field_stride, float time, float domain_size) {
+              const c32* __restrict__ tw, InterLayout lay, float time, float domain_size) {
     constexpr int T = N / E;
     constexpr int H2 = P / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     c32* lds = reinterpret_cast<c32*>(smem);
     const int tid = threadIdx.x;
-    const int ll = (T >= 64) ? wave_uniform(tid / T) : (tid / T);   // a wave never straddles lines when T >= 64
+    const int c = (T >= 64) ? wave_uniform(tid / T) : (tid / T);   // a wave never straddles lines when T >= 64
     const int j = tid % T;
     const int X = pass1_group(blockIdx.x, gridDim.x);
-    const uint32_t x = (uint32_t)(X * P + ll);                     // gl_GlobalInvocationID.x
-    c32* lds_line = lds + ll * LinePitch<N>::elems;
+    const uint32_t x = (uint32_t)(X * P + c);                      // gl_GlobalInvocationID.x
+    c32* lds_line = lds + c * LinePitch<N>::elems;
 
     // propagate.comp:42-72 along the transposed inputs: own line x, mirror line N-1-x reversed.
     const c32* own = h0T + (size_t)x * N;
@@ -196,7 +208,11 @@ k_frame_pass1(const c32* __restrict__ h0T, const float* __restrict__ omegaT, c32
         hs[e] = propagate_height(own[y], mir[N - 1 - y], om[y], time);
     }
 
-    c32* out_group = inter + (size_t)X * slab;
+    // chunk assembly coordinates: thread -> (column pair h, row y = i + q*2T)
+    const int h = tid % H2;
+    const int i = tid / H2;
+    const c32* l0 = lds + (2 * h) * LinePitch<N>::elems;
+    const c32* l1 = lds + (2 * h + 1) * LinePitch<N>::elems;
 #pragma unroll
     for (int f = 0; f < 3; ++f) {
         c32 reg[E];
@@ -213,69 +229,44 @@ k_frame_pass1(const c32* __restrict__ h0T, const float* __restrict__ omegaT, c32
             }
         }
         if (f > 0) __syncthreads();                                // previous field's LDS reads done
-        fft_line_to_lds<N, E>(reg, jf, tw, lds_line);               // ends with data in LDS + barrier
-        // chunk-order store: thread -> (column pair h, position i + q*2T): 16-B lanes, contiguous
-        c32* dst = out_group + (size_t)f * field_stride;
-        const int h = tid % H2;
-        const int i = tid / H2;
-        const c32* l0 = lds + (2 * h) * LinePitch<N>::elems;
-        const c32* l1 = lds + (2 * h + 1) * LinePitch<N>::elems;
+        fft_line_to_lds<N, E>(reg, jf, tw, lds_line);              // ends with data in LDS + barrier
+        // row y -> chunk row Y = y / P, r = y % P; (2T) % P == 0 keeps r fixed per thread
+        c32* dst = inter + (size_t)f * lay.fs + (size_t)X * lay.sx + (size_t)(i / P) * lay.sy + (i % P) * P + 2 * h;
 #pragma unroll
         for (int q = 0; q < E / 2; ++q) {
             const int y = i + q * (2 * T);
             const c32 v0 = l0[lds_pad(y)];
             const c32 v1 = l1[lds_pad(y)];
-            *reinterpret_cast<float4*>(dst + (size_t)y * P + 2 * h) = make_float4(v0.x, v0.y, v1.x, v1.y);
+            *reinterpret_cast<float4*>(dst + (size_t)q * ((2 * T) / P) * lay.sy) = make_float4(v0.x, v0.y, v1.x, v1.y);
         }
     }
 }
 
+// Pass 2 ("fat": P rows per workgroup, used for A/B measurements): thread = (r = tid % P, j = tid / P),
+// row index fastest, so 16 lanes read one whole 128-byte chunk and no LDS input exchange is needed.
 template <int N, int E, int P>
 __global__ void __launch_bounds__((N / E) * P)
-k_frame_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32* __restrict__ tw,
-              size_t slab, size_t field_stride) {
+k_frame_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32* __restrict__ tw, InterLayout lay) {
     constexpr int T = N / E;
-    constexpr int H2 = P / 2;
+    static_assert(T % P == 0, "a thread's elements must keep the same column within a chunk");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     c32* lds = reinterpret_cast<c32*>(smem);
     const int tid = threadIdx.x;
-    const int ll = (T >= 64) ? wave_uniform(tid / T) : (tid / T);
-    const int j = tid % T;
+    const int r = tid % P;
+    const int j = tid / P;
     const int Y = blockIdx.x;
-    const int y = Y * P + ll;
-    c32* lds_line = lds + ll * LinePitch<N>::elems;
-
-    // chunk-order load coordinates: P*H2 consecutive threads read one P x P chunk (P*P*8 bytes)
-    const int h = tid % H2;
-    const int r = (tid / H2) % P;
-    const int xi = tid / (H2 * P);
-    constexpr int XSTEP = (2 * T) / P;       // chunks covered by the workgroup per iteration
-    c32* lds_r = lds + r * LinePitch<N>::elems;
+    const int y = Y * P + r;
+    c32* lds_line = lds + r * LinePitch<N>::elems;
 
     float keep[2][E];
 #pragma unroll
     for (int f = 0; f < 3; ++f) {
-        const c32* src = inter + (size_t)f * field_stride + (size_t)(Y * P + r) * P + 2 * h;
-        float4 v[E / 2];
-#pragma unroll
-        for (int q = 0; q < E / 2; ++q) {
-            const int X = xi + q * XSTEP;
-            v[q] = *reinterpret_cast<const float4*>(src + (size_t)X * slab);
-        }
-        if (f > 0) __syncthreads();                                // previous field's LDS reads done
-#pragma unroll
-        for (int q = 0; q < E / 2; ++q) {
-            const int x0 = (xi + q * XSTEP) * P + 2 * h;
-            lds_r[lds_pad(x0)] = make_float2(v[q].x, v[q].y);
-            lds_r[lds_pad(x0 + 1)] = make_float2(v[q].z, v[q].w);
-        }
-        __syncthreads();
-        c32 reg[E];
         const int jf = opaque_lane(j);                             // no twiddle CSE across fields
-        const c32* g = lds_line + lds_pad(jf);
+        const c32* src = inter + (size_t)f * lay.fs + (size_t)Y * lay.sy + (size_t)(jf / P) * lay.sx + r * P + (jf % P);
+        c32 reg[E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) reg[e] = g[e * (T + T / 16)];  // = lds_pad(j + e*T)
-        __syncthreads();
+        for (int e = 0; e < E; ++e) reg[e] = src[(size_t)e * (T / P) * lay.sx];
+        if (f > 0) __syncthreads();                                // previous field's LDS reads done
         fft_line<N, E>(reg, jf, tw, lds_line);
         if (f < 2) {
 #pragma unroll
@@ -292,15 +283,16 @@ k_frame_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32
     }
 }
 
-// Thin variant of pass 2: R2 rows per workgroup (R2 = 1 at N >= 4096: 256 threads, ~35 KiB LDS,
+// Pass 2 ("thin", shipped): R2 rows per workgroup (R2 = 1 at N >= 4096: 256 threads, ~35 KiB LDS,
 // 4 workgroups per CU like k_fft_lines<ROW>), each thread gathering its own row straight from the
-// chunked intermediate (8*P1-byte row of a P1 x P1 chunk per 4 lanes).  The P1/R2 workgroups that
+// chunked intermediate (8*P1-byte row of a P1 x P1 chunk per P1 lanes).  The P1/R2 workgroups that
 // share a chunk run on the same XCD in adjacent dispatch slots, so the other rows of a 128-byte
-// line are L2 hits rather than HBM re-reads.  No LDS input exchange, no 1024-thread barriers.
+// line are L2 hits rather than HBM re-reads (measured: +9% fetch over ideal, 270 -> 140 us vs an
+// unmapped grid).  The FFT is fully hidden behind the memory stream here (ablation: removing it
+// does not make the kernel faster).
 template <int N, int E, int P1, int R2>
 __global__ void __launch_bounds__((N / E) * R2)
-k_frame_pass2_thin(const c32* __restrict__ inter, float4* __restrict__ out, const c32* __restrict__ tw,
-                   size_t slab, size_t field_stride) {
+k_frame_pass2_thin(const c32* __restrict__ inter, float4* __restrict__ out, const c32* __restrict__ tw, InterLayout lay) {
     constexpr int T = N / E;
     static_assert(T % P1 == 0, "a thread's elements must keep the same column within a chunk");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -322,11 +314,12 @@ k_frame_pass2_thin(const c32* __restrict__ inter, float4* __restrict__ out, cons
 #pragma unroll
     for (int f = 0; f < 3; ++f) {
         const int jf = opaque_lane(j);                             // no twiddle CSE across fields
-        // element x = jf + e*T lives at (x / P1) * slab + y * P1 + x % P1; T % P1 == 0
-        const c32* src = inter + (size_t)f * field_stride + (size_t)(jf / P1) * slab + (size_t)y * P1 + (jf % P1);
+        // element x = jf + e*T: chunk X = x / P1, c = x % P1 (T % P1 == 0); row y: Y = y / P1, r = y % P1
+        const c32* src = inter + (size_t)f * lay.fs + (size_t)(y / P1) * lay.sy + (size_t)(jf / P1) * lay.sx +
+                         (y % P1) * P1 + (jf % P1);
         c32 reg[E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) reg[e] = src[(size_t)e * (T / P1) * slab];
+        for (int e = 0; e < E; ++e) reg[e] = src[(size_t)e * (T / P1) * lay.sx];
         if (f > 0) __syncthreads();                                // previous field's LDS reads done
         fft_line<N, E>(reg, jf, tw, lds_line);
         if (f < 2) {

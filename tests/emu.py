@@ -29,8 +29,8 @@ def lib():
     if _LIB is None:
         build()
         _LIB = ctypes.CDLL(_SO)
-        _LIB.emu_frame_pass1.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_size_t] * 2 + [ctypes.c_float] * 2
-        _LIB.emu_frame_pass2.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_size_t] * 2
+        _LIB.emu_frame_pass1.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_size_t] * 3 + [ctypes.c_float] * 2
+        _LIB.emu_frame_pass2.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_size_t] * 3
         _LIB.emu_frame_pass2_thin.argtypes = _LIB.emu_frame_pass2.argtypes
         _LIB.emu_fft_lines.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         _LIB.emu_propagate.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_float] * 2
@@ -72,19 +72,38 @@ def correct(h, dx, dz):
     return out
 
 
-def frame(h0, omega, time, L=1000.0, slab_pad=32, return_inter=False, thin=True):
+def inter_layout(n, P, layout="p2", pad=32):
+    """(sx, sy, fs) in elements -- mirrors ocean_context_create."""
+    groups, chunk = n // P, P * P
+    if layout == "p1":
+        sy, sx = chunk, groups * chunk + pad
+        return sx, sy, sx * groups
+    sx, sy = chunk, groups * chunk + pad
+    return sx, sy, sy * groups
+
+
+def unpack_inter(inter, n, P, lay, f):
+    """Intermediate field f -> natural [y, x] array (NaN where never written)."""
+    sx, sy, fs = lay
+    X, Y, r, c = np.meshgrid(np.arange(n // P), np.arange(n // P), np.arange(P), np.arange(P), indexing="ij")
+    idx = f * fs + X * sx + Y * sy + r * P + c
+    out = np.empty((n, n), np.complex64)
+    out[(Y * P + r).ravel(), (X * P + c).ravel()] = inter[idx.ravel()]
+    return out
+
+
+def frame(h0, omega, time, L=1000.0, return_inter=False, thin=True, layout="p2"):
     n = h0.shape[0]
     P = lib().emu_frame_p(n)
     h0T = np.ascontiguousarray(h0.T, np.complex64)
     omT = np.ascontiguousarray(omega.T, np.float32)
-    slab = n * P + slab_pad
-    fstride = slab * (n // P)
-    inter = np.full(3 * fstride, np.nan + 1j * np.nan, np.complex64)
+    sx, sy, fs = inter_layout(n, P, layout)
+    inter = np.full(3 * fs, np.nan + 1j * np.nan, np.complex64)
     tw = twiddles(n)
-    assert lib().emu_frame_pass1(n, _p(h0T), _p(omT), _p(inter), _p(tw), slab, fstride, time, L) == 0
+    assert lib().emu_frame_pass1(n, _p(h0T), _p(omT), _p(inter), _p(tw), sx, sy, fs, time, L) == 0
     out = np.full((n, n, 4), np.nan, np.float32)
     p2 = lib().emu_frame_pass2_thin if thin else lib().emu_frame_pass2
-    assert p2(n, _p(inter), _p(out), _p(tw), slab, fstride) == 0
+    assert p2(n, _p(inter), _p(out), _p(tw), sx, sy, fs) == 0
     if return_inter:
-        return out, inter, (P, slab, fstride)
+        return out, inter, (P, (sx, sy, fs))
     return out

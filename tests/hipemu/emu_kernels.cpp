@@ -50,23 +50,23 @@ template <int N> static int run_fft_lines(int col, c32* data, const c32* tw) {
     else emu_launch(G::row_grid, G::row_threads, [&] { k_fft_lines<N, G::E, G::ROW_LPW, false>(data, tw); });
     return 0;
 }
-template <int N> static int run_pass1(const c32* h0T, const float* omT, c32* inter, const c32* tw, size_t slab,
-                                      size_t fstride, float time, float L) {
+template <int N> static int run_pass1(const c32* h0T, const float* omT, c32* inter, const c32* tw, InterLayout lay,
+                                      float time, float L) {
     using G = Geo<N>;
     emu_launch(G::frame_grid, G::frame_threads,
-               [&] { k_frame_pass1<N, G::E, G::P>(h0T, omT, inter, tw, slab, fstride, time, L); });
+               [&] { k_frame_pass1<N, G::E, G::P>(h0T, omT, inter, tw, lay, time, L); });
     return 0;
 }
-template <int N> static int run_pass2(const c32* inter, float4* out, const c32* tw, size_t slab, size_t fstride) {
+template <int N> static int run_pass2(const c32* inter, float4* out, const c32* tw, InterLayout lay) {
     using G = Geo<N>;
-    emu_launch(G::frame_grid, G::frame_threads, [&] { k_frame_pass2<N, G::E, G::P>(inter, out, tw, slab, fstride); });
+    emu_launch(G::frame_grid, G::frame_threads, [&] { k_frame_pass2<N, G::E, G::P>(inter, out, tw, lay); });
     return 0;
 }
 
-template <int N> static int run_pass2_thin(const c32* inter, float4* out, const c32* tw, size_t slab, size_t fstride) {
+template <int N> static int run_pass2_thin(const c32* inter, float4* out, const c32* tw, InterLayout lay) {
     using G = Geo<N>;
     emu_launch(G::thin_grid, G::thin_threads,
-               [&] { k_frame_pass2_thin<N, G::E, G::P, G::R2>(inter, out, tw, slab, fstride); });
+               [&] { k_frame_pass2_thin<N, G::E, G::P, G::R2>(inter, out, tw, lay); });
     return 0;
 }
 
@@ -91,19 +91,19 @@ int emu_fft_lines(int n, int col, float* data, const float* tw) {
     DISPATCH(n, C_)
 #undef C_
 }
-int emu_frame_pass1(int n, const float* h0T, const float* omT, float* inter, const float* tw, size_t slab,
-                    size_t fstride, float time, float L) {
-#define C_(N) run_pass1<N>((const c32*)h0T, omT, (c32*)inter, (const c32*)tw, slab, fstride, time, L)
+int emu_frame_pass1(int n, const float* h0T, const float* omT, float* inter, const float* tw, size_t sx, size_t sy,
+                    size_t fs, float time, float L) {
+#define C_(N) run_pass1<N>((const c32*)h0T, omT, (c32*)inter, (const c32*)tw, InterLayout{sx, sy, fs}, time, L)
     DISPATCH(n, C_)
 #undef C_
 }
-int emu_frame_pass2(int n, const float* inter, float* out, const float* tw, size_t slab, size_t fstride) {
-#define C_(N) run_pass2<N>((const c32*)inter, (float4*)out, (const c32*)tw, slab, fstride)
+int emu_frame_pass2(int n, const float* inter, float* out, const float* tw, size_t sx, size_t sy, size_t fs) {
+#define C_(N) run_pass2<N>((const c32*)inter, (float4*)out, (const c32*)tw, InterLayout{sx, sy, fs})
     DISPATCH(n, C_)
 #undef C_
 }
-int emu_frame_pass2_thin(int n, const float* inter, float* out, const float* tw, size_t slab, size_t fstride) {
-#define C_(N) run_pass2_thin<N>((const c32*)inter, (float4*)out, (const c32*)tw, slab, fstride)
+int emu_frame_pass2_thin(int n, const float* inter, float* out, const float* tw, size_t sx, size_t sy, size_t fs) {
+#define C_(N) run_pass2_thin<N>((const c32*)inter, (float4*)out, (const c32*)tw, InterLayout{sx, sy, fs})
     DISPATCH(n, C_)
 #undef C_
 }

@@ -56,18 +56,16 @@ def test_emu_fused_frame_512(ref_inputs, thin):
     assert_parity(out[..., :3], oc.frame_f64(h0, om, 10.0)[..., :3], 5e-6, "emu fused frame 512")
 
 
-def test_emu_intermediate_layout(ref_inputs_256):
-    """pass1 writes inter[f][X*slab + y*P + c] = column FFT of field f at (y, x = X*P + c)."""
+@pytest.mark.parametrize("layout", ["p2", "p1"])
+def test_emu_intermediate_layout(ref_inputs_256, layout):
+    """pass 1 writes P x P chunks: chunk (X, Y) of field f at f*fs + X*sx + Y*sy, element (r, c) at
+    r*P + c = the FFT along y of field f at (y = Y*P + r, x = X*P + c); padding is never written."""
     h0, om = ref_inputs_256
     n = 256
-    _, inter, (P, slab, fstride) = emu.frame(h0, om, 2.0, return_inter=True)
+    out, inter, (P, lay) = emu.frame(h0, om, 2.0, return_inter=True, layout=layout)
     h, dx, dz = oc.propagate_f64(h0, om, 2.0)
     for f, spec in ((0, dx), (1, h), (2, dz)):
         ref = np.fft.ifft(spec, axis=0) * n          # transform along y only
-        got = np.empty((n, n), np.complex64)
-        for X in range(n // P):
-            blk = inter[f * fstride + X * slab: f * fstride + X * slab + n * P].reshape(n, P)
-            got[:, X * P:(X + 1) * P] = blk
-        assert_parity(got, ref, 5e-6, f"intermediate field {f}")
-    pad = inter[slab - 32 + 0: slab]                 # the slab padding is never written
-    assert np.isnan(pad.real).all()
+        assert_parity(emu.unpack_inter(inter, n, P, lay, f), ref, 5e-6, f"intermediate field {f}")
+    assert np.isnan(inter.real).sum() == 3 * (lay[2] - n * n)     # exactly the padding is untouched
+    assert_parity(out[..., :3], oc.frame_f64(h0, om, 2.0)[..., :3], 5e-6, "frame")
