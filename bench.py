@@ -35,6 +35,22 @@ def aggregate(values_ms, n_gpus, steps):
     return {"ms_per_step": ms_per_step, "value": n_gpus * 1000.0 / ms_per_step}
 
 
+def measured_traffic(n, kernel_name):
+    """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and
+    WRITE_SIZE are collected in separate runs of this same command, never inside the timed bench;
+    gfx950 correction 2*FETCH_SIZE + WRITE_SIZE -- DESIGN.md 7).  None if no pass exists for this N."""
+    path = os.path.join(ROOT, "profiles", f"hbm_traffic_n{n}.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    for k, v in rec.items():
+        if kernel_name.startswith(k) or k.startswith(kernel_name):
+            return v["hbm_bytes"]
+    return None
+
+
 def tile_seed(n, rank):
     return n + rank     # SURVEY.md 8d: tile r of a multi-GPU run uses seed N + r
 
@@ -124,7 +140,7 @@ def main():
         kernels.append({"name": name, "avg_ms": avg_ms, "algorithmic_bytes": b, "GBps": b / avg_ms / 1e6})
     dom = max(kernels, key=lambda k: k["avg_ms"])
     roofline = {"bound": "hbm", "kernel": dom["name"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": None,
+                "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": measured_traffic(n, dom["name"]),
                 "algorithmic_bytes_per_launch": dom["algorithmic_bytes"], "avg_launch_ms": dom["avg_ms"],
                 "kernels": kernels,
                 "frame": {"algorithmic_bytes": 76.0 * n * n, "GBps": 76.0 * n * n / (event_ms / args.steps) / 1e6,

@@ -1,0 +1,54 @@
+//! Raw bindings of include/ocean_hip.h (one line per exported symbol).
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_void};
+
+#[repr(C)]
+pub struct OceanContext { _p: [u8; 0] }
+#[repr(C)]
+pub struct OceanFft { _p: [u8; 0] }
+#[repr(C)]
+pub struct OceanPropagation { _p: [u8; 0] }
+#[repr(C)]
+pub struct OceanCorrection { _p: [u8; 0] }
+
+/// src/ocean.rs:8-13 -- here with the explicit layout the reference relies on by accident (Q6).
+#[repr(C)]
+#[derive(Debug, Clone, Copy)]
+pub struct OceanPropagateLocals { pub time: f32, pub resolution: i32, pub domain_size: f32 }
+/// src/ocean.rs:179-182
+#[repr(C)]
+#[derive(Debug, Clone, Copy)]
+pub struct OceanCorrectionLocals { pub resolution: u32 }
+
+extern "C" {
+    pub fn ocean_abi_version() -> i32;
+    pub fn ocean_context_create(device: i32, resolution: i32, out: *mut *mut OceanContext) -> i32;
+    pub fn ocean_context_destroy(ctx: *mut OceanContext);
+    pub fn ocean_last_error(ctx: *const OceanContext) -> *const c_char;
+    pub fn ocean_resolution(ctx: *const OceanContext) -> i32;
+    pub fn ocean_upload_spectrum(ctx: *mut OceanContext, h0_re_im: *const f32, omega: *const f32) -> i32;
+    pub fn ocean_fft_init(ctx: *mut OceanContext, out: *mut *mut OceanFft) -> i32;
+    pub fn ocean_fft_destroy(fft: *mut OceanFft);
+    pub fn ocean_propagation_init(ctx: *mut OceanContext, out: *mut *mut OceanPropagation) -> i32;
+    pub fn ocean_propagation_destroy(p: *mut OceanPropagation);
+    pub fn ocean_correction_init(ctx: *mut OceanContext, out: *mut *mut OceanCorrection) -> i32;
+    pub fn ocean_correction_destroy(c: *mut OceanCorrection);
+    pub fn ocean_propagate(p: *mut OceanPropagation, locals: *const OceanPropagateLocals, stream: *mut c_void) -> i32;
+    pub fn ocean_fft_rows(fft: *mut OceanFft, field: i32, stream: *mut c_void) -> i32;
+    pub fn ocean_fft_cols(fft: *mut OceanFft, field: i32, stream: *mut c_void) -> i32;
+    pub fn ocean_correct(c: *mut OceanCorrection, locals: *const OceanCorrectionLocals, stream: *mut c_void) -> i32;
+    pub fn ocean_frame(ctx: *mut OceanContext, time: f32, stream: *mut c_void) -> i32;
+    pub fn ocean_frame_ex(ctx: *mut OceanContext, locals: *const OceanPropagateLocals, stream: *mut c_void) -> i32;
+    pub fn ocean_sync(ctx: *mut OceanContext) -> i32;
+    pub fn ocean_read_displacement(ctx: *mut OceanContext, host_rgba: *mut f32) -> i32;
+    pub fn ocean_read_field(ctx: *mut OceanContext, field: i32, host_re_im: *mut f32) -> i32;
+    pub fn ocean_write_field(ctx: *mut OceanContext, field: i32, host_re_im: *const f32) -> i32;
+    pub fn ocean_displacement_device_ptr(ctx: *mut OceanContext) -> *mut c_void;
+    pub fn ocean_bind_displacement(ctx: *mut OceanContext, device_rgba: *mut c_void) -> i32;
+    pub fn ocean_stream(ctx: *mut OceanContext) -> *mut c_void;
+    pub fn ocean_time_frames(ctx: *mut OceanContext, frames: i32, t0: f32, dt: f32, out_ms: *mut f32) -> i32;
+    pub fn ocean_profile_frame(ctx: *mut OceanContext, time: f32, cap: i32, names: *mut *const c_char,
+                               ms: *mut f32, out_n: *mut i32) -> i32;
+    pub fn ocean_profile_staged(ctx: *mut OceanContext, time: f32, cap: i32, names: *mut *const c_char,
+                                ms: *mut f32, out_n: *mut i32) -> i32;
+}

@@ -1,0 +1,129 @@
+//! `ocean_hip`: the reference's `mod ocean` / `mod fft` names over the MI355X C ABI.
+//!
+//! In gfx-ocean, `src/render.rs:223-225` becomes
+//! ```ignore
+//! let device = ocean_hip::Device::new(0, RESOLUTION as i32)?;      // replaces the gfx_hal buffers of :607-670
+//! let mut fft = ocean_hip::fft::Fft::init(&device)?;
+//! let mut propagation = ocean_hip::ocean::Propagation::init(&device)?;
+//! let mut correction = ocean_hip::ocean::Correction::init(&device)?;
+//! device.upload_spectrum(&spectrum, &omega)?;                      // replaces :742-924
+//! ```
+//! and the dispatch block `:1101-1310` becomes
+//! ```ignore
+//! propagation.dispatch(&PropagateLocals { time, resolution: RESOLUTION as i32, domain_size: DOMAIN_SIZE })?;
+//! fft.row_pass(fft::FIELD_ALL)?;
+//! fft.col_pass(fft::FIELD_ALL)?;
+//! correction.dispatch(&CorrectionLocals { resolution: RESOLUTION as u32 })?;
+//! // or, fused:  device.frame(time)?;
+//! ```
+pub mod ffi;
+
+use std::error::Error;
+use std::ffi::CStr;
+use std::fmt;
+use std::ptr;
+
+#[derive(Debug)]
+pub struct OceanError { pub status: i32, pub message: String }
+impl fmt::Display for OceanError {
+    fn fmt(&self, f: &mut fmt::Formatter<'_>) -> fmt::Result { write!(f, "ocean_hip status {}: {}", self.status, self.message) }
+}
+impl Error for OceanError {}
+
+/// One GPU + the buffers of the path (the slice of `Renderer` in src/render.rs:72-101 the compute path owns).
+pub struct Device { ctx: *mut ffi::OceanContext }
+
+impl Device {
+    pub fn new(ordinal: i32, resolution: i32) -> Result<Self, Box<dyn Error>> {
+        let mut ctx = ptr::null_mut();
+        let st = unsafe { ffi::ocean_context_create(ordinal, resolution, &mut ctx) };
+        if st != 0 { return Err(Box::new(error(ptr::null(), st))); }
+        Ok(Device { ctx })
+    }
+    fn check(&self, st: i32) -> Result<(), Box<dyn Error>> {
+        if st == 0 { Ok(()) } else { Err(Box::new(error(self.ctx, st))) }
+    }
+    /// bincode-decoded `Vec<[f32; 2]>` / `Vec<f32>` exactly as src/render.rs:769-771, :808-810 produce them.
+    pub fn upload_spectrum(&self, spectrum: &[[f32; 2]], omega: &[f32]) -> Result<(), Box<dyn Error>> {
+        self.check(unsafe { ffi::ocean_upload_spectrum(self.ctx, spectrum.as_ptr() as *const f32, omega.as_ptr()) })
+    }
+    pub fn frame(&self, time: f32) -> Result<(), Box<dyn Error>> {
+        self.check(unsafe { ffi::ocean_frame(self.ctx, time, ptr::null_mut()) })
+    }
+    pub fn read_displacement(&self, rgba: &mut [f32]) -> Result<(), Box<dyn Error>> {
+        self.check(unsafe { ffi::ocean_read_displacement(self.ctx, rgba.as_mut_ptr()) })
+    }
+    pub fn raw(&self) -> *mut ffi::OceanContext { self.ctx }
+}
+impl Drop for Device { fn drop(&mut self) { unsafe { ffi::ocean_context_destroy(self.ctx) } } }
+
+fn error(ctx: *const ffi::OceanContext, status: i32) -> OceanError {
+    let message = unsafe { CStr::from_ptr(ffi::ocean_last_error(ctx)) }.to_string_lossy().into_owned();
+    OceanError { status, message }
+}
+
+pub mod ocean {
+    //! src/ocean.rs
+    use super::*;
+    pub use crate::ffi::OceanCorrectionLocals as CorrectionLocals;
+    pub use crate::ffi::OceanPropagateLocals as PropagateLocals;
+
+    /// src/ocean.rs:15-177
+    pub struct Propagation<'d> { h: *mut ffi::OceanPropagation, device: &'d Device }
+    impl<'d> Propagation<'d> {
+        pub fn init(device: &'d Device) -> Result<Self, Box<dyn Error>> {
+            let mut h = ptr::null_mut();
+            device.check(unsafe { ffi::ocean_propagation_init(device.raw(), &mut h) })?;
+            Ok(Propagation { h, device })
+        }
+        /// bind pipeline + descriptor set + dispatch [N/16, N/16, 1] (src/render.rs:1101-1130)
+        pub fn dispatch(&mut self, locals: &PropagateLocals) -> Result<(), Box<dyn Error>> {
+            self.device.check(unsafe { ffi::ocean_propagate(self.h, locals, ptr::null_mut()) })
+        }
+        pub fn destroy(self) { unsafe { ffi::ocean_propagation_destroy(self.h) } }
+    }
+
+    /// src/ocean.rs:184-328
+    pub struct Correction<'d> { h: *mut ffi::OceanCorrection, device: &'d Device }
+    impl<'d> Correction<'d> {
+        pub fn init(device: &'d Device) -> Result<Self, Box<dyn Error>> {
+            let mut h = ptr::null_mut();
+            device.check(unsafe { ffi::ocean_correction_init(device.raw(), &mut h) })?;
+            Ok(Correction { h, device })
+        }
+        /// src/render.rs:1280-1287
+        pub fn dispatch(&mut self, locals: &CorrectionLocals) -> Result<(), Box<dyn Error>> {
+            self.device.check(unsafe { ffi::ocean_correct(self.h, locals, ptr::null_mut()) })
+        }
+        pub fn destroy(self) { unsafe { ffi::ocean_correction_destroy(self.h) } }
+    }
+}
+
+pub mod fft {
+    //! src/fft.rs
+    use super::*;
+    /// desc_sets[0,1,2] -> dx_spec, dy_spec, dz_spec (src/render.rs:971-988)
+    pub const FIELD_DX: i32 = 0;
+    pub const FIELD_DY: i32 = 1;
+    pub const FIELD_DZ: i32 = 2;
+    pub const FIELD_ALL: i32 = -1;
+
+    /// src/fft.rs:7-111
+    pub struct Fft<'d> { h: *mut ffi::OceanFft, device: &'d Device }
+    impl<'d> Fft<'d> {
+        pub fn init(device: &'d Device) -> Result<Self, Box<dyn Error>> {
+            let mut h = ptr::null_mut();
+            device.check(unsafe { ffi::ocean_fft_init(device.raw(), &mut h) })?;
+            Ok(Fft { h, device })
+        }
+        /// src/render.rs:1158-1179
+        pub fn row_pass(&mut self, field: i32) -> Result<(), Box<dyn Error>> {
+            self.device.check(unsafe { ffi::ocean_fft_rows(self.h, field, ptr::null_mut()) })
+        }
+        /// src/render.rs:1210-1231
+        pub fn col_pass(&mut self, field: i32) -> Result<(), Box<dyn Error>> {
+            self.device.check(unsafe { ffi::ocean_fft_cols(self.h, field, ptr::null_mut()) })
+        }
+        pub fn destroy(self) { unsafe { ffi::ocean_fft_destroy(self.h) } }
+    }
+}

@@ -1,0 +1,13 @@
+// Compile-only check of the C++ host mirror against the C ABI (run by tests/test_abi.py).
+#include "../gfx-ocean_amd/csrc/host/ocean.hpp"
+int main(int argc, char**) {
+    if (argc > 1000) {   // never executed in the CPU tier: it only has to compile and link
+        ocean_host::Device d(512);
+        auto p = ocean_host::Propagation::init(d);
+        auto f = ocean_host::Fft::init(d);
+        auto c = ocean_host::Correction::init(d);
+        ocean_host::render(d, p, f, c, 0.0f);
+        p.destroy(); f.destroy(); c.destroy();
+    }
+    return ocean_abi_version() == OCEAN_ABI_VERSION ? 0 : 1;
+}

@@ -53,3 +53,21 @@ def test_null_handles_are_rejected_not_crashed(so_path):
     assert lib.ocean_sync(None) == -1
     lib.ocean_context_destroy(None)      # NULL-safe
     lib.ocean_fft_destroy(None)
+
+
+def test_cpp_host_mirror_compiles_and_links(so_path, tmp_path):
+    """gfx-ocean_amd/csrc/host/ocean.hpp (the C++ mirror of mod ocean / mod fft) against the C ABI."""
+    exe = str(tmp_path / "host_mirror_check")
+    libdir = os.path.dirname(so_path)
+    subprocess.check_call(["g++", "-std=c++17", os.path.join(ROOT, "tests", "host_mirror_check.cpp"), "-o", exe,
+                           "-L", libdir, "-locean_hip", "-Wl,-rpath," + libdir,
+                           "-L", "/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    assert subprocess.call([exe]) == 0
+
+
+def test_rust_shim_lists_every_symbol():
+    """The uncompiled Rust shim (no cargo in this image) must at least bind every exported symbol."""
+    with open(os.path.join(ROOT, "gfx-ocean_amd", "rust", "src", "ffi.rs")) as f:
+        src = f.read()
+    bound = sorted(set(re.findall(r"pub fn (ocean_[a-z_0-9]+)\(", src)))
+    assert bound == header_symbols()
