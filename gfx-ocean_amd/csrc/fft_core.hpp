@@ -6,7 +6,7 @@
 // E elements of a line in VGPRs, does radix-R butterflies (R <= E) entirely in registers and
 // only crosses threads through LDS between passes (2 exchanges for N = 4096 instead of the
 // reference's 12 barrier-separated LDS round trips).  Twiddles come from one fp64-computed table
-// lookup per thread per pass (w), the powers w^2..w^(R-1) by a depth<=4 product tree, instead of
+// lookup per thread per pass (w) and a two-level rotation (apply_twiddles), instead of
 // the reference's cos/sin per butterfly (fft_row.comp:32-33).
 //
 // Index algebra (verified against numpy in oracle prototype, see DESIGN.md "FFT schedule"):
@@ -126,18 +126,39 @@ template <int N, int E> struct Plan {
 __device__ __forceinline__ int lds_pad(int i) { return i + (i >> 4); }
 template <int N> struct LdsLine { static constexpr int elems = N + (N >> 4); };
 
-// w^0..w^(R-1) from w by a shallow product tree (depth <= 4 for R = 16, <= 5 for 32).
+// a[t] *= w^t, t in [0, R).  For R > 4 the rotation is split in two levels, t = 4*t1 + t2:
+// w^t = (w^4)^t1 * w^t2, so only {w, w^2, w^3, w^4, w^8, w^12} are ever live (12 VGPRs instead of
+// the 30 of a full power table) for 29 complex multiplies per radix-16 butterfly instead of 26.
+// Product depth <= 5 (w^12 * w^3), i.e. a few ulp on the twiddle.
 template <int R>
-__device__ __forceinline__ void twiddle_powers(c32 w, c32 (&p)[R]) {
-    p[0] = make_float2(1.0f, 0.0f);
-    if constexpr (R > 1) p[1] = w;
+__device__ __forceinline__ void apply_twiddles(c32 (&a)[R], c32 w) {
+    if constexpr (R == 2) {
+        a[1] = cmul(a[1], w);
+    } else if constexpr (R == 4) {
+        const c32 w2 = cmul(w, w);
+        a[1] = cmul(a[1], w);
+        a[2] = cmul(a[2], w2);
+        a[3] = cmul(a[3], cmul(w2, w));
+    } else {
+        static_assert(R % 4 == 0 && R <= 16, "two-level twiddle split supports R = 8, 16");
+        constexpr int R1 = R / 4;
+        const c32 w2 = cmul(w, w);
+        const c32 w3 = cmul(w2, w);
+        const c32 w4 = cmul(w2, w2);
+        c32 hi[R1];
+        hi[0] = make_float2(1.0f, 0.0f);
+        hi[1] = w4;
+        if constexpr (R1 > 2) { hi[2] = cmul(w4, w4); hi[3] = cmul(hi[2], w4); }
 #pragma unroll
-    for (int t = 2; t < R; ++t) {
-        // t = hi + lo with hi the largest power of two <= t (hi itself = (hi/2)+(hi/2))
-        int hi = 1;
-        while (hi * 2 <= t) hi *= 2;
-        const int lo = t - hi;
-        p[t] = (lo == 0) ? cmul(p[hi / 2], p[hi / 2]) : cmul(p[hi], p[lo]);
+        for (int t = 1; t < R; ++t) {
+            const int t1 = t / 4, t2 = t % 4;
+            c32 v = a[t];
+            if (t1 > 0) v = cmul(v, hi[t1]);
+            if (t2 == 1) v = cmul(v, w);
+            if (t2 == 2) v = cmul(v, w2);
+            if (t2 == 3) v = cmul(v, w3);
+            a[t] = v;
+        }
     }
 }
 
@@ -148,22 +169,17 @@ template <int N, int E, int R, int NS, class Emit>
 __device__ __forceinline__ void fft_pass(c32 (&reg)[E], int j, const c32* __restrict__ tw, Emit&& emit) {
     constexpr int T = N / E;
     constexpr int U = E / R;
-    c32 pw[R];
-    if constexpr (NS > 1 && U == 1) {
-        const int k = j & (NS - 1);
-        twiddle_powers<R>(tw[k * (N / (NS * R))], pw);
-    }
+    c32 w = make_float2(1.0f, 0.0f);
+    if constexpr (NS > 1 && U == 1) w = tw[(j & (NS - 1)) * (N / (NS * R))];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int jv = j + u * T;
         const int k = jv & (NS - 1);
-        if constexpr (NS > 1 && U > 1) twiddle_powers<R>(tw[k * (N / (NS * R))], pw);
+        if constexpr (NS > 1 && U > 1) w = tw[k * (N / (NS * R))];
         c32 a[R], b[R];
 #pragma unroll
-        for (int t = 0; t < R; ++t) {
-            a[t] = reg[u + t * U];
-            if constexpr (NS > 1) { if (t > 0) a[t] = cmul(a[t], pw[t]); }
-        }
+        for (int t = 0; t < R; ++t) a[t] = reg[u + t * U];
+        if constexpr (NS > 1) apply_twiddles<R>(a, w);
         Dft<R>::run(a, b);
         const int base = (jv / NS) * (NS * R) + k;
         // lds_pad(base + s*NS) == lds_pad(base) + s*NS + ((s*NS) >> 4) for power-of-two NS, R

@@ -45,7 +45,10 @@ struct OceanContext {
     c32* h0T = nullptr;
     float* omegaT = nullptr;
     c32* inter = nullptr;
-    InterLayout lay{0, 0, 0};
+    InterLayout lay{0, 0, 0};     // three complex fields, all N columns        (OCEAN_ALGO=c2c)
+    InterLayout lay_h{0, 0, 0};   // three complex fields, columns 0..N/2-1     (half-spectrum path)
+    float* nyq = nullptr;         // Nyquist column of the half-spectrum path: 3 x N real
+    bool half = true;             // OCEAN_ALGO=c2c selects the three-complex-transform frame (A/B)
     int P = 0;
     c32* tw = nullptr;          // e^{+2 pi i k/N}
     float4* out_own = nullptr;  // displacement map (src/render.rs:820-869), linear RGBA32F
@@ -102,6 +105,12 @@ template <int N> struct Launch {
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute((const void*)k_frame_pass2_thin<N, G::E, G::P, G::R2>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, G::thin_lds);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)k_half_pass1<N, G::E, G::P>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, G::frame_lds);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)k_half_pass2<N, G::E, G::P, G::R2>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, G::thin_lds);
         return e;
     }
     static void rows(OceanContext* c, c32* data, hipStream_t s) {
@@ -113,10 +122,20 @@ template <int N> struct Launch {
                            G::col_lds, s, data, c->tw);
     }
     static void pass1(OceanContext* c, float time, float domain, hipStream_t s) {
+        if (c->half) {
+            hipLaunchKernelGGL((k_half_pass1<N, G::E, G::P>), dim3(G::half_grid1), dim3(G::frame_threads),
+                               G::frame_lds, s, c->h0T, c->omegaT, c->inter, c->nyq, c->tw, c->lay_h, time, domain);
+            return;
+        }
         hipLaunchKernelGGL((k_frame_pass1<N, G::E, G::P>), dim3(G::frame_grid), dim3(G::frame_threads),
                            G::frame_lds, s, c->h0T, c->omegaT, c->inter, c->tw, c->lay, time, domain);
     }
     static void pass2(OceanContext* c, hipStream_t s) {
+        if (c->half) {
+            hipLaunchKernelGGL((k_half_pass2<N, G::E, G::P, G::R2>), dim3(G::thin_grid), dim3(G::thin_threads),
+                               G::thin_lds, s, c->inter, c->nyq, c->out, c->tw, c->lay_h);
+            return;
+        }
         if (c->pass2_thin)
             hipLaunchKernelGGL((k_frame_pass2_thin<N, G::E, G::P, G::R2>), dim3(G::thin_grid), dim3(G::thin_threads),
                                G::thin_lds, s, c->inter, c->out, c->tw, c->lay);
@@ -166,7 +185,7 @@ int32_t check_launch(OceanContext* c, const char* what) {
 void free_all(OceanContext* c) {
     auto f = [](void* p) { if (p) (void)hipFree(p); };
     f(c->h0); f(c->omega); f(c->field[0]); f(c->field[1]); f(c->field[2]);
-    f(c->h0T); f(c->omegaT); f(c->inter); f(c->tw); f(c->out_own);
+    f(c->h0T); f(c->omegaT); f(c->inter); f(c->nyq); f(c->tw); f(c->out_own);
     if (c->stream) (void)hipStreamDestroy(c->stream);
 }
 
@@ -211,6 +230,18 @@ int32_t ocean_context_create(int32_t device, int32_t resolution, OceanContext** 
             c->lay.sy = groups * chunk + 32;
             c->lay.fs = c->lay.sy * groups;
         }
+        // half-spectrum path: N/2 columns -> groups/2 chunk columns, same number of chunk rows
+        const size_t gx = groups / 2;
+        if (p1) {
+            c->lay_h.sy = chunk;
+            c->lay_h.sx = groups * chunk + 32;
+            c->lay_h.fs = c->lay_h.sx * gx;
+        } else {
+            c->lay_h.sx = chunk;
+            c->lay_h.sy = gx * chunk + 32;
+            c->lay_h.fs = c->lay_h.sy * groups;
+        }
+        if (const char* a = std::getenv("OCEAN_ALGO")) c->half = (std::strcmp(a, "c2c") != 0);
     }
     auto bail = [&](hipError_t err, const char* what) {
         const int32_t code = hip_fail(nullptr, err, what);
@@ -226,6 +257,7 @@ int32_t ocean_context_create(int32_t device, int32_t resolution, OceanContext** 
     CTX_TRY(hipMalloc((void**)&c->h0T, n2 * sizeof(c32)));
     CTX_TRY(hipMalloc((void**)&c->omegaT, n2 * sizeof(float)));
     CTX_TRY(hipMalloc((void**)&c->inter, 3 * c->lay.fs * sizeof(c32)));
+    CTX_TRY(hipMalloc((void**)&c->nyq, 3 * (size_t)resolution * sizeof(float)));
     CTX_TRY(hipMalloc((void**)&c->out_own, n2 * sizeof(float4)));
     CTX_TRY(hipMalloc((void**)&c->tw, (size_t)resolution * sizeof(c32)));
     c->out = c->out_own;
@@ -446,7 +478,7 @@ static int32_t profile_common(OceanContext* ctx, float time, int32_t cap, const 
     if (!ctx->uploaded) return fail(ctx, OCEAN_E_STATE, "ocean_upload_spectrum has not been called");
     static const char* kStaged[8] = {"k_propagate", "k_fft_lines<ROW> dx", "k_fft_lines<ROW> dy", "k_fft_lines<ROW> dz",
                                      "k_fft_lines<COL> dx", "k_fft_lines<COL> dy", "k_fft_lines<COL> dz", "k_correct"};
-    static const char* kFused[2] = {"k_frame_pass1", "k_frame_pass2"};   // pass2 = fat or thin variant
+    static const char* kFused[2] = {"k_frame_pass1", "k_frame_pass2"};   // whichever variant is selected
     const int count = staged ? 8 : 2;
     if (cap < count) return fail(ctx, OCEAN_E_INVALID_ARG, "capacity too small");
     DeviceGuard guard(ctx->device);

@@ -14,6 +14,14 @@ __device__ __forceinline__ int opaque_lane(int x) {
     return x;
 }
 
+// Returns x, but only after `dep` has been computed: orders the loads whose addresses derive from
+// the result behind the arithmetic that produced `dep` (splits a long load phase in two so that
+// the first half's input registers are free before the second half's loads are issued).
+__device__ __forceinline__ int opaque_after(int x, float dep) {
+    asm volatile("" : "+v"(x) : "v"(dep));
+    return x;
+}
+
 // x is known to be identical in every lane of the wave: move it to an SGPR so that addresses
 // derived from it become scalar bases (one VGPR offset + SGPR base instead of E 64-bit VGPR pairs).
 __device__ __forceinline__ int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }

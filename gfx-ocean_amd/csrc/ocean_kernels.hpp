@@ -338,6 +338,235 @@ k_frame_pass2_thin(const c32* __restrict__ inter, float4* __restrict__ out, cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fused frame, half-spectrum variant ("real-output" algorithm)
+// ---------------------------------------------------------------------------------------------
+// correction.comp:31 keeps only the real part of each inverse transform, and for any complex F
+//     Re(IDFT2(F)) = IDFT2(S(F)),   S(F)[ky][kx] = (F[ky][kx] + conj(F[(-ky)%N][(-kx)%N])) / 2.
+// S(F) is Hermitian, so after the transform along y the columns kx and N-kx are conjugates: pass 1
+// only has to produce columns kx = 0 .. N/2-1 (plus the self-paired Nyquist column N/2, a real
+// N-vector per field), i.e. HALF the column FFTs and 12 instead of 24 bytes/texel of intermediate.
+// Pass 2 rebuilds the full rows in LDS (C[kx] = A + iB, C[N-kx] = conj(A) + i conj(B)) and gets
+// two real channels per complex FFT: (disp_x, disp_z) from one, height from the other.
+// Same result as the three complex transforms up to fp32 rounding; the factors 1/2 are applied
+// once in the epilogue.  HBM traffic per texel: pass 1 14 R + 12 W, pass 2 12 R + 16 W.
+//
+// Per output column x < N/2 and row y the symmetrised spectrum needs the propagated height at
+// (y, x) and at ((-y)%N, (-x)%N):   H1 from h0T[x][y], h0T[N-1-x][N-1-y], omegaT[x][y];
+//                                    H2 from h0T[x2][y2], h0T[(x-1)%N][(y-1)%N], omegaT[x2][y2],
+// x2 = (N-x)%N, y2 = (N-y)%N  (the second mirror index is N-1-x2 = (x-1)%N).  With A = H1,
+// B = conj(H2) and k1 = k_norm(x, y), k2 = k_norm(x2, y2)   (all quirks Q1/Q2 kept):
+//     2 S(H)  = A + B,     2 S(Dx) = i (k2.x B - k1.x A),     2 S(Dz) = i (k2.y B - k1.y A).
+
+// One field's symmetrised column spectrum (times 2) for E positions of a thread.
+template <int N, int E>
+__device__ __forceinline__ void half_spectrum(int f, const c32 (&A)[E], const c32 (&B)[E], float kx1, float kx2,
+                                              float kscale, int j, c32 (&reg)[E]) {
+    constexpr int T = N / E;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (f == 1) {
+            reg[e] = make_float2(A[e].x + B[e].x, A[e].y + B[e].y);
+        } else {
+            const int y = j + e * T;
+            const int y2 = (N - y) & (N - 1);
+            float knx1, kny1, knx2, kny2;
+            k_normalised_fast(kx1, wave_index_q1((uint32_t)y, N) * kscale, knx1, kny1);
+            k_normalised_fast(kx2, wave_index_q1((uint32_t)y2, N) * kscale, knx2, kny2);
+            const float k1 = (f == 0) ? knx1 : kny1;
+            const float k2 = (f == 0) ? knx2 : kny2;
+            const c32 v = make_float2(k2 * B[e].x - k1 * A[e].x, k2 * B[e].y - k1 * A[e].y);
+            reg[e] = make_float2(-v.y, v.x);                       // i * v
+        }
+    }
+}
+
+// A = H(y, x), B = conj(H((-y)%N, (-x)%N)) for the E positions of a thread on column x.
+template <int N, int E>
+__device__ __forceinline__ void half_load_AB(const c32* __restrict__ h0T, const float* __restrict__ omegaT,
+                                             uint32_t x, int j, float time, c32 (&A)[E], c32 (&B)[E]) {
+    constexpr int T = N / E;
+    const uint32_t x2 = (N - x) & (N - 1);
+    const uint32_t xm = (x - 1u) & (N - 1);
+    const c32* own = h0T + (size_t)x * N;
+    const c32* mir = h0T + (size_t)(N - 1 - x) * N;
+    const c32* own2 = h0T + (size_t)x2 * N;
+    const c32* mir2 = h0T + (size_t)xm * N;
+    const float* om = omegaT + (size_t)x * N;
+    const float* om2 = omegaT + (size_t)x2 * N;
+    // LOAD_BATCHES batches: a batch's 6 loads per element are issued only after the previous batch's
+    // inputs have been consumed (otherwise 16 x 10 input VGPRs are live at once next to A and B and
+    // the kernel spills at the 128-VGPR budget of a 1024-thread workgroup; a spill reload in the
+    // load phase also drains every outstanding global load, vmcnt being in-order)
+    constexpr int LOAD_BATCHES = 4;
+    constexpr int PER = E / LOAD_BATCHES;
+    int jj = j;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (e > 0 && (e % PER) == 0) jj = opaque_after(j, A[e - 1].x + B[e - 1].y);
+        const int y = jj + e * T;
+        const int y2 = (N - y) & (N - 1);
+        const int ym = (y - 1) & (N - 1);
+        A[e] = propagate_height(own[y], mir[N - 1 - y], om[y], time);
+        const c32 h2 = propagate_height(own2[y2], mir2[ym], om2[y2], time);
+        B[e] = make_float2(h2.x, -h2.y);
+    }
+}
+
+// grid = 1 + (N/2)/P blocks: block 0 does the Nyquist column (three line FFTs, one per field, spread
+// over the P lines; a fraction of a regular block's work, dispatched first; measured cost 3 us at
+// N = 4096), blocks 1.. the column groups.
+template <int N, int E, int P>
+__global__ void __launch_bounds__((N / E) * P)
+k_half_pass1(const c32* __restrict__ h0T, const float* __restrict__ omegaT, c32* __restrict__ inter,
+             float* __restrict__ nyq, const c32* __restrict__ tw, InterLayout lay, float time, float domain_size) {
+    constexpr int T = N / E;
+    constexpr int H2 = P / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    c32* lds = reinterpret_cast<c32*>(smem);
+    const int tid = threadIdx.x;
+    const int c = (T >= 64) ? wave_uniform(tid / T) : (tid / T);
+    const int j = tid % T;
+    c32* lds_line = lds + c * LinePitch<N>::elems;
+    const float kscale = OCEAN_PI_F / domain_size;
+
+    if (blockIdx.x == 0) {                                         // uniform: the Nyquist column kx = N/2
+        // line c transforms fields c, c + P, ... (one round for P = 4, two for P = 2); every line runs
+        // the same number of rounds so that the barriers inside fft_line stay uniform
+        c32 A[E], B[E];
+        half_load_AB<N, E>(h0T, omegaT, (uint32_t)(N / 2), j, time, A, B);
+        const float kxn = wave_index_q1((uint32_t)(N / 2), N) * kscale;
+        constexpr int ROUNDS = (3 + P - 1) / P;
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int fr = c + r * P;
+            const int f = (fr < 3) ? fr : 2;
+            c32 reg[E];
+            half_spectrum<N, E>(f, A, B, kxn, kxn, kscale, opaque_lane(j), reg);
+            if (r > 0) __syncthreads();
+            fft_line<N, E>(reg, j, tw, lds_line);
+            if (fr < 3) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) nyq[(size_t)f * N + j + e * T] = reg[e].x;   // real by symmetry
+            }
+        }
+        return;
+    }
+
+    const int X = xcd_contiguous((int)blockIdx.x - 1, (int)gridDim.x - 1);
+    const uint32_t x = (uint32_t)(X * P + c);                      // kx in [0, N/2)
+    const uint32_t x2 = (N - x) & (N - 1);
+    c32 A[E], B[E];
+    half_load_AB<N, E>(h0T, omegaT, x, j, time, A, B);
+    const float kx1 = wave_index_q1(x, N) * kscale;
+    const float kx2 = wave_index_q1(x2, N) * kscale;
+
+    const int h = tid % H2;
+    const int i = tid / H2;
+    const c32* l0 = lds + (2 * h) * LinePitch<N>::elems;
+    const c32* l1 = lds + (2 * h + 1) * LinePitch<N>::elems;
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+        c32 reg[E];
+        const int jf = opaque_lane(j);
+        half_spectrum<N, E>(f, A, B, kx1, kx2, kscale, jf, reg);
+        if (f > 0) __syncthreads();
+        fft_line_to_lds<N, E>(reg, jf, tw, lds_line);
+        c32* dst = inter + (size_t)f * lay.fs + (size_t)X * lay.sx + (size_t)(i / P) * lay.sy + (i % P) * P + 2 * h;
+#pragma unroll
+        for (int q = 0; q < E / 2; ++q) {
+            const int y = i + q * (2 * T);
+            const c32 v0 = l0[lds_pad(y)];
+            const c32 v1 = l1[lds_pad(y)];
+            *reinterpret_cast<float4*>(dst + (size_t)q * ((2 * T) / P) * lay.sy) = make_float4(v0.x, v0.y, v1.x, v1.y);
+        }
+    }
+}
+
+// Pass 2 of the half-spectrum path: one row per R2-slot; two complex FFTs per row.
+template <int N, int E, int P1, int R2>
+__global__ void __launch_bounds__((N / E) * R2)
+k_half_pass2(const c32* __restrict__ inter, const float* __restrict__ nyq, float4* __restrict__ out,
+             const c32* __restrict__ tw, InterLayout lay) {
+    constexpr int T = N / E;
+    constexpr int EH = E / 2;                                      // elements of the half spectrum per thread
+    static_assert(T % P1 == 0 && (E % 2) == 0, "geometry");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    c32* lds = reinterpret_cast<c32*>(smem);
+    const int tid = threadIdx.x;
+    const int ll = (T >= 64) ? wave_uniform(tid / T) : (tid / T);
+    const int j = tid % T;
+    constexpr int S = (P1 > R2) ? (P1 / R2) : 1;
+    int rb = blockIdx.x;
+    if (S > 1 && (gridDim.x % (8 * S)) == 0) {
+        const int xcd = rb & 7, slot = rb >> 3;
+        rb = ((slot / S) * 8 + xcd) * S + (slot % S);
+    }
+    const int y = rb * R2 + ll;
+    c32* lds_line = lds + ll * LinePitch<N>::elems;
+    const float ny_x = nyq[y], ny_h = nyq[(size_t)N + y], ny_z = nyq[(size_t)2 * N + y];
+
+    float keep_h[E];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {                         // 0: height, 1: (disp_x, disp_z)
+        const int jf = opaque_lane(j);
+        const size_t off = (size_t)(y / P1) * lay.sy + (size_t)(jf / P1) * lay.sx + (y % P1) * P1 + (jf % P1);
+        c32 a[EH], b[EH];
+        if (pass == 0) {
+            const c32* src = inter + (size_t)1 * lay.fs + off;
+#pragma unroll
+            for (int e = 0; e < EH; ++e) a[e] = src[(size_t)e * (T / P1) * lay.sx];
+        } else {
+            const c32* sx_ = inter + off;
+            const c32* sz_ = inter + (size_t)2 * lay.fs + off;
+#pragma unroll
+            for (int e = 0; e < EH; ++e) { a[e] = sx_[(size_t)e * (T / P1) * lay.sx]; b[e] = sz_[(size_t)e * (T / P1) * lay.sx]; }
+        }
+        if (pass > 0) __syncthreads();                             // previous FFT's LDS reads done
+        // rebuild the full row: C[k] = A + iB, C[N-k] = conj(A) + i conj(B); C[0], C[N/2] real pairs
+        c32* lo = lds_line + lds_pad(jf);                          // lds_pad(jf + e*T) = lds_pad(jf) + e*(T + T/16)
+        c32* hi = lds_line + lds_pad(N - jf);                      // lds_pad(N - jf - e*T) = lds_pad(N - jf) - e*(T + T/16)
+#pragma unroll
+        for (int e = 0; e < EH; ++e) {
+            const float ar = a[e].x, ai = a[e].y;
+            const float br = (pass == 0) ? 0.0f : b[e].x, bi = (pass == 0) ? 0.0f : b[e].y;
+            c32 ck = make_float2(ar - bi, ai + br);
+            c32 cm = make_float2(ar + bi, br - ai);
+            if (e == 0) {
+                const bool dc = (jf == 0);                         // kx = 0: real pair; its mirror slot is the Nyquist bin
+                if (dc) {
+                    ck = make_float2(ar, br);
+                    cm = (pass == 0) ? make_float2(ny_h, 0.0f) : make_float2(ny_x, ny_z);
+                }
+                lo[0] = ck;
+                (dc ? (lds_line + lds_pad(N / 2)) : hi)[0] = cm;
+            } else {
+                lo[e * (T + T / 16)] = ck;
+                hi[-e * (T + T / 16)] = cm;
+            }
+        }
+        __syncthreads();
+        c32 reg[E];
+        const c32* g = lds_line + lds_pad(jf);
+#pragma unroll
+        for (int e = 0; e < E; ++e) reg[e] = g[e * (T + T / 16)];
+        __syncthreads();
+        fft_line<N, E>(reg, jf, tw, lds_line);
+        if (pass == 0) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) keep_h[e] = reg[e].x;
+        } else {
+            float4* orow = out + (size_t)y * N;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int xo = j + e * T;
+                const float s = (((xo + y) & 1) == 0) ? -0.5f : 0.5f;   // correction.comp:29 and the 1/2 of S(F)
+                orow[xo] = make_float4(reg[e].x * s, keep_h[e] * s, reg[e].y * s, 0.0f);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Launch geometry per resolution -- the single source for the API (ocean_api.hip) and for the
 // host emulation harness (tests/hipemu).
 // ---------------------------------------------------------------------------------------------
@@ -361,6 +590,7 @@ template <int N> struct Geo {
     static constexpr int thin_threads = T * R2;
     static constexpr int thin_lds = R2 * line_bytes;
     static constexpr int thin_grid = N / R2;
+    static constexpr int half_grid1 = 1 + (N / 2) / P;             // Nyquist block + column groups
     static_assert(row_threads <= 1024 && col_threads <= 1024 && frame_threads <= 1024, "workgroup too large");
     static_assert(col_lds <= 160 * 1024 && frame_lds <= 160 * 1024, "LDS budget (gfx950: 160 KiB)");
 };

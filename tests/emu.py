@@ -32,6 +32,7 @@ def lib():
         _LIB.emu_frame_pass1.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_size_t] * 3 + [ctypes.c_float] * 2
         _LIB.emu_frame_pass2.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_size_t] * 3
         _LIB.emu_frame_pass2_thin.argtypes = _LIB.emu_frame_pass2.argtypes
+        _LIB.emu_frame_half.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 6 + [ctypes.c_size_t] * 3 + [ctypes.c_float] * 2
         _LIB.emu_fft_lines.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         _LIB.emu_propagate.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_float] * 2
         _LIB.emu_correct.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4
@@ -106,4 +107,30 @@ def frame(h0, omega, time, L=1000.0, return_inter=False, thin=True, layout="p2")
     assert p2(n, _p(inter), _p(out), _p(tw), sx, sy, fs) == 0
     if return_inter:
         return out, inter, (P, (sx, sy, fs))
+    return out
+
+
+def half_layout(n, P, layout="p2", pad=32):
+    """(sx, sy, fs) of the half-spectrum intermediate (N/2 columns) -- mirrors ocean_context_create."""
+    groups, gx, chunk = n // P, n // P // 2, P * P
+    if layout == "p1":
+        sy, sx = chunk, groups * chunk + pad
+        return sx, sy, sx * gx
+    sx, sy = chunk, gx * chunk + pad
+    return sx, sy, sy * groups
+
+
+def frame_half(h0, omega, time, L=1000.0, layout="p2", return_inter=False):
+    n = h0.shape[0]
+    P = lib().emu_frame_p(n)
+    h0T = np.ascontiguousarray(h0.T, np.complex64)
+    omT = np.ascontiguousarray(omega.T, np.float32)
+    sx, sy, fs = half_layout(n, P, layout)
+    inter = np.full(3 * fs, np.nan + 1j * np.nan, np.complex64)
+    nyq = np.full(3 * n, np.nan, np.float32)
+    out = np.full((n, n, 4), np.nan, np.float32)
+    tw = twiddles(n)
+    assert lib().emu_frame_half(n, _p(h0T), _p(omT), _p(inter), _p(nyq), _p(out), _p(tw), sx, sy, fs, time, L) == 0
+    if return_inter:
+        return out, inter, nyq, (P, (sx, sy, fs))
     return out

@@ -70,6 +70,16 @@ template <int N> static int run_pass2_thin(const c32* inter, float4* out, const 
     return 0;
 }
 
+template <int N> static int run_half(const c32* h0T, const float* omT, c32* inter, float* nyq, float4* out, const c32* tw,
+                                     InterLayout lay, float time, float L) {
+    using G = Geo<N>;
+    emu_launch(G::half_grid1, G::frame_threads,
+               [&] { k_half_pass1<N, G::E, G::P>(h0T, omT, inter, nyq, tw, lay, time, L); });
+    emu_launch(G::thin_grid, G::thin_threads,
+               [&] { k_half_pass2<N, G::E, G::P, G::R2>(inter, nyq, out, tw, lay); });
+    return 0;
+}
+
 #define DISPATCH(n, CALL)                 \
     switch (n) {                          \
         case 256: return CALL(256);       \
@@ -104,6 +114,12 @@ int emu_frame_pass2(int n, const float* inter, float* out, const float* tw, size
 }
 int emu_frame_pass2_thin(int n, const float* inter, float* out, const float* tw, size_t sx, size_t sy, size_t fs) {
 #define C_(N) run_pass2_thin<N>((const c32*)inter, (float4*)out, (const c32*)tw, InterLayout{sx, sy, fs})
+    DISPATCH(n, C_)
+#undef C_
+}
+int emu_frame_half(int n, const float* h0T, const float* omT, float* inter, float* nyq, float* out, const float* tw,
+                   size_t sx, size_t sy, size_t fs, float time, float L) {
+#define C_(N) run_half<N>((const c32*)h0T, omT, (c32*)inter, nyq, (float4*)out, (const c32*)tw, InterLayout{sx, sy, fs}, time, L)
     DISPATCH(n, C_)
 #undef C_
 }

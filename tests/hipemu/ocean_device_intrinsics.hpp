@@ -3,4 +3,5 @@
 namespace ocean {
 static inline int opaque_lane(int x) { return x; }
 static inline int wave_uniform(int x) { return x; }
+static inline int opaque_after(int x, float) { return x; }
 }  // namespace ocean

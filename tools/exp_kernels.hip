@@ -189,6 +189,90 @@ x_pass2_fat(const c32* __restrict__ inter, float4* __restrict__ out, const c32* 
     }
 }
 
+// half-spectrum pass 1 ablations: MODE bit0: no Nyquist block (grid = groups); bit1: no FFT; bit2: B = conj(A) (no second propagate/loads)
+template <int N, int E, int P, int MODE>
+__global__ void __launch_bounds__((N / E) * P)
+x_half_pass1(const c32* __restrict__ h0T, const float* __restrict__ omegaT, c32* __restrict__ inter,
+             float* __restrict__ nyq, const c32* __restrict__ tw, InterLayout lay, float time, float domain_size,
+             unsigned long long* __restrict__ stamps = nullptr) {
+#define STAMP(k) do { if ((MODE & 256) && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+    STAMP(0);
+    constexpr int T = N / E;
+    constexpr int H2 = P / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    c32* lds = reinterpret_cast<c32*>(smem);
+    const int tid = threadIdx.x;
+    const int c = (T >= 64) ? wave_uniform(tid / T) : (tid / T);
+    const int j = tid % T;
+    c32* lds_line = lds + c * LinePitch<N>::elems;
+    const float kscale = OCEAN_PI_F / domain_size;
+    int bid = blockIdx.x, nb = gridDim.x;
+    if (!(MODE & 1)) {
+        if (blockIdx.x == 0) {
+            const int f = (c < 3) ? c : 2;
+            c32 A[E], B[E], reg[E];
+            half_load_AB<N, E>(h0T, omegaT, (uint32_t)(N / 2), j, time, A, B);
+            const float kxn = wave_index_q1((uint32_t)(N / 2), N) * kscale;
+            half_spectrum<N, E>(f, A, B, kxn, kxn, kscale, j, reg);
+            fft_line<N, E>(reg, j, tw, lds_line);
+            if (c < 3) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) nyq[(size_t)f * N + j + e * T] = reg[e].x;
+            }
+            return;
+        }
+        bid -= 1; nb -= 1;
+    }
+    if (MODE & 8) {   // phase staggering: every other first-round workgroup starts ~SLEEPS*3.9 us late
+        if (bid < 256 && (bid & 8)) { for (int s = 0; s < (MODE >> 4); ++s) __builtin_amdgcn_s_sleep(127); }
+    }
+    const int X = xcd_contiguous(bid, nb);
+    const uint32_t x = (uint32_t)(X * P + c);
+    const uint32_t x2 = (N - x) & (N - 1);
+    c32 A[E], B[E];
+    if (MODE & 4) {
+        const c32* own = h0T + (size_t)x * N; const c32* mir = h0T + (size_t)(N - 1 - x) * N; const float* om = omegaT + (size_t)x * N;
+#pragma unroll
+        for (int e = 0; e < E; ++e) { const int y = j + e * T; A[e] = propagate_height(own[y], mir[N - 1 - y], om[y], time); B[e] = make_float2(A[e].x, -A[e].y); }
+    } else {
+        half_load_AB<N, E>(h0T, omegaT, x, j, time, A, B);
+    }
+    const float kx1 = wave_index_q1(x, N) * kscale;
+    const float kx2 = wave_index_q1(x2, N) * kscale;
+    const int h = tid % H2;
+    const int i = tid / H2;
+    const c32* l0 = lds + (2 * h) * LinePitch<N>::elems;
+    const c32* l1 = lds + (2 * h + 1) * LinePitch<N>::elems;
+    if (MODE & 256) { asm volatile("" :: "v"(A[E - 1].x), "v"(B[E - 1].y)); __syncthreads(); STAMP(1); }
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+        c32 reg[E];
+        const int jf = opaque_lane(j);
+        half_spectrum<N, E>(f, A, B, kx1, kx2, kscale, jf, reg);
+        if (MODE & 256) { asm volatile("" :: "v"(reg[E - 1].x)); STAMP(2 + 3 * f); }
+        if (f > 0) __syncthreads();
+        if (MODE & 2) {
+            c32* g = lds_line + lds_pad(jf);
+#pragma unroll
+            for (int e = 0; e < E; ++e) g[e * (T + T / 16)] = reg[e];
+            __syncthreads();
+        } else {
+            fft_line_to_lds<N, E>(reg, jf, tw, lds_line);
+        }
+        STAMP(3 + 3 * f);
+        c32* dst = inter + (size_t)f * lay.fs + (size_t)X * lay.sx + (size_t)(i / P) * lay.sy + (i % P) * P + 2 * h;
+#pragma unroll
+        for (int q = 0; q < E / 2; ++q) {
+            const int y = i + q * (2 * T);
+            const c32 v0 = l0[lds_pad(y)];
+            const c32 v1 = l1[lds_pad(y)];
+            *reinterpret_cast<float4*>(dst + (size_t)q * ((2 * T) / P) * lay.sy) = make_float4(v0.x, v0.y, v1.x, v1.y);
+        }
+        STAMP(4 + 3 * f);
+    }
+    STAMP(11);
+}
+
 template <class F> float time_ms(F&& f, int iters = 20) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     for (int i = 0; i < 3; ++i) f();
@@ -233,6 +317,44 @@ int main() {
         float ms = time_ms([&] { hipLaunchKernelGGL(k, dim3(G::frame_grid), dim3(G::frame_threads), G::frame_lds, 0, h0T, omT, inter, tw, sx, sy, fs, 1.5f, 1000.0f); }); \
         printf("{\"kernel\":\"pass1\",\"layout\":%d,\"mode\":%d,\"ms\":%.4f,\"GBps_alg\":%.0f}\n", layout, MODE, ms, 36.0 * n2 / ms / 1e6); }
         P1(0) P1(1)
+    }
+    {
+        float* nyq; CK(hipMalloc(&nyq, 3 * N * 4));
+        const size_t gx = (N / G::P) / 2;
+        InterLayout lh{16, gx * 16 + 32, (gx * 16 + 32) * (size_t)(N / G::P)};
+#define PH(MODE) { auto k = x_half_pass1<N, G::E, G::P, MODE>; \
+        CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G::frame_lds)); \
+        const int grid = ((MODE) & 1) ? (N / 2) / G::P : 1 + (N / 2) / G::P; \
+        float ms = time_ms([&] { hipLaunchKernelGGL(k, dim3(grid), dim3(G::frame_threads), G::frame_lds, 0, h0T, omT, inter, nyq, tw, lh, 1.5f, 1000.0f, (unsigned long long*)nullptr); }); \
+        printf("{\"kernel\":\"half_pass1\",\"mode\":%d,\"ms\":%.4f}\n", MODE, ms); }
+        PH(0) PH(1)
+        {   // timeline of one launch
+            unsigned long long* st; const int grid = (N / 2) / G::P;
+            CK(hipMalloc(&st, (size_t)grid * 16 * 8)); CK(hipMemset(st, 0, (size_t)grid * 16 * 8));
+            auto k = x_half_pass1<N, G::E, G::P, 257>;
+            CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G::frame_lds));
+            float msi = time_ms([&] { hipLaunchKernelGGL(k, dim3(grid), dim3(G::frame_threads), G::frame_lds, 0, h0T, omT, inter, nyq, tw, lh, 1.5f, 1000.0f, st); });
+            printf("{\"kernel\":\"half_pass1 instrumented\",\"ms\":%.4f}\n", msi);
+            CK(hipDeviceSynchronize());
+            std::vector<unsigned long long> hs((size_t)grid * 16);
+            CK(hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost));
+            unsigned long long t0 = ~0ull; for (int b = 0; b < grid; ++b) if (hs[(size_t)b * 16] < t0) t0 = hs[(size_t)b * 16];
+            const char* names[12] = {"start", "AB_ready", "spec0", "fft0", "store0", "spec1", "fft1", "store1", "spec2", "fft2", "store2", "end"};
+            for (int b : {0, 1, 7, 100, 255, 256, 257, 300, 511}) {
+                printf("{\"wg\":%d", b);
+                for (int k2 = 0; k2 < 12; ++k2) printf(",\"%s\":%.1f", names[k2], (double)(hs[(size_t)b * 16 + k2] - t0) / 100.0);
+                printf("}\n");
+            }
+            double acc[12] = {0};
+            for (int b = 0; b < grid; ++b) for (int k2 = 1; k2 < 12; ++k2) acc[k2] += (double)(hs[(size_t)b * 16 + k2] - hs[(size_t)b * 16 + k2 - 1]) / 100.0;
+            printf("{\"avg_phase_us\":{");
+            for (int k2 = 1; k2 < 12; ++k2) printf("\"%s\":%.2f%s", names[k2], acc[k2] / grid, k2 < 11 ? "," : "");
+            printf("}}\n");
+        }
+        auto k2 = k_half_pass2<N, G::E, G::P, G::R2>;
+        CK(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, G::thin_lds));
+        float ms = time_ms([&] { hipLaunchKernelGGL(k2, dim3(G::thin_grid), dim3(G::thin_threads), G::thin_lds, 0, inter, nyq, out, tw, lh); });
+        printf("{\"kernel\":\"half_pass2\",\"ms\":%.4f}\n", ms);
     }
     return 0;
 }
