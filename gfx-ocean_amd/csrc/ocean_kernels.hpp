@@ -40,13 +40,15 @@ __device__ __forceinline__ float wave_index_q1(uint32_t g, uint32_t n) {
 // h = h0 * e^{+i w t} + h0[index_neg] * e^{-i w t}   (:55-62; no conjugate, quirk Q2)
 __device__ __forceinline__ c32 propagate_height(c32 h0, c32 h0_neg, float omega, float time) {
     const float disp = omega * time;                               // :55 (one fp32 multiply, as the shader)
-    // cos/sin of the fp32 phase, full range (phases reach 1e4..1e5 rad): reduce disp/(2 pi) to
-    // [-0.5, 0.5] in fp64 (exact to ~1e-12), then a pi-scaled sincos that needs no further
-    // reduction.  Abs error <= 2e-7; no Payne-Hanek slow path, a third of sincosf's registers.
-    const double rev = (double)disp * 0.15915494309189535;         // 1 / (2 pi)
-    const float half_turns = (float)(2.0 * (rev - rint(rev)));     // in [-1, 1]
-    float s, c;
-    sincospif(half_turns, &s, &c);
+    // cos/sin of the fp32 phase, full range (phases reach 1e4..1e5 rad): reduce to revolutions in
+    // [-0.5, 0.5] with a two-constant fp32 product (1/(2 pi) = HI + LO, both FMAs exact in the
+    // product: fraction error < 6e-8 revolutions for |disp| < 1e5), then the hardware sin/cos.
+    // Total abs error <= 4e-7 against the correctly rounded value the oracle uses.
+    constexpr float INV_2PI_HI = 0.15915494f;                      // fl32(1 / (2 pi)) = 0x3E22F983
+    constexpr float INV_2PI_LO = 6.4206382e-09f;                   // 1 / (2 pi) - INV_2PI_HI
+    const float turns = rintf(disp * INV_2PI_HI);
+    const float frac = fmaf(disp, INV_2PI_LO, fmaf(disp, INV_2PI_HI, -turns));
+    const float s = sin_rev(frac), c = cos_rev(frac);
     const c32 a = make_float2(h0.x * c - h0.y * s, h0.y * c + h0.x * s);                  // * (c, s)
     const c32 b = make_float2(h0_neg.x * c + h0_neg.y * s, h0_neg.y * c - h0_neg.x * s);  // * (c,-s)
     return make_float2(a.x + b.x, a.y + b.y);
@@ -237,7 +239,7 @@ k_frame_pass1(const c32* __restrict__ h0T, const float* __restrict__ omegaT, c32
             const int y = i + q * (2 * T);
             const c32 v0 = l0[lds_pad(y)];
             const c32 v1 = l1[lds_pad(y)];
-            *reinterpret_cast<float4*>(dst + (size_t)q * ((2 * T) / P) * lay.sy) = make_float4(v0.x, v0.y, v1.x, v1.y);
+            store_float4_nt(reinterpret_cast<float4*>(dst + (size_t)q * ((2 * T) / P) * lay.sy), make_float4(v0.x, v0.y, v1.x, v1.y));
         }
     }
 }
@@ -277,7 +279,7 @@ k_frame_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32
             for (int e = 0; e < E; ++e) {
                 const int xo = j + e * T;
                 const float s = (((xo + y) & 1) == 0) ? -1.0f : 1.0f;   // correction.comp:29
-                orow[xo] = make_float4(keep[0][e] * s, keep[1][e] * s, reg[e].x * s, 0.0f);
+                store_float4_nt(orow + xo, make_float4(keep[0][e] * s, keep[1][e] * s, reg[e].x * s, 0.0f));
             }
         }
     }
@@ -331,7 +333,7 @@ k_frame_pass2_thin(const c32* __restrict__ inter, float4* __restrict__ out, cons
             for (int e = 0; e < E; ++e) {
                 const int xo = j + e * T;
                 const float s = (((xo + y) & 1) == 0) ? -1.0f : 1.0f;   // correction.comp:29
-                orow[xo] = make_float4(keep[0][e] * s, keep[1][e] * s, reg[e].x * s, 0.0f);
+                store_float4_nt(orow + xo, make_float4(keep[0][e] * s, keep[1][e] * s, reg[e].x * s, 0.0f));
             }
         }
     }
@@ -477,7 +479,7 @@ k_half_pass1(const c32* __restrict__ h0T, const float* __restrict__ omegaT, c32*
             const int y = i + q * (2 * T);
             const c32 v0 = l0[lds_pad(y)];
             const c32 v1 = l1[lds_pad(y)];
-            *reinterpret_cast<float4*>(dst + (size_t)q * ((2 * T) / P) * lay.sy) = make_float4(v0.x, v0.y, v1.x, v1.y);
+            store_float4_nt(reinterpret_cast<float4*>(dst + (size_t)q * ((2 * T) / P) * lay.sy), make_float4(v0.x, v0.y, v1.x, v1.y));
         }
     }
 }
@@ -560,7 +562,7 @@ k_half_pass2(const c32* __restrict__ inter, const float* __restrict__ nyq, float
             for (int e = 0; e < E; ++e) {
                 const int xo = j + e * T;
                 const float s = (((xo + y) & 1) == 0) ? -0.5f : 0.5f;   // correction.comp:29 and the 1/2 of S(F)
-                orow[xo] = make_float4(reg[e].x * s, keep_h[e] * s, reg[e].y * s, 0.0f);
+                store_float4_nt(orow + xo, make_float4(reg[e].x * s, keep_h[e] * s, reg[e].y * s, 0.0f));
             }
         }
     }

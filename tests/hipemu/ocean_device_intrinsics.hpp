@@ -1,7 +1,11 @@
 // Host stand-in for gfx-ocean_amd/csrc/ocean_device_intrinsics.hpp (CPU emulation build only).
 #pragma once
+#include <cmath>
 namespace ocean {
 static inline int opaque_lane(int x) { return x; }
 static inline int wave_uniform(int x) { return x; }
+static inline float sin_rev(float x) { return (float)std::sin(6.283185307179586 * (double)x); }
+static inline float cos_rev(float x) { return (float)std::cos(6.283185307179586 * (double)x); }
+static inline void store_float4_nt(float4* p, float4 v) { *p = v; }
 static inline int opaque_after(int x, float) { return x; }
 }  // namespace ocean

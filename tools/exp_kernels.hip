@@ -6,6 +6,11 @@
 #include <vector>
 #include "ocean_kernels.hpp"
 using namespace ocean;
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st4(c32* p, float4 v, bool nt) { if (nt) { v4f t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(p)); } else *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ c32 ld2(const c32* p, bool nt) { if (nt) { v2f t = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(p)); return make_float2(t.x, t.y); } return *p; }
+__device__ __forceinline__ float ld1(const float* p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
 // MODE: 0 full, 1 no FFT (memory pattern only), 2 prefetch next field's loads before the FFT
@@ -91,8 +96,8 @@ x_pass1(const c32* __restrict__ h0T, const float* __restrict__ omegaT, c32* __re
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int y = j + e * T;
-        if (MODE & 2) { const c32 a = own[y], m = mir[N - 1 - y]; const float w = om[y]; hs[e] = make_float2(a.x + m.x * w, a.y + m.y); }
-        else hs[e] = propagate_height(own[y], mir[N - 1 - y], om[y], time);
+        if (MODE & 2) { const c32 a = ld2(own + y, MODE & 32), m = ld2(mir + (N - 1 - y), MODE & 32); const float w = ld1(om + y, MODE & 32); hs[e] = make_float2(a.x + m.x * w, a.y + m.y); }
+        else hs[e] = propagate_height(ld2(own + y, MODE & 32), ld2(mir + (N - 1 - y), MODE & 32), ld1(om + y, MODE & 32), time);
     }
     c32* out_group = inter + (size_t)X * sx;
 #pragma unroll
@@ -129,7 +134,7 @@ x_pass1(const c32* __restrict__ h0T, const float* __restrict__ omegaT, c32* __re
             const int y = i + q * (2 * T);
             const c32 v0 = l0[lds_pad(y)];
             const c32 v1 = l1[lds_pad(y)];
-            *reinterpret_cast<float4*>(dst + (size_t)(y / P) * sy + (size_t)(y % P) * P + 2 * h) = make_float4(v0.x, v0.y, v1.x, v1.y);
+            st4(dst + (size_t)(y / P) * sy + (size_t)(y % P) * P + 2 * h, make_float4(v0.x, v0.y, v1.x, v1.y), MODE & 16);
         }
     }
 }
@@ -327,8 +332,16 @@ int main() {
         const int grid = ((MODE) & 1) ? (N / 2) / G::P : 1 + (N / 2) / G::P; \
         float ms = time_ms([&] { hipLaunchKernelGGL(k, dim3(grid), dim3(G::frame_threads), G::frame_lds, 0, h0T, omT, inter, nyq, tw, lh, 1.5f, 1000.0f, (unsigned long long*)nullptr); }); \
         printf("{\"kernel\":\"half_pass1\",\"mode\":%d,\"ms\":%.4f}\n", MODE, ms); }
-        PH(0) PH(1)
-        {   // timeline of one launch
+        PH(0) PH(1) PH(3) PH(5) PH(7)
+        {
+            const size_t sx = 16, sy = (size_t)(N / G::P) * 16 + 32;
+#define P1H(MODE, GRID) { auto k = x_pass1<N, G::E, G::P, MODE>; \
+            CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G::frame_lds)); \
+            float ms = time_ms([&] { hipLaunchKernelGGL(k, dim3(GRID), dim3(G::frame_threads), G::frame_lds, 0, h0T, omT, inter, tw, sx, sy, fs, 1.5f, 1000.0f); }); \
+            printf("{\"kernel\":\"c2c_pass1\",\"grid\":%d,\"mode\":%d,\"ms\":%.4f}\n", GRID, MODE, ms); }
+            P1H(0, 1024) P1H(16, 1024) P1H(32, 1024) P1H(48, 1024) P1H(3, 1024) P1H(19, 1024) P1H(35, 1024) P1H(51, 1024) P1H(51, 512) P1H(51, 256)
+        }
+        if (0) {   // timeline of one launch
             unsigned long long* st; const int grid = (N / 2) / G::P;
             CK(hipMalloc(&st, (size_t)grid * 16 * 8)); CK(hipMemset(st, 0, (size_t)grid * 16 * 8));
             auto k = x_half_pass1<N, G::E, G::P, 257>;
