@@ -25,12 +25,16 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s me
 # Algorithmic bytes per texel of each fused kernel (DESIGN.md "Kernels"):
 #   pass1: read h0 8 + omega 4, write 3 complex fields 24            = 36
 #   pass2: read 3 complex fields 24, write RGBA32F 16                = 40   (frame total 76)
-KERNEL_BYTES_PER_TEXEL = {"k_frame_pass1": 36.0, "k_frame_pass2": 40.0}
+KERNEL_BYTES_PER_TEXEL = {"pass1": 36.0, "pass2": 40.0}
 # Bytes the shipped half-spectrum algorithm itself has to move: only columns
 # kx < N/2 of the three fields cross between the passes (12 B/texel instead of 24).
 #   pass1: read h0 10 + omega 4 (lines x, x-1, N-x, N-1-x), write 12     = 26
 #   pass2: read 12, write RGBA32F 16                                      = 28   (frame total 54)
-HALF_BYTES_PER_TEXEL = {"k_frame_pass1": 26.0, "k_frame_pass2": 28.0}
+HALF_BYTES_PER_TEXEL = {"pass1": 26.0, "pass2": 28.0}
+
+
+def pass_of(kernel_name):
+    return "pass1" if "pass1" in kernel_name else "pass2"
 
 
 def aggregate(values_ms, n_gpus, steps):
@@ -50,10 +54,8 @@ def measured_traffic(n, kernel_name):
             rec = json.load(f)["kernels"]
     except (OSError, ValueError, KeyError):
         return None
-    for k, v in rec.items():
-        if kernel_name.startswith(k) or k.startswith(kernel_name):
-            return v["hbm_bytes"]
-    return None
+    v = rec.get(kernel_name)
+    return v["hbm_bytes"] if v else None
 
 
 def tile_seed(n, rank):
@@ -141,10 +143,12 @@ def main():
     kernels = []
     for name, total in acc.items():
         avg_ms = total / args.profile_frames
-        b = KERNEL_BYTES_PER_TEXEL[name] * n * n
-        hb = HALF_BYTES_PER_TEXEL[name] * n * n
-        kernels.append({"name": name, "avg_ms": avg_ms, "algorithmic_bytes": b, "GBps": b / avg_ms / 1e6,
-                        "half_spectrum_bytes": hb, "half_spectrum_GBps": hb / avg_ms / 1e6})
+        b = KERNEL_BYTES_PER_TEXEL[pass_of(name)] * n * n
+        rec = {"name": name, "avg_ms": avg_ms, "algorithmic_bytes": b, "GBps": b / avg_ms / 1e6}
+        if "half" in name:
+            hb = HALF_BYTES_PER_TEXEL[pass_of(name)] * n * n
+            rec.update({"half_spectrum_bytes": hb, "half_spectrum_GBps": hb / avg_ms / 1e6})
+        kernels.append(rec)
     dom = max(kernels, key=lambda k: k["avg_ms"])
     roofline = {"bound": "hbm", "kernel": dom["name"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": measured_traffic(n, dom["name"]),

@@ -478,7 +478,8 @@ static int32_t profile_common(OceanContext* ctx, float time, int32_t cap, const 
     if (!ctx->uploaded) return fail(ctx, OCEAN_E_STATE, "ocean_upload_spectrum has not been called");
     static const char* kStaged[8] = {"k_propagate", "k_fft_lines<ROW> dx", "k_fft_lines<ROW> dy", "k_fft_lines<ROW> dz",
                                      "k_fft_lines<COL> dx", "k_fft_lines<COL> dy", "k_fft_lines<COL> dz", "k_correct"};
-    static const char* kFused[2] = {"k_frame_pass1", "k_frame_pass2"};   // whichever variant is selected
+    const char* kFused[2] = {ctx->half ? "k_half_pass1" : "k_frame_pass1",
+                             ctx->half ? "k_half_pass2" : (ctx->pass2_thin ? "k_frame_pass2_thin" : "k_frame_pass2")};
     const int count = staged ? 8 : 2;
     if (cap < count) return fail(ctx, OCEAN_E_INVALID_ARG, "capacity too small");
     DeviceGuard guard(ctx->device);

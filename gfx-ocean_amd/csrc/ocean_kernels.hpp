@@ -405,11 +405,27 @@ __device__ __forceinline__ void half_load_AB(const c32* __restrict__ h0T, const 
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         if (e > 0 && (e % PER) == 0) jj = opaque_after(j, A[e - 1].x + B[e - 1].y);
-        const int y = jj + e * T;
-        const int y2 = (N - y) & (N - 1);
-        const int ym = (y - 1) & (N - 1);
-        A[e] = propagate_height(own[y], mir[N - 1 - y], om[y], time);
-        const c32 h2 = propagate_height(own2[y2], mir2[ym], om2[y2], time);
+        // y = jj + e*T.  Every address is written as (uniform base + e-dependent constant)[small lane index]
+        // so that the six streams share three lane offsets and the bases stay in SGPRs; only e == 0 can
+        // hit the wrap of y2 = (N - y) % N and ym = (y - 1) % N (at jj == 0).
+        const c32 a = (own + e * T)[jj];
+        const c32 m = (mir + (N - (e + 1) * T))[T - 1 - jj];       // mir[N - 1 - y]
+        const float w = (om + e * T)[jj];
+        c32 a2, m2;
+        float w2;
+        if (e == 0) {
+            const int y2 = (N - jj) & (N - 1);
+            const int ym = (jj - 1) & (N - 1);
+            a2 = own2[y2];
+            m2 = mir2[ym];
+            w2 = om2[y2];
+        } else {
+            a2 = (own2 + (N - (e + 1) * T))[T - jj];               // own2[N - y]
+            m2 = (mir2 + (e * T - 1))[jj];                         // mir2[y - 1]
+            w2 = (om2 + (N - (e + 1) * T))[T - jj];
+        }
+        A[e] = propagate_height(a, m, w, time);
+        const c32 h2 = propagate_height(a2, m2, w2, time);
         B[e] = make_float2(h2.x, -h2.y);
     }
 }

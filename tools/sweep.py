@@ -29,8 +29,7 @@ def main():
                 for name, t in fn(i / 60.0):
                     acc[name] = acc.get(name, 0.0) + t / reps
             rec[kind] = acc
-        b = {"k_frame_pass1": 36.0, "k_frame_pass2": 40.0}
-        rec["fused_GBps"] = {k: b[k] * n * n / v / 1e6 for k, v in rec["fused"].items()}
+        rec["fused_GBps"] = {k: (36.0 if "pass1" in k else 40.0) * n * n / v / 1e6 for k, v in rec["fused"].items()}
         st = rec["staged"]
         rec["staged_GBps"] = {k: (16.0 if "fft" in k else (36.0 if "prop" in k else 40.0)) * n * n / v / 1e6
                               for k, v in st.items()}
