@@ -18,9 +18,11 @@ STATUS_NAMES = {0: "OCEAN_OK", -1: "OCEAN_E_INVALID_ARG", -2: "OCEAN_E_UNSUPPORT
 # every symbol include/ocean_hip.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [
     "ocean_abi_version", "ocean_context_create", "ocean_context_destroy", "ocean_last_error", "ocean_resolution",
-    "ocean_upload_spectrum", "ocean_fft_init", "ocean_fft_destroy", "ocean_propagation_init",
+    "ocean_upload_spectrum", "ocean_upload_spectrum_f16", "ocean_spectrum_scale_log2", "ocean_read_spectrum",
+    "ocean_fft_init", "ocean_fft_destroy", "ocean_propagation_init",
     "ocean_propagation_destroy", "ocean_correction_init", "ocean_correction_destroy", "ocean_propagate",
     "ocean_fft_rows", "ocean_fft_cols", "ocean_correct", "ocean_frame", "ocean_frame_ex", "ocean_sync",
+    "ocean_normals", "ocean_read_normals",
     "ocean_read_displacement", "ocean_read_field", "ocean_write_field", "ocean_displacement_device_ptr",
     "ocean_bind_displacement", "ocean_stream", "ocean_time_frames", "ocean_profile_frame", "ocean_profile_staged",
 ]
@@ -80,6 +82,9 @@ def load_library():
         "ocean_last_error": (ctypes.c_char_p, [vp]),
         "ocean_resolution": (i32, [vp]),
         "ocean_upload_spectrum": (i32, [vp, vp, vp]),
+        "ocean_upload_spectrum_f16": (i32, [vp, vp, vp]),
+        "ocean_spectrum_scale_log2": (i32, [vp]),
+        "ocean_read_spectrum": (i32, [vp, vp]),
         "ocean_fft_init": (i32, [vp, pp]),
         "ocean_fft_destroy": (None, [vp]),
         "ocean_propagation_init": (i32, [vp, pp]),
@@ -93,6 +98,8 @@ def load_library():
         "ocean_frame": (i32, [vp, f32, vp]),
         "ocean_frame_ex": (i32, [vp, ctypes.POINTER(PropagateLocalsC), vp]),
         "ocean_sync": (i32, [vp]),
+        "ocean_normals": (i32, [vp, i32, vp]),
+        "ocean_read_normals": (i32, [vp, vp]),
         "ocean_read_displacement": (i32, [vp, vp]),
         "ocean_read_field": (i32, [vp, i32, vp]),
         "ocean_write_field": (i32, [vp, i32, vp]),

@@ -42,7 +42,9 @@ struct OceanContext {
     float* omega = nullptr;     // omega_buffer
     c32* field[3] = {nullptr, nullptr, nullptr};   // dx_spec, dy_spec, dz_spec
     // fused path: transposed static inputs + chunked intermediate
-    c32* h0T = nullptr;
+    c32* h0T = nullptr;         // fp32 complex, or (h0_f16) packed half2 in the first N*N*4 bytes
+    bool h0_f16 = false;        // BASELINE config 5: fp16 spectrum storage for the fused path
+    int scale_log2 = 0;
     float* omegaT = nullptr;
     c32* inter = nullptr;
     InterLayout lay{0, 0, 0};     // three complex fields, all N columns        (OCEAN_ALGO=c2c)
@@ -53,6 +55,7 @@ struct OceanContext {
     c32* tw = nullptr;          // e^{+2 pi i k/N}
     float4* out_own = nullptr;  // displacement map (src/render.rs:820-869), linear RGBA32F
     float4* out = nullptr;      // = out_own or the caller's buffer (ocean_bind_displacement)
+    float4* normals = nullptr;  // allocated on first ocean_normals call
     bool uploaded = false;
     bool pass2_thin = true;           // OCEAN_PASS2=fat selects the 1024-thread variant (A/B measurements)
     float default_domain = 1000.0f;   // src/render.rs:46
@@ -106,7 +109,10 @@ template <int N> struct Launch {
         e = hipFuncSetAttribute((const void*)k_frame_pass2_thin<N, G::E, G::P, G::R2>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, G::thin_lds);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)k_half_pass1<N, G::E, G::P>,
+        e = hipFuncSetAttribute((const void*)k_half_pass1<N, G::E, G::P, false>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, G::frame_lds);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)k_half_pass1<N, G::E, G::P, true>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, G::frame_lds);
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute((const void*)k_half_pass2<N, G::E, G::P, G::R2>,
@@ -123,8 +129,15 @@ template <int N> struct Launch {
     }
     static void pass1(OceanContext* c, float time, float domain, hipStream_t s) {
         if (c->half) {
-            hipLaunchKernelGGL((k_half_pass1<N, G::E, G::P>), dim3(G::half_grid1), dim3(G::frame_threads),
-                               G::frame_lds, s, c->h0T, c->omegaT, c->inter, c->nyq, c->tw, c->lay_h, time, domain);
+            const float descale = std::ldexp(1.0f, -c->scale_log2);
+            if (c->h0_f16)
+                hipLaunchKernelGGL((k_half_pass1<N, G::E, G::P, true>), dim3(G::half_grid1), dim3(G::frame_threads),
+                                   G::frame_lds, s, (const void*)c->h0T, descale, c->omegaT, c->inter, c->nyq, c->tw,
+                                   c->lay_h, time, domain);
+            else
+                hipLaunchKernelGGL((k_half_pass1<N, G::E, G::P, false>), dim3(G::half_grid1), dim3(G::frame_threads),
+                                   G::frame_lds, s, (const void*)c->h0T, 1.0f, c->omegaT, c->inter, c->nyq, c->tw,
+                                   c->lay_h, time, domain);
             return;
         }
         hipLaunchKernelGGL((k_frame_pass1<N, G::E, G::P>), dim3(G::frame_grid), dim3(G::frame_threads),
@@ -185,7 +198,7 @@ int32_t check_launch(OceanContext* c, const char* what) {
 void free_all(OceanContext* c) {
     auto f = [](void* p) { if (p) (void)hipFree(p); };
     f(c->h0); f(c->omega); f(c->field[0]); f(c->field[1]); f(c->field[2]);
-    f(c->h0T); f(c->omegaT); f(c->inter); f(c->nyq); f(c->tw); f(c->out_own);
+    f(c->h0T); f(c->omegaT); f(c->inter); f(c->nyq); f(c->tw); f(c->out_own); f(c->normals);
     if (c->stream) (void)hipStreamDestroy(c->stream);
 }
 
@@ -295,30 +308,86 @@ const char* ocean_last_error(const OceanContext* ctx) {
 
 int32_t ocean_resolution(const OceanContext* ctx) { return valid(ctx) ? ctx->n : OCEAN_E_INVALID_ARG; }
 
-int32_t ocean_upload_spectrum(OceanContext* ctx, const float* h0_re_im, const float* omega) {
+namespace {
+
+// fp32 -> fp16 bits, round to nearest even (host side of the config-5 upload)
+uint16_t float_to_half_bits(float f) {
+    const _Float16 h = (_Float16)f;
+    uint16_t b;
+    std::memcpy(&b, &h, sizeof b);
+    return b;
+}
+float half_bits_to_float(uint16_t b) {
+    _Float16 h;
+    std::memcpy(&h, &b, sizeof h);
+    return (float)h;
+}
+
+int32_t upload_common(OceanContext* ctx, const float* h0_re_im, const float* omega, bool f16) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
     if (!h0_re_im || !omega) return fail(ctx, OCEAN_E_INVALID_ARG, "NULL input");
     DeviceGuard guard(ctx->device);
     const size_t n = (size_t)ctx->n, n2 = n * n;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipMemcpy(ctx->h0, h0_re_im, n2 * sizeof(c32), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(ctx->omega, omega, n2 * sizeof(float), hipMemcpyHostToDevice));
-    // one-time re-layout for the fused path: h0T[x][y] = h0[y][x] (blocked host transpose)
-    std::vector<c32> tT;
+    std::vector<c32> nat, tT;
     std::vector<float> oT;
-    try { tT.resize(n2); oT.resize(n2); } catch (...) { return fail(ctx, OCEAN_E_OOM, "host staging allocation failed"); }
+    std::vector<uint32_t> packedT;
+    try { nat.resize(n2); tT.resize(n2); oT.resize(n2); if (f16) packedT.resize(n2); }
+    catch (...) { return fail(ctx, OCEAN_E_OOM, "host staging allocation failed"); }
     const c32* src = reinterpret_cast<const c32*>(h0_re_im);
+    int scale_log2 = 0;
+    if (f16) {
+        float mx = 0.0f;
+        for (size_t i = 0; i < 2 * n2; ++i) { const float a = std::fabs(h0_re_im[i]); if (a > mx) mx = a; }
+        if (!(mx > 0.0f) || !std::isfinite(mx)) scale_log2 = 0;
+        else scale_log2 = 14 - (int)std::floor(std::log2(mx));       // max * 2^s in [2^14, 2^15)
+        const float up = std::ldexp(1.0f, scale_log2), down = std::ldexp(1.0f, -scale_log2);
+        for (size_t i = 0; i < n2; ++i) {                              // the values every kernel will use
+            nat[i] = make_float2(half_bits_to_float(float_to_half_bits(src[i].x * up)) * down,
+                                 half_bits_to_float(float_to_half_bits(src[i].y * up)) * down);
+        }
+    } else {
+        std::memcpy(nat.data(), src, n2 * sizeof(c32));
+    }
+    // one-time re-layout for the fused path: h0T[x][y] = h0[y][x] (blocked host transpose)
     constexpr size_t B = 32;
+    const float up = std::ldexp(1.0f, scale_log2);
     for (size_t y0 = 0; y0 < n; y0 += B)
         for (size_t x0 = 0; x0 < n; x0 += B)
             for (size_t y = y0; y < y0 + B; ++y)
                 for (size_t x = x0; x < x0 + B; ++x) {
-                    tT[x * n + y] = src[y * n + x];
+                    tT[x * n + y] = nat[y * n + x];
                     oT[x * n + y] = omega[y * n + x];
+                    if (f16) packedT[x * n + y] = (uint32_t)float_to_half_bits(nat[y * n + x].x * up) |
+                                                  ((uint32_t)float_to_half_bits(nat[y * n + x].y * up) << 16);
                 }
-    HIP_TRY(ctx, hipMemcpy(ctx->h0T, tT.data(), n2 * sizeof(c32), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->h0, nat.data(), n2 * sizeof(c32), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->omega, omega, n2 * sizeof(float), hipMemcpyHostToDevice));
+    if (f16) HIP_TRY(ctx, hipMemcpy(ctx->h0T, packedT.data(), n2 * sizeof(uint32_t), hipMemcpyHostToDevice));
+    else HIP_TRY(ctx, hipMemcpy(ctx->h0T, tT.data(), n2 * sizeof(c32), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->omegaT, oT.data(), n2 * sizeof(float), hipMemcpyHostToDevice));
+    ctx->h0_f16 = f16;
+    ctx->scale_log2 = scale_log2;
     ctx->uploaded = true;
+    return OCEAN_OK;
+}
+
+}  // namespace
+
+int32_t ocean_upload_spectrum(OceanContext* ctx, const float* h0_re_im, const float* omega) {
+    return upload_common(ctx, h0_re_im, omega, false);
+}
+int32_t ocean_upload_spectrum_f16(OceanContext* ctx, const float* h0_re_im, const float* omega) {
+    if (valid(ctx) && !ctx->half) return fail(ctx, OCEAN_E_STATE, "fp16 spectrum needs the half-spectrum frame (OCEAN_ALGO=c2c is set)");
+    return upload_common(ctx, h0_re_im, omega, true);
+}
+int32_t ocean_spectrum_scale_log2(const OceanContext* ctx) { return valid(ctx) ? ctx->scale_log2 : OCEAN_E_INVALID_ARG; }
+int32_t ocean_read_spectrum(OceanContext* ctx, float* host_re_im) {
+    if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    if (!host_re_im) return fail(ctx, OCEAN_E_INVALID_ARG, "NULL output");
+    if (!ctx->uploaded) return fail(ctx, OCEAN_E_STATE, "ocean_upload_spectrum has not been called");
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, hipMemcpy(host_re_im, ctx->h0, (size_t)ctx->n * ctx->n * sizeof(c32), hipMemcpyDeviceToHost));
     return OCEAN_OK;
 }
 
@@ -407,6 +476,26 @@ int32_t ocean_frame(OceanContext* ctx, float time, void* stream) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
     OceanPropagateLocals l{time, ctx->n, ctx->default_domain};
     return ocean_frame_ex(ctx, &l, stream);
+}
+
+int32_t ocean_normals(OceanContext* ctx, int32_t source_channel, void* stream) {
+    if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    if (source_channel < 0 || source_channel > 2) return fail(ctx, OCEAN_E_INVALID_ARG, "source_channel must be 0, 1 or 2");
+    DeviceGuard guard(ctx->device);
+    const size_t n2 = (size_t)ctx->n * ctx->n;
+    if (!ctx->normals) HIP_TRY(ctx, hipMalloc((void**)&ctx->normals, n2 * sizeof(float4)));
+    hipLaunchKernelGGL(k_normals, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, pick(ctx, stream), ctx->out,
+                       ctx->normals, ctx->n, source_channel);
+    return check_launch(ctx, "k_normals launch");
+}
+int32_t ocean_read_normals(OceanContext* ctx, float* host_xyz0) {
+    if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    if (!host_xyz0) return fail(ctx, OCEAN_E_INVALID_ARG, "NULL output");
+    if (!ctx->normals) return fail(ctx, OCEAN_E_STATE, "ocean_normals has not been called");
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(host_xyz0, ctx->normals, (size_t)ctx->n * ctx->n * sizeof(float4), hipMemcpyDeviceToHost));
+    return OCEAN_OK;
 }
 
 int32_t ocean_sync(OceanContext* ctx) {

@@ -39,6 +39,14 @@ __device__ __forceinline__ void store_float4_nt(float4* p, float4 v) {
 __device__ __forceinline__ float sin_rev(float x) { return __builtin_amdgcn_sinf(x); }
 __device__ __forceinline__ float cos_rev(float x) { return __builtin_amdgcn_cosf(x); }
 
+// BASELINE config 5: the initial spectrum stored as two fp16 (re, im) per texel, scaled by a power
+// of two; all arithmetic stays fp32.  v_cvt_f32_f16 x2.
+typedef _Float16 ocean_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 unpack_half2(uint32_t bits, float descale) {
+    const ocean_h2 h = __builtin_bit_cast(ocean_h2, bits);
+    return make_float2((float)h.x * descale, (float)h.y * descale);
+}
+
 // x is known to be identical in every lane of the wave: move it to an SGPR so that addresses
 // derived from it become scalar bases (one VGPR offset + SGPR base instead of E 64-bit VGPR pairs).
 __device__ __forceinline__ int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }

@@ -120,6 +120,32 @@ k_correct(const c32* __restrict__ height, const c32* __restrict__ disp_x, const 
     out[index + 1u] = make_float4(dx.z * s1, h.z * s1, dz.z * s1, 0.0f);
 }
 
+// SURVEY 8f #1 -- the reference's "normal field" (shader/ocean.frag:50-66) as a compute kernel at
+// texel centres: finite differences of one channel of the displacement map with Tile wrap
+// (src/render.rs:398), height_scale 180 (:19), diff = 2/N (the shader's literal 512 -> N).
+// channel 0 = disp_x is what the reference differentiates (quirk Q5); 1 = height is the
+// physically meant source.  One thread per texel; the four neighbours are L1/L2 hits.
+__global__ void __launch_bounds__(256)
+k_normals(const float4* __restrict__ rgba, float4* __restrict__ normals, int n, int channel) {
+    const uint32_t un = (uint32_t)n;
+    const uint32_t index = blockIdx.x * 256u + threadIdx.x;
+    if (index >= un * un) return;
+    const uint32_t x = index % un, y = index / un;
+    const uint32_t xm = (x + un - 1u) % un, xp = (x + 1u) % un, ym = (y + un - 1u) % un, yp = (y + 1u) % un;
+    const float* f = reinterpret_cast<const float*>(rgba) + channel;
+    const float x0 = f[((size_t)y * un + xm) * 4], x1 = f[((size_t)y * un + xp) * 4];
+    const float z0 = f[((size_t)ym * un + x) * 4], z1 = f[((size_t)yp * un + x) * 4];
+    const float d = 2.0f / (float)n;                               // :52
+    // na = normalize(-d, (x1-x0)/180, 0), nb = normalize(0, (z1-z0)/180, d)      :64-65
+    const float ay = (x1 - x0) / 180.0f, by = (z1 - z0) / 180.0f;
+    const float la = sqrtf(d * d + ay * ay), lb = sqrtf(by * by + d * d);
+    const float nax = -d / la, nay = ay / la, nby = by / lb, nbz = d / lb;
+    // cross(na, nb) with na.z = nb.x = 0                                           :66
+    const float cx = nay * nbz, cy = -nax * nbz, cz = nax * nby;
+    const float lc = sqrtf(cx * cx + cy * cy + cz * cz);
+    normals[index] = make_float4(cx / lc, cy / lc, cz / lc, 0.0f);
+}
+
 // LDS pitch of one line buffer: padded line + 4 elements so that P adjacent lines do not alias.
 template <int N> struct LinePitch { static constexpr int elems = LdsLine<N>::elems + 4; };
 
@@ -382,17 +408,31 @@ __device__ __forceinline__ void half_spectrum(int f, const c32 (&A)[E], const c3
     }
 }
 
+// The initial spectrum in HBM: fp32 complex (8 B/texel), or -- BASELINE config 5 -- two fp16 with
+// a power-of-two scale (4 B/texel); arithmetic is fp32 either way.
+template <bool H16> struct Spec;
+template <> struct Spec<false> {
+    typedef c32 elem;
+    static __device__ __forceinline__ c32 load(const elem* p, float) { return *p; }
+};
+template <> struct Spec<true> {
+    typedef uint32_t elem;
+    static __device__ __forceinline__ c32 load(const elem* p, float descale) { return unpack_half2(*p, descale); }
+};
+
 // A = H(y, x), B = conj(H((-y)%N, (-x)%N)) for the E positions of a thread on column x.
-template <int N, int E>
-__device__ __forceinline__ void half_load_AB(const c32* __restrict__ h0T, const float* __restrict__ omegaT,
+template <int N, int E, bool H16>
+__device__ __forceinline__ void half_load_AB(const void* __restrict__ h0T_, float descale, const float* __restrict__ omegaT,
                                              uint32_t x, int j, float time, c32 (&A)[E], c32 (&B)[E]) {
+    typedef typename Spec<H16>::elem S;
     constexpr int T = N / E;
+    const S* h0T = reinterpret_cast<const S*>(h0T_);
     const uint32_t x2 = (N - x) & (N - 1);
     const uint32_t xm = (x - 1u) & (N - 1);
-    const c32* own = h0T + (size_t)x * N;
-    const c32* mir = h0T + (size_t)(N - 1 - x) * N;
-    const c32* own2 = h0T + (size_t)x2 * N;
-    const c32* mir2 = h0T + (size_t)xm * N;
+    const S* own = h0T + (size_t)x * N;
+    const S* mir = h0T + (size_t)(N - 1 - x) * N;
+    const S* own2 = h0T + (size_t)x2 * N;
+    const S* mir2 = h0T + (size_t)xm * N;
     const float* om = omegaT + (size_t)x * N;
     const float* om2 = omegaT + (size_t)x2 * N;
     // LOAD_BATCHES batches: a batch's 6 loads per element are issued only after the previous batch's
@@ -408,20 +448,20 @@ __device__ __forceinline__ void half_load_AB(const c32* __restrict__ h0T, const 
         // y = jj + e*T.  Every address is written as (uniform base + e-dependent constant)[small lane index]
         // so that the six streams share three lane offsets and the bases stay in SGPRs; only e == 0 can
         // hit the wrap of y2 = (N - y) % N and ym = (y - 1) % N (at jj == 0).
-        const c32 a = (own + e * T)[jj];
-        const c32 m = (mir + (N - (e + 1) * T))[T - 1 - jj];       // mir[N - 1 - y]
+        const c32 a = Spec<H16>::load((own + e * T) + jj, descale);
+        const c32 m = Spec<H16>::load((mir + (N - (e + 1) * T)) + (T - 1 - jj), descale);   // mir[N - 1 - y]
         const float w = (om + e * T)[jj];
         c32 a2, m2;
         float w2;
         if (e == 0) {
             const int y2 = (N - jj) & (N - 1);
             const int ym = (jj - 1) & (N - 1);
-            a2 = own2[y2];
-            m2 = mir2[ym];
+            a2 = Spec<H16>::load(own2 + y2, descale);
+            m2 = Spec<H16>::load(mir2 + ym, descale);
             w2 = om2[y2];
         } else {
-            a2 = (own2 + (N - (e + 1) * T))[T - jj];               // own2[N - y]
-            m2 = (mir2 + (e * T - 1))[jj];                         // mir2[y - 1]
+            a2 = Spec<H16>::load((own2 + (N - (e + 1) * T)) + (T - jj), descale);   // own2[N - y]
+            m2 = Spec<H16>::load((mir2 + (e * T - 1)) + jj, descale);               // mir2[y - 1]
             w2 = (om2 + (N - (e + 1) * T))[T - jj];
         }
         A[e] = propagate_height(a, m, w, time);
@@ -433,9 +473,9 @@ __device__ __forceinline__ void half_load_AB(const c32* __restrict__ h0T, const 
 // grid = 1 + (N/2)/P blocks: block 0 does the Nyquist column (three line FFTs, one per field, spread
 // over the P lines; a fraction of a regular block's work, dispatched first; measured cost 3 us at
 // N = 4096), blocks 1.. the column groups.
-template <int N, int E, int P>
+template <int N, int E, int P, bool H16>
 __global__ void __launch_bounds__((N / E) * P)
-k_half_pass1(const c32* __restrict__ h0T, const float* __restrict__ omegaT, c32* __restrict__ inter,
+k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restrict__ omegaT, c32* __restrict__ inter,
              float* __restrict__ nyq, const c32* __restrict__ tw, InterLayout lay, float time, float domain_size) {
     constexpr int T = N / E;
     constexpr int H2 = P / 2;
@@ -451,7 +491,7 @@ k_half_pass1(const c32* __restrict__ h0T, const float* __restrict__ omegaT, c32*
         // line c transforms fields c, c + P, ... (one round for P = 4, two for P = 2); every line runs
         // the same number of rounds so that the barriers inside fft_line stay uniform
         c32 A[E], B[E];
-        half_load_AB<N, E>(h0T, omegaT, (uint32_t)(N / 2), j, time, A, B);
+        half_load_AB<N, E, H16>(h0T, descale, omegaT, (uint32_t)(N / 2), j, time, A, B);
         const float kxn = wave_index_q1((uint32_t)(N / 2), N) * kscale;
         constexpr int ROUNDS = (3 + P - 1) / P;
 #pragma unroll
@@ -474,7 +514,7 @@ k_half_pass1(const c32* __restrict__ h0T, const float* __restrict__ omegaT, c32*
     const uint32_t x = (uint32_t)(X * P + c);                      // kx in [0, N/2)
     const uint32_t x2 = (N - x) & (N - 1);
     c32 A[E], B[E];
-    half_load_AB<N, E>(h0T, omegaT, x, j, time, A, B);
+    half_load_AB<N, E, H16>(h0T, descale, omegaT, x, j, time, A, B);
     const float kx1 = wave_index_q1(x, N) * kscale;
     const float kx2 = wave_index_q1(x2, N) * kscale;
 

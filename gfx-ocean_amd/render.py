@@ -49,18 +49,44 @@ class OceanDevice:
         self._check(load_library().ocean_sync(self._ctx))
 
     # -- upload (src/render.rs:742-924) ----------------------------------------------------------
-    def upload_spectrum(self, h0: np.ndarray, omega: np.ndarray):
+    def upload_spectrum(self, h0: np.ndarray, omega: np.ndarray, spectrum_fp16: bool = False):
+        """spectrum_fp16=True: BASELINE config 5 -- h0 kept in HBM as scaled fp16 pairs for the fused
+        path (fp32 arithmetic); read_spectrum() then returns the dequantised values in use."""
         n = self.resolution
         h0 = np.ascontiguousarray(h0, dtype=np.complex64)
         omega = np.ascontiguousarray(omega, dtype=np.float32)
         if h0.shape != (n, n) or omega.shape != (n, n):
             raise OceanError(-1, f"expected ({n},{n}) arrays, got {h0.shape} and {omega.shape}")
-        self._check(load_library().ocean_upload_spectrum(self._ctx, h0.ctypes.data, omega.ctypes.data))
+        fn = load_library().ocean_upload_spectrum_f16 if spectrum_fp16 else load_library().ocean_upload_spectrum
+        self._check(fn(self._ctx, h0.ctypes.data, omega.ctypes.data))
+
+    def read_spectrum(self) -> np.ndarray:
+        n = self.resolution
+        out = np.empty((n, n), dtype=np.complex64)
+        self._check(load_library().ocean_read_spectrum(self._ctx, out.ctypes.data))
+        return out
+
+    @property
+    def spectrum_scale_log2(self) -> int:
+        return int(load_library().ocean_spectrum_scale_log2(self._ctx))
 
     # -- fused frame ---------------------------------------------------------------------------------
     def frame(self, time: float, domain_size: float = DOMAIN_SIZE, stream=None):
         loc = PropagateLocals(time, self.resolution, domain_size)._c()
         self._check(load_library().ocean_frame_ex(self._ctx, ctypes.byref(loc), stream))
+
+    # -- SURVEY 8f #1: normal field (shader/ocean.frag:50-66) ----------------------------------------
+    def normals(self, source_channel: int = 0, stream=None) -> np.ndarray:
+        """Finite-difference normals of the current displacement map; channel 0 = disp_x as the
+        reference does (quirk Q5), 1 = height.  -> float32 [N, N, 4] = (n.x, n.y, n.z, 0)."""
+        lib = load_library()
+        self._check(lib.ocean_normals(self._ctx, int(source_channel), stream))
+        n = self.resolution
+        out = np.empty((n, n, 4), dtype=np.float32)
+        if stream is not None:
+            raise OceanError(-1, "normals(): pass stream=None (the readback synchronises the context stream)")
+        self._check(lib.ocean_read_normals(self._ctx, out.ctypes.data))
+        return out
 
     # -- readback / injection ----------------------------------------------------------------------
     def read_displacement(self) -> np.ndarray:
@@ -125,8 +151,8 @@ class OceanRenderer:
         self.correction = Correction.init(self.device)    # src/render.rs:225
         self.domain_size = float(domain_size)
 
-    def upload(self, h0, omega):
-        self.device.upload_spectrum(h0, omega)
+    def upload(self, h0, omega, spectrum_fp16: bool = False):
+        self.device.upload_spectrum(h0, omega, spectrum_fp16)
 
     def render(self, time: float, stream=None):
         n = self.device.resolution

@@ -27,6 +27,9 @@ extern "C" {
     pub fn ocean_last_error(ctx: *const OceanContext) -> *const c_char;
     pub fn ocean_resolution(ctx: *const OceanContext) -> i32;
     pub fn ocean_upload_spectrum(ctx: *mut OceanContext, h0_re_im: *const f32, omega: *const f32) -> i32;
+    pub fn ocean_upload_spectrum_f16(ctx: *mut OceanContext, h0_re_im: *const f32, omega: *const f32) -> i32;
+    pub fn ocean_spectrum_scale_log2(ctx: *const OceanContext) -> i32;
+    pub fn ocean_read_spectrum(ctx: *mut OceanContext, host_re_im: *mut f32) -> i32;
     pub fn ocean_fft_init(ctx: *mut OceanContext, out: *mut *mut OceanFft) -> i32;
     pub fn ocean_fft_destroy(fft: *mut OceanFft);
     pub fn ocean_propagation_init(ctx: *mut OceanContext, out: *mut *mut OceanPropagation) -> i32;
@@ -39,6 +42,8 @@ extern "C" {
     pub fn ocean_correct(c: *mut OceanCorrection, locals: *const OceanCorrectionLocals, stream: *mut c_void) -> i32;
     pub fn ocean_frame(ctx: *mut OceanContext, time: f32, stream: *mut c_void) -> i32;
     pub fn ocean_frame_ex(ctx: *mut OceanContext, locals: *const OceanPropagateLocals, stream: *mut c_void) -> i32;
+    pub fn ocean_normals(ctx: *mut OceanContext, source_channel: i32, stream: *mut c_void) -> i32;
+    pub fn ocean_read_normals(ctx: *mut OceanContext, host_xyz0: *mut f32) -> i32;
     pub fn ocean_sync(ctx: *mut OceanContext) -> i32;
     pub fn ocean_read_displacement(ctx: *mut OceanContext, host_rgba: *mut f32) -> i32;
     pub fn ocean_read_field(ctx: *mut OceanContext, field: i32, host_re_im: *mut f32) -> i32;

@@ -80,6 +80,17 @@ int32_t ocean_resolution(const OceanContext* ctx);
  * src/render.rs:742-818 (decode + staging) and :872-924 (copy_buffer, submit, wait).  Synchronous. */
 int32_t ocean_upload_spectrum(OceanContext* ctx, const float* h0_re_im, const float* omega);
 
+/* BASELINE config 5 ("fp16 spectrum / fp32 accumulate"): same upload, but the fused path keeps the
+ * initial spectrum in HBM as two fp16 per texel, h0 * 2^scale_log2 rounded to nearest even, the
+ * scale chosen so that max|component| lands in [2^14, 2^15) (small amplitudes would otherwise fall
+ * below the fp16 normal range).  Every kernel computes in fp32 on the dequantised values; the staged
+ * path and ocean_read_spectrum use exactly those values, so parity is judged against the oracle
+ * fed the same quantised inputs.  omega stays fp32. */
+int32_t ocean_upload_spectrum_f16(OceanContext* ctx, const float* h0_re_im, const float* omega);
+int32_t ocean_spectrum_scale_log2(const OceanContext* ctx);          /* 0 for an fp32 upload */
+/* The initial spectrum the kernels actually use (dequantised if uploaded as fp16), N*N complex. */
+int32_t ocean_read_spectrum(OceanContext* ctx, float* host_re_im);
+
 /* ---- stage objects: init/destroy mirror the reference 1:1 -------------------------------- */
 int32_t ocean_fft_init(OceanContext* ctx, OceanFft** out);                  /* src/fft.rs:19-100 */
 void ocean_fft_destroy(OceanFft* fft);                                      /* src/fft.rs:102-110 */
@@ -103,6 +114,13 @@ int32_t ocean_correct(OceanCorrection* c, const OceanCorrectionLocals* locals, v
  * within fp32 re-association.  The staged field buffers are NOT updated by this call. */
 int32_t ocean_frame(OceanContext* ctx, float time, void* stream);
 int32_t ocean_frame_ex(OceanContext* ctx, const OceanPropagateLocals* locals, void* stream);
+
+/* the reference's normal field (shader/ocean.frag:50-66: finite differences of the
+ * displacement map with Tile wrap, height_scale 180) as a compute pass over the current
+ * displacement map.  source_channel 0 = disp_x (what the reference differentiates, quirk Q5),
+ * 1 = height.  Result: float4[N*N] = (n.x, n.y, n.z, 0), read with ocean_read_normals. */
+int32_t ocean_normals(OceanContext* ctx, int32_t source_channel, void* stream);
+int32_t ocean_read_normals(OceanContext* ctx, float* host_xyz0 /* N*N*4 */);
 
 int32_t ocean_sync(OceanContext* ctx); /* wait for the context stream (the reference never waits: src/render.rs:1068-1075) */
 

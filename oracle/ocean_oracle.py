@@ -242,6 +242,56 @@ def ifft_lines_f64(lines):
 
 
 # --------------------------------------------------------------------------
+# 8f #1: the "normal field" -- shader/ocean.frag:50-66, restated at texel centres with the
+# sampler's Tile wrap (src/render.rs:398).  Channel R (= disp_x) is differentiated, not height
+# (quirk Q5); dim literal 512 -> N; height_scale = 180 (:19).
+# --------------------------------------------------------------------------
+HEIGHT_SCALE = np.float32(180.0)
+
+
+def normals_literal(rgba: np.ndarray, channel: int = 0) -> np.ndarray:
+    """rgba float32 [N,N,4] -> float32 [N,N,4] = (n.x, n.y, n.z, 0).  channel 0 = reference (Q5)."""
+    f = np.float32
+    r = rgba[..., channel].astype(f)
+    n = r.shape[0]
+    x0, x1 = np.roll(r, 1, axis=1), np.roll(r, -1, axis=1)      # textureOffset(-1,0) / (+1,0), wrap
+    z0, z1 = np.roll(r, 1, axis=0), np.roll(r, -1, axis=0)
+    d = f(2.0) / f(n)                                             # diff = 2 / dim (:52)
+
+    def normalize(v):
+        ln = np.sqrt((v[0] * v[0] + v[1] * v[1] + v[2] * v[2]).astype(f)).astype(f)
+        return [(c / ln).astype(f) for c in v]
+
+    zero = np.zeros_like(r)
+    na = normalize([np.full_like(r, -d), ((x1 - x0).astype(f) / HEIGHT_SCALE).astype(f), zero])   # :64
+    nb = normalize([zero, ((z1 - z0).astype(f) / HEIGHT_SCALE).astype(f), np.full_like(r, d)])    # :65
+    cx = (na[1] * nb[2] - na[2] * nb[1]).astype(f)
+    cy = (na[2] * nb[0] - na[0] * nb[2]).astype(f)
+    cz = (na[0] * nb[1] - na[1] * nb[0]).astype(f)
+    nn = normalize([cx, cy, cz])                                                                  # :66
+    out = np.zeros(rgba.shape[:2] + (4,), f)
+    out[..., 0], out[..., 1], out[..., 2] = nn
+    return out
+
+
+def normals_f64(rgba: np.ndarray, channel: int = 0) -> np.ndarray:
+    r = rgba[..., channel].astype(np.float64)
+    n = r.shape[0]
+    dx = (np.roll(r, -1, axis=1) - np.roll(r, 1, axis=1)) / 180.0
+    dz = (np.roll(r, -1, axis=0) - np.roll(r, 1, axis=0)) / 180.0
+    d = 2.0 / n
+    na = np.stack([np.full_like(r, -d), dx, np.zeros_like(r)], -1)
+    nb = np.stack([np.zeros_like(r), dz, np.full_like(r, d)], -1)
+    na /= np.linalg.norm(na, axis=-1, keepdims=True)
+    nb /= np.linalg.norm(nb, axis=-1, keepdims=True)
+    c = np.cross(na, nb)
+    c /= np.linalg.norm(c, axis=-1, keepdims=True)
+    out = np.zeros(rgba.shape[:2] + (4,))
+    out[..., :3] = c
+    return out
+
+
+# --------------------------------------------------------------------------
 # Parity metric, SURVEY 8d: normalised max and relative L2 per channel.
 # --------------------------------------------------------------------------
 def parity_errors(a, b):

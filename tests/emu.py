@@ -32,7 +32,8 @@ def lib():
         _LIB.emu_frame_pass1.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_size_t] * 3 + [ctypes.c_float] * 2
         _LIB.emu_frame_pass2.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_size_t] * 3
         _LIB.emu_frame_pass2_thin.argtypes = _LIB.emu_frame_pass2.argtypes
-        _LIB.emu_frame_half.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 6 + [ctypes.c_size_t] * 3 + [ctypes.c_float] * 2
+        _LIB.emu_frame_half.argtypes = ([ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_float] + [ctypes.c_void_p] * 5 +
+                                        [ctypes.c_size_t] * 3 + [ctypes.c_float] * 2)
         _LIB.emu_fft_lines.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         _LIB.emu_propagate.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_float] * 2
         _LIB.emu_correct.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4
@@ -120,17 +121,45 @@ def half_layout(n, P, layout="p2", pad=32):
     return sx, sy, sy * groups
 
 
-def frame_half(h0, omega, time, L=1000.0, layout="p2", return_inter=False):
+def quantize_f16(h0):
+    """Host side of the config-5 upload (mirrors ocean_api.hip upload_common): -> (packed uint32 [N,N]
+    = fp16 re | fp16 im << 16 of h0 * 2^s, dequantised complex64 [N,N], s)."""
+    h0 = np.ascontiguousarray(h0, np.complex64)
+    mx = float(np.abs(h0.view(np.float32)).max())
+    s = 14 - int(np.floor(np.log2(mx))) if mx > 0 else 0
+    scaled = (h0.view(np.float32).astype(np.float32) * np.float32(2.0 ** s)).astype(np.float16)
+    deq = (scaled.astype(np.float32) * np.float32(2.0 ** -s)).view(np.complex64).reshape(h0.shape)
+    bits = scaled.view(np.uint16).reshape(h0.shape + (2,)).astype(np.uint32)
+    return (bits[..., 0] | (bits[..., 1] << 16)).astype(np.uint32), deq, s
+
+
+def frame_half(h0, omega, time, L=1000.0, layout="p2", return_inter=False, spectrum_fp16=False):
     n = h0.shape[0]
     P = lib().emu_frame_p(n)
-    h0T = np.ascontiguousarray(h0.T, np.complex64)
+    descale = 1.0
+    if spectrum_fp16:
+        packed, _, s = quantize_f16(h0)
+        h0T = np.ascontiguousarray(packed.T, np.uint32)
+        descale = 2.0 ** -s
+    else:
+        h0T = np.ascontiguousarray(h0.T, np.complex64)
     omT = np.ascontiguousarray(omega.T, np.float32)
     sx, sy, fs = half_layout(n, P, layout)
     inter = np.full(3 * fs, np.nan + 1j * np.nan, np.complex64)
     nyq = np.full(3 * n, np.nan, np.float32)
     out = np.full((n, n, 4), np.nan, np.float32)
     tw = twiddles(n)
-    assert lib().emu_frame_half(n, _p(h0T), _p(omT), _p(inter), _p(nyq), _p(out), _p(tw), sx, sy, fs, time, L) == 0
+    assert lib().emu_frame_half(n, _p(h0T), int(spectrum_fp16), descale, _p(omT), _p(inter), _p(nyq), _p(out), _p(tw),
+                                sx, sy, fs, time, L) == 0
     if return_inter:
         return out, inter, nyq, (P, (sx, sy, fs))
+    return out
+
+
+def normals(rgba, channel=0):
+    rgba = np.ascontiguousarray(rgba, np.float32)
+    n = rgba.shape[0]
+    out = np.empty((n, n, 4), np.float32)
+    lib().emu_normals.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    assert lib().emu_normals(n, _p(rgba), _p(out), int(channel)) == 0
     return out

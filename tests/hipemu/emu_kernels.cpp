@@ -70,11 +70,13 @@ template <int N> static int run_pass2_thin(const c32* inter, float4* out, const 
     return 0;
 }
 
-template <int N> static int run_half(const c32* h0T, const float* omT, c32* inter, float* nyq, float4* out, const c32* tw,
-                                     InterLayout lay, float time, float L) {
+template <int N> static int run_half(const void* h0T, int f16, float descale, const float* omT, c32* inter, float* nyq, float4* out,
+                                     const c32* tw, InterLayout lay, float time, float L) {
     using G = Geo<N>;
-    emu_launch(G::half_grid1, G::frame_threads,
-               [&] { k_half_pass1<N, G::E, G::P>(h0T, omT, inter, nyq, tw, lay, time, L); });
+    if (f16) emu_launch(G::half_grid1, G::frame_threads,
+                        [&] { k_half_pass1<N, G::E, G::P, true>(h0T, descale, omT, inter, nyq, tw, lay, time, L); });
+    else emu_launch(G::half_grid1, G::frame_threads,
+                    [&] { k_half_pass1<N, G::E, G::P, false>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L); });
     emu_launch(G::thin_grid, G::thin_threads,
                [&] { k_half_pass2<N, G::E, G::P, G::R2>(inter, nyq, out, tw, lay); });
     return 0;
@@ -117,11 +119,16 @@ int emu_frame_pass2_thin(int n, const float* inter, float* out, const float* tw,
     DISPATCH(n, C_)
 #undef C_
 }
-int emu_frame_half(int n, const float* h0T, const float* omT, float* inter, float* nyq, float* out, const float* tw,
-                   size_t sx, size_t sy, size_t fs, float time, float L) {
-#define C_(N) run_half<N>((const c32*)h0T, omT, (c32*)inter, nyq, (float4*)out, (const c32*)tw, InterLayout{sx, sy, fs}, time, L)
+int emu_frame_half(int n, const void* h0T, int f16, float descale, const float* omT, float* inter, float* nyq, float* out,
+                   const float* tw, size_t sx, size_t sy, size_t fs, float time, float L) {
+#define C_(N) run_half<N>(h0T, f16, descale, omT, (c32*)inter, nyq, (float4*)out, (const c32*)tw, InterLayout{sx, sy, fs}, time, L)
     DISPATCH(n, C_)
 #undef C_
+}
+int emu_normals(int n, const float* rgba, float* normals, int channel) {
+    const int grid = (n * n + 255) / 256;
+    emu_launch(grid, 256, [&] { k_normals((const float4*)rgba, (float4*)normals, n, channel); });
+    return 0;
 }
 int emu_propagate(int n, const float* h0, const float* omega, float* h, float* dx, float* dz, float time, float L) {
     const int grid = (n * n / 2 + 255) / 256;

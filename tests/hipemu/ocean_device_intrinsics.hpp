@@ -1,8 +1,23 @@
 // Host stand-in for gfx-ocean_amd/csrc/ocean_device_intrinsics.hpp (CPU emulation build only).
 #pragma once
 #include <cmath>
+#include <cstdint>
 namespace ocean {
 static inline int opaque_lane(int x) { return x; }
+static inline float ocean_emu_half_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    const int exp = (h >> 10) & 31;
+    const uint32_t man = h & 1023u;
+    float mag;
+    if (exp == 0) mag = std::ldexp((float)man, -24);
+    else if (exp == 31) mag = man ? NAN : INFINITY;
+    else mag = std::ldexp((float)(man | 1024u), exp - 25);
+    return sign ? -mag : mag;
+}
+static inline float2 unpack_half2(uint32_t bits, float descale) {
+    return make_float2(ocean_emu_half_to_float((uint16_t)(bits & 0xFFFFu)) * descale,
+                       ocean_emu_half_to_float((uint16_t)(bits >> 16)) * descale);
+}
 static inline int wave_uniform(int x) { return x; }
 static inline float sin_rev(float x) { return (float)std::sin(6.283185307179586 * (double)x); }
 static inline float cos_rev(float x) { return (float)std::cos(6.283185307179586 * (double)x); }

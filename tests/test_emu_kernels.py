@@ -69,3 +69,42 @@ def test_emu_intermediate_layout(ref_inputs_256, layout):
         assert_parity(emu.unpack_inter(inter, n, P, lay, f), ref, 5e-6, f"intermediate field {f}")
     assert np.isnan(inter.real).sum() == 3 * (lay[2] - n * n)     # exactly the padding is untouched
     assert_parity(out[..., :3], oc.frame_f64(h0, om, 2.0)[..., :3], 5e-6, "frame")
+
+
+@pytest.mark.parametrize("channel", [0, 1])
+def test_emu_normals(ref_inputs_256, channel):
+    """SURVEY 8f #1: k_normals vs the restatement of shader/ocean.frag:50-66."""
+    h0, om = ref_inputs_256
+    rgba = oc.frame_literal(h0, om, 2.0)
+    got = emu.normals(rgba, channel)
+    ref = oc.normals_literal(rgba, channel)
+    assert np.abs(got - ref).max() <= 2e-6
+    assert np.abs(got[..., :3] - oc.normals_f64(rgba, channel)[..., :3]).max() <= 2e-6
+    assert np.allclose(np.linalg.norm(got[..., :3], axis=-1), 1.0, atol=1e-6) and np.all(got[..., 3] == 0)
+
+
+@pytest.mark.parametrize("t", [0.0, 3.0])
+def test_emu_half_spectrum_frame(ref_inputs_256, t):
+    """The shipped fused path (real-output algorithm: half the column FFTs, two row FFTs)."""
+    h0, om = ref_inputs_256
+    out = emu.frame_half(h0, om, t)
+    assert not np.isnan(out).any()
+    assert_parity(out[..., :3], oc.frame_f64(h0, om, t)[..., :3], 5e-6, "emu half-spectrum frame")
+    assert np.all(out[..., 3] == 0.0)
+
+
+def test_emu_half_spectrum_frame_512(ref_inputs):
+    h0, om = ref_inputs
+    assert_parity(emu.frame_half(h0, om, 10.0)[..., :3], oc.frame_f64(h0, om, 10.0)[..., :3], 5e-6, "emu half 512")
+
+
+def test_emu_fp16_spectrum_config5(ref_inputs_256):
+    """BASELINE config 5 semantics at a small N: fp16-stored h0 (scaled), fp32 arithmetic; parity
+    against the oracle fed the SAME quantised inputs, and the quantisation error itself is ~3e-4."""
+    h0, om = ref_inputs_256
+    _, deq, s = emu.quantize_f16(h0)
+    assert 2 ** 14 <= np.abs(h0.view(np.float32)).max() * 2.0 ** s < 2 ** 15
+    out = emu.frame_half(h0, om, 1.0, spectrum_fp16=True)
+    assert_parity(out[..., :3], oc.frame_f64(deq, om, 1.0)[..., :3], 5e-6, "fp16 spectrum vs oracle on quantised inputs")
+    nmax, rl2 = oc.parity_errors(out[..., :3], oc.frame_f64(h0, om, 1.0)[..., :3])
+    assert 1e-5 < rl2.max() < 2e-3          # fp16 rounding of the inputs is visible, as SURVEY 7 predicts

@@ -212,6 +212,57 @@ def test_linearity_and_impulse_1024():
         r.dispose()
 
 
+@pytest.mark.parametrize("channel", [0, 1])
+def test_normal_field(r512, ref_inputs, channel):
+    """SURVEY 8f #1: normals of the displacement map (shader/ocean.frag:50-66, quirk Q5 for channel 0)."""
+    r512.render_fused(2.0)
+    rgba = r512.displacement()
+    got = r512.device.normals(channel)
+    ref = oc.normals_literal(rgba, channel)              # same fp32 map in, so the comparison is elementwise
+    assert np.abs(got - ref).max() <= 1e-5
+    # and end to end against the fp64 oracle of the whole path: normals are O(1), tolerance absolute
+    ref64 = oc.normals_f64(oc.frame_f64(*ref_inputs, 2.0), channel)
+    assert np.abs(got[..., :3] - ref64[..., :3]).max() <= 1e-3   # d(normal)/d(field) ~ N/360: 1e-6 field error -> ~1e-4
+    assert np.allclose(np.linalg.norm(got[..., :3], axis=-1), 1.0, atol=1e-5)
+
+
+@pytest.mark.parametrize("n", [512, 8192])
+def test_config5_fp16_spectrum(n, ref_inputs):
+    """BASELINE config 5: fp16 spectrum / fp32 accumulate (N = 8192 is the configured size; 512 uses the
+    reference data).  Parity against the oracle fed the same quantised inputs (SURVEY 7)."""
+    if n == 512:
+        h0, om = ref_inputs
+    else:
+        h0, om = g.synth.make_inputs(n)
+    d = g.OceanDevice(n)
+    try:
+        d.upload_spectrum(h0, om, spectrum_fp16=True)
+        s = d.spectrum_scale_log2
+        assert 2 ** 14 <= np.abs(h0.view(np.float32)).max() * 2.0 ** s < 2 ** 15
+        deq = d.read_spectrum()
+        q = (h0.view(np.float32) * np.float32(2.0 ** s)).astype(np.float16).astype(np.float32) * np.float32(2.0 ** -s)
+        assert np.array_equal(deq.view(np.float32), q.reshape(deq.view(np.float32).shape))   # RNE fp16, power-of-two scale
+        t = 1.25
+        d.frame(t)
+        out = d.read_displacement()
+        if n == 512:
+            assert_parity(out[..., :3], oc.frame_f64(deq, om, t)[..., :3], TOL, "fp16 spectrum vs oracle(quantised)")
+            nmax, rl2 = oc.parity_errors(out[..., :3], oc.frame_f64(h0, om, t)[..., :3])
+            assert rl2.max() > 1e-5              # the quantisation is real: not the fp32 result
+        else:
+            # full size: sampled texels by direct fp64 summation of the quantised spectrum
+            H, DX, DZ = oc.propagate_f64(deq, om, t)
+            k = np.arange(n)
+            scale = np.abs(out[..., :3]).max((0, 1))
+            for (x, y) in [(0, 0), (n // 2 + 3, n // 3), (n - 1, n - 1)]:
+                ey, ex = np.exp(2j * np.pi * k * y / n), np.exp(2j * np.pi * k * x / n)
+                sgn = -1.0 if (x + y) % 2 == 0 else 1.0
+                ref = np.array([(ey @ (F @ ex)).real for F in (DX, H, DZ)]) * sgn
+                assert np.all(np.abs(out[y, x, :3] - ref) <= TOL * scale), (x, y, out[y, x, :3], ref)
+    finally:
+        d.destroy()
+
+
 def test_time_is_stateless(r512, ref_inputs):
     """No state but `time` (SURVEY 5 checkpoint/resume): frames are reproducible in any order."""
     r512.render_fused(5.0)

@@ -216,7 +216,7 @@ x_half_pass1(const c32* __restrict__ h0T, const float* __restrict__ omegaT, c32*
         if (blockIdx.x == 0) {
             const int f = (c < 3) ? c : 2;
             c32 A[E], B[E], reg[E];
-            half_load_AB<N, E>(h0T, omegaT, (uint32_t)(N / 2), j, time, A, B);
+            half_load_AB<N, E, false>(h0T, 1.0f, omegaT, (uint32_t)(N / 2), j, time, A, B);
             const float kxn = wave_index_q1((uint32_t)(N / 2), N) * kscale;
             half_spectrum<N, E>(f, A, B, kxn, kxn, kscale, j, reg);
             fft_line<N, E>(reg, j, tw, lds_line);
@@ -240,7 +240,7 @@ x_half_pass1(const c32* __restrict__ h0T, const float* __restrict__ omegaT, c32*
 #pragma unroll
         for (int e = 0; e < E; ++e) { const int y = j + e * T; A[e] = propagate_height(own[y], mir[N - 1 - y], om[y], time); B[e] = make_float2(A[e].x, -A[e].y); }
     } else {
-        half_load_AB<N, E>(h0T, omegaT, x, j, time, A, B);
+        half_load_AB<N, E, false>(h0T, 1.0f, omegaT, x, j, time, A, B);
     }
     const float kx1 = wave_index_q1(x, N) * kscale;
     const float kx2 = wave_index_q1(x2, N) * kscale;
