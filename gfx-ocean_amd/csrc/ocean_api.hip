@@ -51,7 +51,8 @@ struct OceanContext {
     InterLayout lay_h{0, 0, 0};   // three complex fields, columns 0..N/2-1     (half-spectrum path)
     float* nyq = nullptr;         // Nyquist column of the half-spectrum path: 3 x N real
     bool half = true;             // OCEAN_ALGO=c2c selects the three-complex-transform frame (A/B)
-    int P = 0;
+    int P = 0;                    // chunk width of the c2c path (fixed per N)
+    int Ph = 0;                   // chunk width = lines per pass-1 workgroup of the half-spectrum path (2 or 4)
     c32* tw = nullptr;          // e^{+2 pi i k/N}
     float4* out_own = nullptr;  // displacement map (src/render.rs:820-869), linear RGBA32F
     float4* out = nullptr;      // = out_own or the caller's buffer (ocean_bind_displacement)
@@ -103,21 +104,47 @@ template <int N> struct Launch {
         e = hipFuncSetAttribute((const void*)k_frame_pass1<N, G::E, G::P>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, G::frame_lds);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)k_frame_pass2<N, G::E, G::P>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, G::frame_lds);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)k_frame_pass2_thin<N, G::E, G::P, G::R2>,
+        if constexpr (G::P == 4) {      // the 1024-thread A/B variant owns whole 4 x 4 chunks
+            e = hipFuncSetAttribute((const void*)k_frame_pass2<N, G::E, G::P>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, G::frame_lds);
+            if (e != hipSuccess) return e;
+        }
+        e = hipFuncSetAttribute((const void*)k_frame_pass2_thin<N, G::E, CHUNK_W, G::R2>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, G::thin_lds);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)k_half_pass1<N, G::E, G::P, false>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, G::frame_lds);
+        e = prepare_half<0>();
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)k_half_pass1<N, G::E, G::P, true>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, G::frame_lds);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)k_half_pass2<N, G::E, G::P, G::R2>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, G::thin_lds);
+        if constexpr (N <= 4096) e = prepare_half<2>();
         return e;
+    }
+    template <int PSEL> static hipError_t prepare_half() {
+        using H = Geo<N, PSEL>;
+        hipError_t e;
+        e = hipFuncSetAttribute((const void*)k_half_pass1<N, H::E, H::P, false>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, H::frame_lds);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)k_half_pass1<N, H::E, H::P, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, H::frame_lds);
+        if (e != hipSuccess) return e;
+        return hipFuncSetAttribute((const void*)k_half_pass2<N, H::E, CHUNK_W, H::R2>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, H::thin_lds);
+    }
+    template <int PSEL> static void half_pass1(OceanContext* c, float time, float domain, hipStream_t s) {
+        using H = Geo<N, PSEL>;
+        const float descale = std::ldexp(1.0f, -c->scale_log2);
+        if (c->h0_f16)
+            hipLaunchKernelGGL((k_half_pass1<N, H::E, H::P, true>), dim3(H::half_grid1), dim3(H::frame_threads),
+                               H::frame_lds, s, (const void*)c->h0T, descale, c->omegaT, c->inter, c->nyq, c->tw,
+                               c->lay_h, time, domain);
+        else
+            hipLaunchKernelGGL((k_half_pass1<N, H::E, H::P, false>), dim3(H::half_grid1), dim3(H::frame_threads),
+                               H::frame_lds, s, (const void*)c->h0T, 1.0f, c->omegaT, c->inter, c->nyq, c->tw,
+                               c->lay_h, time, domain);
+    }
+    template <int PSEL> static void half_pass2(OceanContext* c, hipStream_t s) {
+        using H = Geo<N, PSEL>;
+        hipLaunchKernelGGL((k_half_pass2<N, H::E, CHUNK_W, H::R2>), dim3(H::thin_grid), dim3(H::thin_threads),
+                           H::thin_lds, s, c->inter, c->nyq, c->out, c->tw, c->lay_h);
     }
     static void rows(OceanContext* c, c32* data, hipStream_t s) {
         hipLaunchKernelGGL((k_fft_lines<N, G::E, G::ROW_LPW, false>), dim3(G::row_grid), dim3(G::row_threads),
@@ -129,15 +156,8 @@ template <int N> struct Launch {
     }
     static void pass1(OceanContext* c, float time, float domain, hipStream_t s) {
         if (c->half) {
-            const float descale = std::ldexp(1.0f, -c->scale_log2);
-            if (c->h0_f16)
-                hipLaunchKernelGGL((k_half_pass1<N, G::E, G::P, true>), dim3(G::half_grid1), dim3(G::frame_threads),
-                                   G::frame_lds, s, (const void*)c->h0T, descale, c->omegaT, c->inter, c->nyq, c->tw,
-                                   c->lay_h, time, domain);
-            else
-                hipLaunchKernelGGL((k_half_pass1<N, G::E, G::P, false>), dim3(G::half_grid1), dim3(G::frame_threads),
-                                   G::frame_lds, s, (const void*)c->h0T, 1.0f, c->omegaT, c->inter, c->nyq, c->tw,
-                                   c->lay_h, time, domain);
+            if constexpr (N <= 4096) { if (c->Ph == 2) { half_pass1<2>(c, time, domain, s); return; } }
+            half_pass1<0>(c, time, domain, s);
             return;
         }
         hipLaunchKernelGGL((k_frame_pass1<N, G::E, G::P>), dim3(G::frame_grid), dim3(G::frame_threads),
@@ -145,16 +165,19 @@ template <int N> struct Launch {
     }
     static void pass2(OceanContext* c, hipStream_t s) {
         if (c->half) {
-            hipLaunchKernelGGL((k_half_pass2<N, G::E, G::P, G::R2>), dim3(G::thin_grid), dim3(G::thin_threads),
-                               G::thin_lds, s, c->inter, c->nyq, c->out, c->tw, c->lay_h);
+            if constexpr (N <= 4096) { if (c->Ph == 2) { half_pass2<2>(c, s); return; } }
+            half_pass2<0>(c, s);
             return;
         }
-        if (c->pass2_thin)
-            hipLaunchKernelGGL((k_frame_pass2_thin<N, G::E, G::P, G::R2>), dim3(G::thin_grid), dim3(G::thin_threads),
-                               G::thin_lds, s, c->inter, c->out, c->tw, c->lay);
-        else
-            hipLaunchKernelGGL((k_frame_pass2<N, G::E, G::P>), dim3(G::frame_grid), dim3(G::frame_threads),
-                               G::frame_lds, s, c->inter, c->out, c->tw, c->lay);
+        if constexpr (G::P == 4) {
+            if (!c->pass2_thin) {
+                hipLaunchKernelGGL((k_frame_pass2<N, G::E, G::P>), dim3(G::frame_grid), dim3(G::frame_threads),
+                                   G::frame_lds, s, c->inter, c->out, c->tw, c->lay);
+                return;
+            }
+        }
+        hipLaunchKernelGGL((k_frame_pass2_thin<N, G::E, CHUNK_W, G::R2>), dim3(G::thin_grid), dim3(G::thin_threads),
+                           G::thin_lds, s, c->inter, c->out, c->tw, c->lay);
     }
 };
 
@@ -226,34 +249,26 @@ int32_t ocean_context_create(int32_t device, int32_t resolution, OceanContext** 
     const size_t n2 = (size_t)resolution * resolution;
     c->P = frame_p(resolution);
     {
-        // chunk (X, Y) of the intermediate at X*sx + Y*sy; +32 elements (256 B) of padding per slab so
-        // that the strided side of the hand-off does not revisit one HBM channel
-        const size_t groups = (size_t)(resolution / c->P), chunk = (size_t)c->P * c->P;
-        // P = 4 (128-byte chunks): pass-2-contiguous is 25 us/frame faster at N = 4096.
-        // P = 2 (N = 8192, 32-byte chunk rows): scattering 64-byte chunks from pass 1 is 3x slower
-        // than gathering them in pass 2, so that size keeps the pass-1-contiguous layout.
+        // Chunks are 4 x 4 complex (128 B); chunk (X, Y) at X*sx + Y*sy, +32 elements
+        // (256 B) of padding per slab so that the strided side of the hand-off does not revisit one channel.
+        // pass-2-contiguous (default): the chunks of one chunk row are adjacent; OCEAN_INTER_LAYOUT=p1
+        // selects pass-1-contiguous (A/B).
         const char* v = std::getenv("OCEAN_INTER_LAYOUT");
-        const bool p1 = v ? (std::strcmp(v, "p1") == 0) : (c->P < 4);
-        if (p1) {                                  // pass-1-contiguous
-            c->lay.sy = chunk;
-            c->lay.sx = groups * chunk + 32;
-            c->lay.fs = c->lay.sx * groups;
-        } else {                                   // pass-2-contiguous
-            c->lay.sx = chunk;
-            c->lay.sy = groups * chunk + 32;
-            c->lay.fs = c->lay.sy * groups;
-        }
-        // half-spectrum path: N/2 columns -> groups/2 chunk columns, same number of chunk rows
-        const size_t gx = groups / 2;
-        if (p1) {
-            c->lay_h.sy = chunk;
-            c->lay_h.sx = groups * chunk + 32;
-            c->lay_h.fs = c->lay_h.sx * gx;
-        } else {
-            c->lay_h.sx = chunk;
-            c->lay_h.sy = gx * chunk + 32;
-            c->lay_h.fs = c->lay_h.sy * groups;
-        }
+        const bool p1 = v && std::strcmp(v, "p1") == 0;
+        auto make = [&](size_t columns) {
+            InterLayout l{0, 0, 0};
+            const size_t gx = columns / CHUNK_W, gy = (size_t)resolution / CHUNK_R;
+            if (p1) { l.sy = 16; l.sx = gy * 16 + 32; l.fs = l.sx * gx; }
+            else { l.sx = 16; l.sy = gx * 16 + 32; l.fs = l.sy * gy; }
+            return l;
+        };
+        // lines per pass-1 workgroup of the half-spectrum path: measured best per size (run 14): two
+        // co-resident 2-line workgroups win where the intermediate is cache-resident (512, 2048) and
+        // are the only option at 8192; one 4-line workgroup wins at 4096 (whole-chunk non-temporal stores).
+        c->Ph = (resolution == 512 || resolution == 2048 || resolution > 4096) ? 2 : 4;
+        if (const char* pe = std::getenv("OCEAN_P")) { const int pv = std::atoi(pe); if (pv == 2 || (pv == 4 && resolution <= 4096)) c->Ph = pv; }
+        c->lay = make((size_t)resolution);
+        c->lay_h = make((size_t)resolution / 2);
         if (const char* a = std::getenv("OCEAN_ALGO")) c->half = (std::strcmp(a, "c2c") != 0);
     }
     auto bail = [&](hipError_t err, const char* what) {

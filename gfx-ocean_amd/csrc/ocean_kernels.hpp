@@ -192,6 +192,11 @@ k_fft_lines(c32* __restrict__ data, const c32* __restrict__ tw) {
 // opposite choice; both are selectable at context creation for A/B runs).
 // Field order in the intermediate: 0 = disp_x, 1 = height, 2 = disp_z (OCEAN_FIELD_*).
 struct InterLayout { size_t sx, sy, fs; };
+// A chunk is 4 columns x 4 rows of complex = 128 bytes.  A pass-1 workgroup owns P = 4 lines (whole
+// chunks, non-temporal stores) or P = 2 lines (the left or right 16 bytes of every chunk row; its
+// neighbour, dispatched in the adjacent slot of the same XCD, writes the other half and the XCD L2
+// merges them into full lines -- plain stores, so that the lines stay in L2 until complete).
+constexpr int CHUNK_W = 4, CHUNK_R = 4;
 
 // Map block -> x-group so that a group and its mirror (which read the same two h0T line sets)
 // run on the same XCD, 8 blocks apart.
@@ -214,6 +219,8 @@ k_frame_pass1(const c32* __restrict__ h0T, const float* __restrict__ omegaT, c32
               const c32* __restrict__ tw, InterLayout lay, float time, float domain_size) {
     constexpr int T = N / E;
     constexpr int H2 = P / 2;
+    constexpr int CR = CHUNK_R, CW = CHUNK_W;                    // row y of a chunk is y % CR, column x % CW
+    static_assert((2 * T) % CR == 0 && CW % P == 0, "chunk geometry");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     c32* lds = reinterpret_cast<c32*>(smem);
     const int tid = threadIdx.x;
@@ -259,13 +266,16 @@ k_frame_pass1(const c32* __restrict__ h0T, const float* __restrict__ omegaT, c32
         if (f > 0) __syncthreads();                                // previous field's LDS reads done
         fft_line_to_lds<N, E>(reg, jf, tw, lds_line);              // ends with data in LDS + barrier
         // row y -> chunk row Y = y / P, r = y % P; (2T) % P == 0 keeps r fixed per thread
-        c32* dst = inter + (size_t)f * lay.fs + (size_t)X * lay.sx + (size_t)(i / P) * lay.sy + (i % P) * P + 2 * h;
+        c32* dst = inter + (size_t)f * lay.fs + (size_t)((X * P) / CW) * lay.sx + (size_t)(i / CR) * lay.sy + (i % CR) * CW +
+                   ((X * P) % CW) + 2 * h;
 #pragma unroll
         for (int q = 0; q < E / 2; ++q) {
             const int y = i + q * (2 * T);
             const c32 v0 = l0[lds_pad(y)];
             const c32 v1 = l1[lds_pad(y)];
-            store_float4_nt(reinterpret_cast<float4*>(dst + (size_t)q * ((2 * T) / P) * lay.sy), make_float4(v0.x, v0.y, v1.x, v1.y));
+            float4* o = reinterpret_cast<float4*>(dst + (size_t)q * ((2 * T) / CR) * lay.sy);
+            if constexpr (P == CW) store_float4_nt(o, make_float4(v0.x, v0.y, v1.x, v1.y));
+            else *o = make_float4(v0.x, v0.y, v1.x, v1.y);        // half a chunk row: must meet its other half in L2
         }
     }
 }
@@ -277,6 +287,7 @@ __global__ void __launch_bounds__((N / E) * P)
 k_frame_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32* __restrict__ tw, InterLayout lay) {
     constexpr int T = N / E;
     static_assert(T % P == 0, "a thread's elements must keep the same column within a chunk");
+    static_assert(P == CHUNK_W && P == CHUNK_R, "the fat variant owns whole chunks");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     c32* lds = reinterpret_cast<c32*>(smem);
     const int tid = threadIdx.x;
@@ -313,7 +324,7 @@ k_frame_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32
 
 // Pass 2 ("thin", shipped): R2 rows per workgroup (R2 = 1 at N >= 4096: 256 threads, ~35 KiB LDS,
 // 4 workgroups per CU like k_fft_lines<ROW>), each thread gathering its own row straight from the
-// chunked intermediate (8*P1-byte row of a P1 x P1 chunk per P1 lanes).  The P1/R2 workgroups that
+// chunked intermediate (8*P1-byte row of a chunk per P1 lanes).  The (16/P1)/R2 workgroups that
 // share a chunk run on the same XCD in adjacent dispatch slots, so the other rows of a 128-byte
 // line are L2 hits rather than HBM re-reads (measured: +9% fetch over ideal, 270 -> 140 us vs an
 // unmapped grid).  The FFT is fully hidden behind the memory stream here (ablation: removing it
@@ -329,7 +340,9 @@ k_frame_pass2_thin(const c32* __restrict__ inter, float4* __restrict__ out, cons
     const int ll = (T >= 64) ? wave_uniform(tid / T) : (tid / T);
     const int j = tid % T;
     // block -> row block: sharers of a chunk = S consecutive slots of one XCD (b % 8)
-    constexpr int S = (P1 > R2) ? (P1 / R2) : 1;
+    constexpr int CR = CHUNK_R;
+    static_assert(P1 == CHUNK_W, "pass 2 reads 4-column chunks");
+    constexpr int S = (CR > R2) ? (CR / R2) : 1;
     int rb = blockIdx.x;
     if (S > 1 && (gridDim.x % (8 * S)) == 0) {
         const int xcd = rb & 7, slot = rb >> 3;
@@ -343,8 +356,8 @@ k_frame_pass2_thin(const c32* __restrict__ inter, float4* __restrict__ out, cons
     for (int f = 0; f < 3; ++f) {
         const int jf = opaque_lane(j);                             // no twiddle CSE across fields
         // element x = jf + e*T: chunk X = x / P1, c = x % P1 (T % P1 == 0); row y: Y = y / P1, r = y % P1
-        const c32* src = inter + (size_t)f * lay.fs + (size_t)(y / P1) * lay.sy + (size_t)(jf / P1) * lay.sx +
-                         (y % P1) * P1 + (jf % P1);
+        const c32* src = inter + (size_t)f * lay.fs + (size_t)(y / CR) * lay.sy + (size_t)(jf / P1) * lay.sx +
+                         (y % CR) * P1 + (jf % P1);
         c32 reg[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) reg[e] = src[(size_t)e * (T / P1) * lay.sx];
@@ -473,12 +486,16 @@ __device__ __forceinline__ void half_load_AB(const void* __restrict__ h0T_, floa
 // grid = 1 + (N/2)/P blocks: block 0 does the Nyquist column (three line FFTs, one per field, spread
 // over the P lines; a fraction of a regular block's work, dispatched first; measured cost 3 us at
 // N = 4096), blocks 1.. the column groups.
+// __launch_bounds__(.., 4 waves/SIMD when the workgroup is >= 512 threads): 1024 threads per CU, i.e. one
+// 4-line or two 2-line workgroups co-resident (128 VGPRs each).
 template <int N, int E, int P, bool H16>
-__global__ void __launch_bounds__((N / E) * P)
+__global__ void __launch_bounds__((N / E) * P, ((N / E) * P >= 512) ? 4 : 1)
 k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restrict__ omegaT, c32* __restrict__ inter,
              float* __restrict__ nyq, const c32* __restrict__ tw, InterLayout lay, float time, float domain_size) {
     constexpr int T = N / E;
     constexpr int H2 = P / 2;
+    constexpr int CR = CHUNK_R, CW = CHUNK_W;                    // row y of a chunk is y % CR, column x % CW
+    static_assert((2 * T) % CR == 0 && CW % P == 0, "chunk geometry");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     c32* lds = reinterpret_cast<c32*>(smem);
     const int tid = threadIdx.x;
@@ -529,13 +546,16 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
         half_spectrum<N, E>(f, A, B, kx1, kx2, kscale, jf, reg);
         if (f > 0) __syncthreads();
         fft_line_to_lds<N, E>(reg, jf, tw, lds_line);
-        c32* dst = inter + (size_t)f * lay.fs + (size_t)X * lay.sx + (size_t)(i / P) * lay.sy + (i % P) * P + 2 * h;
+        c32* dst = inter + (size_t)f * lay.fs + (size_t)((X * P) / CW) * lay.sx + (size_t)(i / CR) * lay.sy + (i % CR) * CW +
+                   ((X * P) % CW) + 2 * h;
 #pragma unroll
         for (int q = 0; q < E / 2; ++q) {
             const int y = i + q * (2 * T);
             const c32 v0 = l0[lds_pad(y)];
             const c32 v1 = l1[lds_pad(y)];
-            store_float4_nt(reinterpret_cast<float4*>(dst + (size_t)q * ((2 * T) / P) * lay.sy), make_float4(v0.x, v0.y, v1.x, v1.y));
+            float4* o = reinterpret_cast<float4*>(dst + (size_t)q * ((2 * T) / CR) * lay.sy);
+            if constexpr (P == CW) store_float4_nt(o, make_float4(v0.x, v0.y, v1.x, v1.y));
+            else *o = make_float4(v0.x, v0.y, v1.x, v1.y);        // half a chunk row: must meet its other half in L2
         }
     }
 }
@@ -553,7 +573,9 @@ k_half_pass2(const c32* __restrict__ inter, const float* __restrict__ nyq, float
     const int tid = threadIdx.x;
     const int ll = (T >= 64) ? wave_uniform(tid / T) : (tid / T);
     const int j = tid % T;
-    constexpr int S = (P1 > R2) ? (P1 / R2) : 1;
+    constexpr int CR = CHUNK_R;
+    static_assert(P1 == CHUNK_W, "pass 2 reads 4-column chunks");
+    constexpr int S = (CR > R2) ? (CR / R2) : 1;
     int rb = blockIdx.x;
     if (S > 1 && (gridDim.x % (8 * S)) == 0) {
         const int xcd = rb & 7, slot = rb >> 3;
@@ -567,7 +589,7 @@ k_half_pass2(const c32* __restrict__ inter, const float* __restrict__ nyq, float
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {                         // 0: height, 1: (disp_x, disp_z)
         const int jf = opaque_lane(j);
-        const size_t off = (size_t)(y / P1) * lay.sy + (size_t)(jf / P1) * lay.sx + (y % P1) * P1 + (jf % P1);
+        const size_t off = (size_t)(y / CR) * lay.sy + (size_t)(jf / P1) * lay.sx + (y % CR) * P1 + (jf % P1);
         c32 a[EH], b[EH];
         if (pass == 0) {
             const c32* src = inter + (size_t)1 * lay.fs + off;
@@ -628,12 +650,15 @@ k_half_pass2(const c32* __restrict__ inter, const float* __restrict__ nyq, float
 // Launch geometry per resolution -- the single source for the API (ocean_api.hip) and for the
 // host emulation harness (tests/hipemu).
 // ---------------------------------------------------------------------------------------------
-template <int N> struct Geo {
+template <int N, int PSEL = 0> struct Geo {
     static constexpr int E = 16;                                   // elements per thread
     static constexpr int T = N / E;                                // threads per line
     static constexpr int ROW_LPW = (256 / T) > 1 ? (256 / T) : 1;  // rows per workgroup (staged)
     static constexpr int COL_LPW = (N > 4096) ? 2 : ((256 / T) > 4 ? (256 / T) : 4);  // columns per workgroup (staged)
-    static constexpr int P = (N > 4096) ? 2 : 4;                   // lines per workgroup, fused passes
+    // lines per workgroup of fused pass 1.  4 lines = 1024 threads at N = 4096 (one workgroup per CU,
+    // whole 4 x 4 chunks); 2 lines = 512 threads and 70 KiB LDS, i.e. two co-resident workgroups whose
+    // load / compute / store phases overlap (each writes half of every chunk row).  PSEL = 0 = default.
+    static constexpr int P = PSEL ? PSEL : ((N > 4096) ? 2 : 4);
     static constexpr int row_threads = T * ROW_LPW;
     static constexpr int col_threads = T * COL_LPW;
     static constexpr int frame_threads = T * P;

@@ -32,7 +32,7 @@ def lib():
         _LIB.emu_frame_pass1.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_size_t] * 3 + [ctypes.c_float] * 2
         _LIB.emu_frame_pass2.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_size_t] * 3
         _LIB.emu_frame_pass2_thin.argtypes = _LIB.emu_frame_pass2.argtypes
-        _LIB.emu_frame_half.argtypes = ([ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_float] + [ctypes.c_void_p] * 5 +
+        _LIB.emu_frame_half.argtypes = ([ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_float] + [ctypes.c_void_p] * 5 +
                                         [ctypes.c_size_t] * 3 + [ctypes.c_float] * 2)
         _LIB.emu_fft_lines.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         _LIB.emu_propagate.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_float] * 2
@@ -74,23 +74,29 @@ def correct(h, dx, dz):
     return out
 
 
-def inter_layout(n, P, layout="p2", pad=32):
-    """(sx, sy, fs) in elements -- mirrors ocean_context_create."""
-    groups, chunk = n // P, P * P
+def _layout(columns, n, P, layout, pad):
+    """(sx, sy, fs) in elements -- mirrors ocean_context_create: chunks are 4 columns x 4 rows whatever
+    the number of lines P a pass-1 workgroup owns."""
+    gx, gy = columns // 4, n // 4
     if layout == "p1":
-        sy, sx = chunk, groups * chunk + pad
-        return sx, sy, sx * groups
-    sx, sy = chunk, groups * chunk + pad
-    return sx, sy, sy * groups
+        sy, sx = 16, gy * 16 + pad
+        return sx, sy, sx * gx
+    sx, sy = 16, gx * 16 + pad
+    return sx, sy, sy * gy
 
 
-def unpack_inter(inter, n, P, lay, f):
-    """Intermediate field f -> natural [y, x] array (NaN where never written)."""
+def inter_layout(n, P, layout="p2", pad=32):
+    return _layout(n, n, P, layout, pad)
+
+
+def unpack_inter(inter, n, P, lay, f, columns=None):
+    """Intermediate field f -> natural [y, x] array (columns < n for the half-spectrum path)."""
     sx, sy, fs = lay
-    X, Y, r, c = np.meshgrid(np.arange(n // P), np.arange(n // P), np.arange(P), np.arange(P), indexing="ij")
-    idx = f * fs + X * sx + Y * sy + r * P + c
-    out = np.empty((n, n), np.complex64)
-    out[(Y * P + r).ravel(), (X * P + c).ravel()] = inter[idx.ravel()]
+    columns = columns or n
+    X, Y, r, c = np.meshgrid(np.arange(columns // 4), np.arange(n // 4), np.arange(4), np.arange(4), indexing="ij")
+    idx = f * fs + X * sx + Y * sy + r * 4 + c
+    out = np.empty((n, columns), np.complex64)
+    out[(Y * 4 + r).ravel(), (X * 4 + c).ravel()] = inter[idx.ravel()]
     return out
 
 
@@ -113,12 +119,7 @@ def frame(h0, omega, time, L=1000.0, return_inter=False, thin=True, layout="p2")
 
 def half_layout(n, P, layout="p2", pad=32):
     """(sx, sy, fs) of the half-spectrum intermediate (N/2 columns) -- mirrors ocean_context_create."""
-    groups, gx, chunk = n // P, n // P // 2, P * P
-    if layout == "p1":
-        sy, sx = chunk, groups * chunk + pad
-        return sx, sy, sx * gx
-    sx, sy = chunk, gx * chunk + pad
-    return sx, sy, sy * groups
+    return _layout(n // 2, n, P, layout, pad)
 
 
 def quantize_f16(h0):
@@ -133,9 +134,9 @@ def quantize_f16(h0):
     return (bits[..., 0] | (bits[..., 1] << 16)).astype(np.uint32), deq, s
 
 
-def frame_half(h0, omega, time, L=1000.0, layout="p2", return_inter=False, spectrum_fp16=False):
+def frame_half(h0, omega, time, L=1000.0, layout="p2", return_inter=False, spectrum_fp16=False, P=None):
     n = h0.shape[0]
-    P = lib().emu_frame_p(n)
+    P = P or lib().emu_frame_p(n)
     descale = 1.0
     if spectrum_fp16:
         packed, _, s = quantize_f16(h0)
@@ -149,7 +150,7 @@ def frame_half(h0, omega, time, L=1000.0, layout="p2", return_inter=False, spect
     nyq = np.full(3 * n, np.nan, np.float32)
     out = np.full((n, n, 4), np.nan, np.float32)
     tw = twiddles(n)
-    assert lib().emu_frame_half(n, _p(h0T), int(spectrum_fp16), descale, _p(omT), _p(inter), _p(nyq), _p(out), _p(tw),
+    assert lib().emu_frame_half(n, int(P), _p(h0T), int(spectrum_fp16), descale, _p(omT), _p(inter), _p(nyq), _p(out), _p(tw),
                                 sx, sy, fs, time, L) == 0
     if return_inter:
         return out, inter, nyq, (P, (sx, sy, fs))

@@ -83,11 +83,13 @@ def test_emu_normals(ref_inputs_256, channel):
     assert np.allclose(np.linalg.norm(got[..., :3], axis=-1), 1.0, atol=1e-6) and np.all(got[..., 3] == 0)
 
 
+@pytest.mark.parametrize("P", [4, 2])
 @pytest.mark.parametrize("t", [0.0, 3.0])
-def test_emu_half_spectrum_frame(ref_inputs_256, t):
-    """The shipped fused path (real-output algorithm: half the column FFTs, two row FFTs)."""
+def test_emu_half_spectrum_frame(ref_inputs_256, t, P):
+    """The shipped fused path (real-output algorithm: half the column FFTs, two row FFTs), with
+    4 or 2 lines per pass-1 workgroup (whole chunks vs half chunk rows)."""
     h0, om = ref_inputs_256
-    out = emu.frame_half(h0, om, t)
+    out = emu.frame_half(h0, om, t, P=P)
     assert not np.isnan(out).any()
     assert_parity(out[..., :3], oc.frame_f64(h0, om, t)[..., :3], 5e-6, "emu half-spectrum frame")
     assert np.all(out[..., 3] == 0.0)
@@ -108,3 +110,20 @@ def test_emu_fp16_spectrum_config5(ref_inputs_256):
     assert_parity(out[..., :3], oc.frame_f64(deq, om, 1.0)[..., :3], 5e-6, "fp16 spectrum vs oracle on quantised inputs")
     nmax, rl2 = oc.parity_errors(out[..., :3], oc.frame_f64(h0, om, 1.0)[..., :3])
     assert 1e-5 < rl2.max() < 2e-3          # fp16 rounding of the inputs is visible, as SURVEY 7 predicts
+
+
+@pytest.mark.parametrize("P", [4, 2])
+def test_emu_half_intermediate_layout(ref_inputs_256, P):
+    """k_half_pass1 writes columns kx < N/2 of FFT_y(2 S(F)) as 4 x 4 chunks (128 bytes), whole or in
+    halves, and the Nyquist column as a real vector."""
+    h0, om = ref_inputs_256
+    n = 256
+    out, inter, nyq, (P_, lay) = emu.frame_half(h0, om, 2.0, return_inter=True, P=P)
+    H, DX, DZ = oc.propagate_f64(h0, om, 2.0)
+    for f, F in ((0, DX), (1, H), (2, DZ)):
+        Fm = np.conj(np.roll(np.roll(F[::-1, ::-1], 1, axis=0), 1, axis=1))
+        G = np.fft.ifft(F + Fm, axis=0) * n                       # 2 S(F), transformed along y
+        got = emu.unpack_inter(inter, n, P, lay, f, columns=n // 2)
+        assert_parity(got, G[:, :n // 2], 5e-6, f"half intermediate field {f}")
+        assert_parity(nyq[f * n:(f + 1) * n][:, None], G[:, n // 2].real[:, None], 5e-6, f"nyquist field {f}")
+    assert np.isnan(inter.real).sum() >= 3 * (lay[2] - n * n // 2)
