@@ -37,6 +37,7 @@ struct OceanContext {
     int device = 0;
     int n = 0;
     hipStream_t stream = nullptr;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;   // reused by ocean_time_frames (event creation is not free)
     // natural-layout buffers of the staged path (src/render.rs:608-670)
     c32* h0 = nullptr;          // initial_spec
     float* omega = nullptr;     // omega_buffer
@@ -222,6 +223,8 @@ void free_all(OceanContext* c) {
     auto f = [](void* p) { if (p) (void)hipFree(p); };
     f(c->h0); f(c->omega); f(c->field[0]); f(c->field[1]); f(c->field[2]);
     f(c->h0T); f(c->omegaT); f(c->inter); f(c->nyq); f(c->tw); f(c->out_own); f(c->normals);
+    if (c->ev_a) (void)hipEventDestroy(c->ev_a);
+    if (c->ev_b) (void)hipEventDestroy(c->ev_b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
 }
 
@@ -279,6 +282,8 @@ int32_t ocean_context_create(int32_t device, int32_t resolution, OceanContext** 
     };
 #define CTX_TRY(expr) do { hipError_t e2_ = (expr); if (e2_ != hipSuccess) return bail(e2_, #expr); } while (0)
     CTX_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CTX_TRY(hipEventCreate(&c->ev_a));
+    CTX_TRY(hipEventCreate(&c->ev_b));
     CTX_TRY(hipMalloc((void**)&c->h0, n2 * sizeof(c32)));
     CTX_TRY(hipMalloc((void**)&c->omega, n2 * sizeof(float)));
     for (int f = 0; f < 3; ++f) CTX_TRY(hipMalloc((void**)&c->field[f], n2 * sizeof(c32)));
@@ -562,16 +567,12 @@ int32_t ocean_time_frames(OceanContext* ctx, int32_t frames, float t0, float dt,
     if (frames <= 0 || !out_ms) return fail(ctx, OCEAN_E_INVALID_ARG, "frames must be > 0 and out_ms non-NULL");
     if (!ctx->uploaded) return fail(ctx, OCEAN_E_STATE, "ocean_upload_spectrum has not been called");
     DeviceGuard guard(ctx->device);
-    hipEvent_t a, b;
-    HIP_TRY(ctx, hipEventCreate(&a));
-    HIP_TRY(ctx, hipEventCreate(&b));
+    hipEvent_t a = ctx->ev_a, b = ctx->ev_b;
     HIP_TRY(ctx, hipEventRecord(a, ctx->stream));
     for (int i = 0; i < frames; ++i) launch_frame(ctx, t0 + dt * (float)i, ctx->default_domain, ctx->stream);
     HIP_TRY(ctx, hipEventRecord(b, ctx->stream));
     HIP_TRY(ctx, hipEventSynchronize(b));
     HIP_TRY(ctx, hipEventElapsedTime(out_ms, a, b));
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
     return check_launch(ctx, "ocean_time_frames");
 }
 
