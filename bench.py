@@ -93,11 +93,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    # OCEAN_BENCH_FORCE_DIST=1 exercises the torch.distributed / RCCL plumbing at world size 1 (1-GPU boxes)
+    if world > 1 or os.environ.get("OCEAN_BENCH_FORCE_DIST") == "1":
         # torch first: libocean_hip.so then binds to the HIP runtime torch loaded (same soname)
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     n_gpus = world if world > 1 else 1
