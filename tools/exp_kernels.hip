@@ -194,6 +194,40 @@ x_pass2_fat(const c32* __restrict__ inter, float4* __restrict__ out, const c32* 
     }
 }
 
+
+template <int N, int E, int SKIP>
+__device__ __forceinline__ void x_load_AB(const c32* __restrict__ h0T, const float* __restrict__ omegaT,
+                                          uint32_t x, int j, float time, c32 (&A)[E], c32 (&B)[E]) {
+    constexpr int T = N / E;
+    const uint32_t x2 = (N - x) & (N - 1);
+    const uint32_t xm = (x - 1u) & (N - 1);
+    const c32* own = h0T + (size_t)x * N;
+    const c32* mir = h0T + (size_t)(N - 1 - x) * N;
+    const c32* own2 = h0T + (size_t)x2 * N;
+    const c32* mir2 = h0T + (size_t)xm * N;
+    const float* om = omegaT + (size_t)x * N;
+    const float* om2 = omegaT + (size_t)x2 * N;
+    constexpr int PER = E / 4;
+    int jj = j;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (e > 0 && (e % PER) == 0) jj = opaque_after(j, A[e - 1].x + B[e - 1].y);
+        const c32 a = (own + e * T)[jj];
+        const c32 m = (mir + (N - (e + 1) * T))[T - 1 - jj];
+        const float w = (om + e * T)[jj];
+        c32 a2, m2; float w2;
+        if (SKIP & 1) { a2 = m; m2 = a; }
+        else if (e == 0) { a2 = own2[(N - jj) & (N - 1)]; m2 = mir2[(jj - 1) & (N - 1)]; }
+        else { a2 = (own2 + (N - (e + 1) * T))[T - jj]; m2 = (mir2 + (e * T - 1))[jj]; }
+        if (SKIP & 2) w2 = w;
+        else if (e == 0) w2 = om2[(N - jj) & (N - 1)];
+        else w2 = (om2 + (N - (e + 1) * T))[T - jj];
+        A[e] = propagate_height(a, m, w, time);
+        const c32 h2 = propagate_height(a2, m2, w2, time);
+        B[e] = make_float2(h2.x, -h2.y);
+    }
+}
+
 // half-spectrum pass 1 ablations: MODE bit0: no Nyquist block (grid = groups); bit1: no FFT; bit2: B = conj(A) (no second propagate/loads)
 template <int N, int E, int P, int MODE>
 __global__ void __launch_bounds__((N / E) * P)
@@ -240,7 +274,9 @@ x_half_pass1(const c32* __restrict__ h0T, const float* __restrict__ omegaT, c32*
 #pragma unroll
         for (int e = 0; e < E; ++e) { const int y = j + e * T; A[e] = propagate_height(own[y], mir[N - 1 - y], om[y], time); B[e] = make_float2(A[e].x, -A[e].y); }
     } else {
-        half_load_AB<N, E, false>(h0T, 1.0f, omegaT, x, j, time, A, B);
+        if (MODE & 512) x_load_AB<N, E, 1>(h0T, omegaT, x, j, time, A, B);
+        else if (MODE & 1024) x_load_AB<N, E, 3>(h0T, omegaT, x, j, time, A, B);
+        else half_load_AB<N, E, false>(h0T, 1.0f, omegaT, x, j, time, A, B);
     }
     const float kx1 = wave_index_q1(x, N) * kscale;
     const float kx2 = wave_index_q1(x2, N) * kscale;
@@ -332,14 +368,14 @@ int main() {
         const int grid = ((MODE) & 1) ? (N / 2) / G::P : 1 + (N / 2) / G::P; \
         float ms = time_ms([&] { hipLaunchKernelGGL(k, dim3(grid), dim3(G::frame_threads), G::frame_lds, 0, h0T, omT, inter, nyq, tw, lh, 1.5f, 1000.0f, (unsigned long long*)nullptr); }); \
         printf("{\"kernel\":\"half_pass1\",\"mode\":%d,\"ms\":%.4f}\n", MODE, ms); }
-        PH(0) PH(1) PH(3) PH(5) PH(7)
+        PH(1) PH(1 + 512) PH(1 + 1024) PH(1) PH(1 + 512) PH(1 + 1024)
         {
             const size_t sx = 16, sy = (size_t)(N / G::P) * 16 + 32;
 #define P1H(MODE, GRID) { auto k = x_pass1<N, G::E, G::P, MODE>; \
             CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G::frame_lds)); \
             float ms = time_ms([&] { hipLaunchKernelGGL(k, dim3(GRID), dim3(G::frame_threads), G::frame_lds, 0, h0T, omT, inter, tw, sx, sy, fs, 1.5f, 1000.0f); }); \
             printf("{\"kernel\":\"c2c_pass1\",\"grid\":%d,\"mode\":%d,\"ms\":%.4f}\n", GRID, MODE, ms); }
-            P1H(0, 1024) P1H(16, 1024) P1H(32, 1024) P1H(48, 1024) P1H(3, 1024) P1H(19, 1024) P1H(35, 1024) P1H(51, 1024) P1H(51, 512) P1H(51, 256)
+            P1H(0, 1024)
         }
         if (0) {   // timeline of one launch
             unsigned long long* st; const int grid = (N / 2) / G::P;
