@@ -65,7 +65,7 @@ def tile_seed(n, rank):
 def cpu_baseline(n, h0, omega, budget_s=10.0, max_frames=12):
     """The C restatement of the reference shaders (oracle/, kind "port") timed on this box's host
     cores on a bounded sample of the same workload: whole frames of the same N until ~budget_s.
-    The thread count is the best of {all hardware threads, half, 64, 32} on one probe frame each
+    The thread count is the best of {all hardware threads, half, 64, 32, 16} on one probe frame each
     (the strided column pass does not scale to 256 SMT threads on a 2-socket box)."""
     from oracle import c_oracle as cc          # cpu_baseline leg: the oracle as the measured CPU path
     cc.build()
@@ -73,7 +73,7 @@ def cpu_baseline(n, h0, omega, budget_s=10.0, max_frames=12):
     hw = cc.max_threads()
     runner.frame(0.0)                          # first-touch of the scratch buffers, not timed
     probes = {}
-    for th in sorted({hw, max(1, hw // 2), min(hw, 64), min(hw, 32)}, reverse=True):
+    for th in sorted({hw, max(1, hw // 2), min(hw, 64), min(hw, 32), min(hw, 16)}, reverse=True):
         cc.set_threads(th)
         t0 = time.perf_counter()
         runner.frame(0.5)
@@ -104,6 +104,13 @@ def main():
     ap.add_argument("--profile-frames", type=int, default=20, help="frames averaged for the per-kernel durations")
     args = ap.parse_args()
 
+    # The JSON line must be the only thing on stdout.  Native libraries (RCCL's banner and WARN lines,
+    # written from its own threads) print to fd 1, so keep a private handle on the real stdout and
+    # point fd 1 at stderr for the rest of the process.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,6 +120,7 @@ def main():
         # torch first: libocean_hip.so then binds to the HIP runtime torch loaded (same soname)
         import torch
         import torch.distributed as dist
+        os.environ["NCCL_DEBUG"] = os.environ.get("OCEAN_NCCL_DEBUG", "WARN")   # keep RCCL's banner off stdout
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("RANK", str(rank))
@@ -223,7 +231,7 @@ def main():
             line["gather"] = gather
         if n_gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, h0, omega)
-        print(json.dumps(line))
+        print(json.dumps(line), file=json_out, flush=True)
     dev.destroy()
     if dist is not None:
         dist.destroy_process_group()
