@@ -48,9 +48,9 @@ def library_path() -> str:
     return _SO
 
 
-def hipcc_command(out: str = _SO):
+def hipcc_command(out: str = _SO, extra=()):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    return [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-I", _CSRC,
+    return [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-I", _CSRC, *extra,
             "-shared", "-fPIC", os.path.join(_CSRC, "ocean_api.hip"), "-o", out]
 
 
@@ -69,10 +69,11 @@ def load_library():
     global _LIB
     if _LIB is not None:
         return _LIB
-    if not os.path.exists(_SO):
-        raise OceanError(-3, f"{_SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+    so = os.environ.get("OCEAN_HIP_LIB", _SO)      # A/B builds of the same ABI (tools/ab_variants.sh)
+    if not os.path.exists(so):
+        raise OceanError(-3, f"{so} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                              "(the HIP extension is the only implementation; there is no CPU fallback)")
-    L = ctypes.CDLL(_SO)
+    L = ctypes.CDLL(so)
     vp, i32, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float
     pp = ctypes.POINTER(vp)
     sig = {

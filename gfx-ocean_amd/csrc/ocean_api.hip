@@ -50,7 +50,7 @@ struct OceanContext {
     c32* inter = nullptr;
     InterLayout lay{0, 0, 0};     // three complex fields, all N columns        (OCEAN_ALGO=c2c)
     InterLayout lay_h{0, 0, 0};   // three complex fields, columns 0..N/2-1     (half-spectrum path)
-    float* nyq = nullptr;         // Nyquist column of the half-spectrum path: 3 x N real
+    c32* nyq = nullptr;           // scratch of the half-spectrum path: the Nyquist column's 3 spectra, 3 x N complex
     bool half = true;             // OCEAN_ALGO=c2c selects the three-complex-transform frame (A/B)
     int P = 0;                    // chunk width of the c2c path (fixed per N)
     int Ph = 0;                   // chunk width = lines per pass-1 workgroup of the half-spectrum path (2 or 4)
@@ -145,7 +145,7 @@ template <int N> struct Launch {
     template <int PSEL> static void half_pass2(OceanContext* c, hipStream_t s) {
         using H = Geo<N, PSEL>;
         hipLaunchKernelGGL((k_half_pass2<N, H::E, CHUNK_W, H::R2>), dim3(H::thin_grid), dim3(H::thin_threads),
-                           H::thin_lds, s, c->inter, c->nyq, c->out, c->tw, c->lay_h);
+                           H::thin_lds, s, c->inter, c->out, c->tw, c->lay_h);
     }
     static void rows(OceanContext* c, c32* data, hipStream_t s) {
         hipLaunchKernelGGL((k_fft_lines<N, G::E, G::ROW_LPW, false>), dim3(G::row_grid), dim3(G::row_threads),
@@ -290,7 +290,7 @@ int32_t ocean_context_create(int32_t device, int32_t resolution, OceanContext** 
     CTX_TRY(hipMalloc((void**)&c->h0T, n2 * sizeof(c32)));
     CTX_TRY(hipMalloc((void**)&c->omegaT, n2 * sizeof(float)));
     CTX_TRY(hipMalloc((void**)&c->inter, 3 * c->lay.fs * sizeof(c32)));
-    CTX_TRY(hipMalloc((void**)&c->nyq, 3 * (size_t)resolution * sizeof(float)));
+    CTX_TRY(hipMalloc((void**)&c->nyq, 3 * (size_t)resolution * sizeof(c32)));
     CTX_TRY(hipMalloc((void**)&c->out_own, n2 * sizeof(float4)));
     CTX_TRY(hipMalloc((void**)&c->tw, (size_t)resolution * sizeof(c32)));
     c->out = c->out_own;

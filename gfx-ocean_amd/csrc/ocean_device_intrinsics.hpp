@@ -33,6 +33,68 @@ __device__ __forceinline__ void store_float4_nt(float4* p, float4 v) {
     __builtin_nontemporal_store(t, reinterpret_cast<ocean_v4f*>(p));
 }
 
+// Global-memory hand-over inside ONE workgroup: every thread's earlier global stores become visible to its
+// other waves after the call.  Workgroup scope is enough and cheap (a wait for the stores; the waves of a
+// workgroup share the CU's write-through L1); a device-scope __threadfence() here compiles to
+// buffer_wbl2 + buffer_inv, i.e. writes back and invalidates the whole L2 of the XCD (measured: +20 us on
+// pass 1 at N = 4096).
+__device__ __forceinline__ void workgroup_publish() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// Timeline probes for tools/timeline.hip (compiled in only with -DOCEAN_TIMELINE; the product build has none):
+// lane 0 of a workgroup records the 100 MHz wall clock at a few points, slot 15 the hardware id.
+#ifdef OCEAN_TIMELINE
+__device__ unsigned long long* ocean_tl;
+// scalar-only probe (no lane branch, no VGPRs: a lane-0 branch moved the register allocation of pass 1 from 9 to
+// 112 spills); every wave of the workgroup writes the slot, the last one wins
+__device__ __forceinline__ unsigned long long* ocean_tl_uniform(unsigned long long* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (unsigned long long*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ void ocean_tl_probe(unsigned long long* slot) {
+    unsigned long long t;
+    slot = ocean_tl_uniform(slot);
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_store_dwordx2 %0, %1, 0x0\n\ts_dcache_wb" : "=&s"(t) : "s"(slot) : "memory");
+}
+__device__ __forceinline__ void ocean_tl_hwid(unsigned long long* slot) {
+    unsigned lo, hi;
+    slot = ocean_tl_uniform(slot);
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(lo), "=s"(hi));
+    const unsigned long long id = ((unsigned long long)hi << 32) | lo;
+    asm volatile("s_store_dwordx2 %0, %1, 0x0\n\ts_dcache_wb" : : "s"(id), "s"(slot) : "memory");
+}
+#define OCEAN_TL(k)                                                            \
+    do {                                                                       \
+        ocean_tl_probe(ocean_tl + (size_t)blockIdx.x * 16 + (k));              \
+        if ((k) == 0) ocean_tl_hwid(ocean_tl + (size_t)blockIdx.x * 16 + 15);  \
+    } while (0)
+#else
+#if defined(OCEAN_FENCE_KIND) && OCEAN_FENCE_KIND == 1
+#define OCEAN_TL(k) __builtin_amdgcn_sched_barrier(0)
+#elif defined(OCEAN_FENCE_KIND) && OCEAN_FENCE_KIND == 2
+#define OCEAN_TL(k) asm volatile("" ::: "memory")
+#elif defined(OCEAN_FENCE_KIND) && OCEAN_FENCE_KIND == 3
+#define OCEAN_TL(k) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 0" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#elif defined(OCEAN_FENCE_KIND) && OCEAN_FENCE_KIND == 4
+#define OCEAN_TL(k) asm volatile("s_nop 0" ::: "memory")
+#elif defined(OCEAN_FENCE_KIND) && OCEAN_FENCE_KIND == 6
+#define OCEAN_TL(k) do { int z_ = __builtin_amdgcn_readfirstlane((int)threadIdx.x + (k)); asm volatile("" :: "s"(z_) : "memory"); } while (0)
+#elif defined(OCEAN_FENCE_KIND) && OCEAN_FENCE_KIND == 7
+#define OCEAN_TL(k) do { __builtin_amdgcn_sched_barrier(0); int z_ = __builtin_amdgcn_readfirstlane((int)threadIdx.x + (k)); asm volatile("" :: "s"(z_) : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#elif defined(OCEAN_FENCE_KIND) && OCEAN_FENCE_KIND == 8
+__device__ unsigned long long* ocean_tl;
+#define OCEAN_TL(k) do { unsigned long long v_ = (unsigned long long)(ocean_tl + (size_t)blockIdx.x * 16 + (k)); unsigned lo_ = __builtin_amdgcn_readfirstlane((unsigned)v_), hi_ = __builtin_amdgcn_readfirstlane((unsigned)(v_ >> 32)); asm volatile("" :: "s"(lo_), "s"(hi_) : "memory"); } while (0)
+#elif defined(OCEAN_FENCE_KIND) && OCEAN_FENCE_KIND == 5
+#define OCEAN_TL(k) do { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(t_) :: "memory"); } while (0)
+#else
+#define OCEAN_TL(k)
+#endif
+#endif
+
 // sin / cos of 2*pi*x for x in [-0.5, 0.5] revolutions: the gfx950 transcendental unit
 // (v_sin_f32 / v_cos_f32 take their argument in revolutions).  Measured max abs error on that
 // interval: 1.25e-7 (tools/sincos_acc.hip; ocml's sincospif: 5.2e-8) at 2 instructions instead of ~45.

@@ -398,27 +398,26 @@ k_frame_pass2_thin(const c32* __restrict__ inter, float4* __restrict__ out, cons
 // B = conj(H2) and k1 = k_norm(x, y), k2 = k_norm(x2, y2)   (all quirks Q1/Q2 kept):
 //     2 S(H)  = A + B,     2 S(Dx) = i (k2.x B - k1.x A),     2 S(Dz) = i (k2.y B - k1.y A).
 
-// One field's symmetrised column spectrum (times 2) for E positions of a thread.
+// One field's symmetrised column spectrum (times 2) at row y of a column pair (kx1 = k(x), kx2 = k((N-x)%N)).
+template <int N>
+__device__ __forceinline__ c32 half_spectrum_at(int f, c32 A, c32 B, float kx1, float kx2, float kscale, int y) {
+    if (f == 1) return make_float2(A.x + B.x, A.y + B.y);
+    const int y2 = (N - y) & (N - 1);
+    float knx1, kny1, knx2, kny2;
+    k_normalised_fast(kx1, wave_index_q1((uint32_t)y, N) * kscale, knx1, kny1);
+    k_normalised_fast(kx2, wave_index_q1((uint32_t)y2, N) * kscale, knx2, kny2);
+    const float k1 = (f == 0) ? knx1 : kny1;
+    const float k2 = (f == 0) ? knx2 : kny2;
+    const c32 v = make_float2(k2 * B.x - k1 * A.x, k2 * B.y - k1 * A.y);
+    return make_float2(-v.y, v.x);                                 // i * v
+}
+// ... for the E positions of a thread.
 template <int N, int E>
 __device__ __forceinline__ void half_spectrum(int f, const c32 (&A)[E], const c32 (&B)[E], float kx1, float kx2,
                                               float kscale, int j, c32 (&reg)[E]) {
     constexpr int T = N / E;
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        if (f == 1) {
-            reg[e] = make_float2(A[e].x + B[e].x, A[e].y + B[e].y);
-        } else {
-            const int y = j + e * T;
-            const int y2 = (N - y) & (N - 1);
-            float knx1, kny1, knx2, kny2;
-            k_normalised_fast(kx1, wave_index_q1((uint32_t)y, N) * kscale, knx1, kny1);
-            k_normalised_fast(kx2, wave_index_q1((uint32_t)y2, N) * kscale, knx2, kny2);
-            const float k1 = (f == 0) ? knx1 : kny1;
-            const float k2 = (f == 0) ? knx2 : kny2;
-            const c32 v = make_float2(k2 * B[e].x - k1 * A[e].x, k2 * B[e].y - k1 * A[e].y);
-            reg[e] = make_float2(-v.y, v.x);                       // i * v
-        }
-    }
+    for (int e = 0; e < E; ++e) reg[e] = half_spectrum_at<N>(f, A[e], B[e], kx1, kx2, kscale, j + e * T);
 }
 
 // The initial spectrum in HBM: fp32 complex (8 B/texel), or -- BASELINE config 5 -- two fp16 with
@@ -452,12 +451,23 @@ __device__ __forceinline__ void half_load_AB(const void* __restrict__ h0T_, floa
     // inputs have been consumed (otherwise 16 x 10 input VGPRs are live at once next to A and B and
     // the kernel spills at the 128-VGPR budget of a 1024-thread workgroup; a spill reload in the
     // load phase also drains every outstanding global load, vmcnt being in-order)
-    constexpr int LOAD_BATCHES = 4;
+#ifndef OCEAN_LOAD_BATCHES
+#define OCEAN_LOAD_BATCHES 4
+#endif
+#ifndef OCEAN_LOAD_LOOKAHEAD
+#define OCEAN_LOAD_LOOKAHEAD 1
+#endif
+    constexpr int LOAD_BATCHES = OCEAN_LOAD_BATCHES;
+    constexpr int LOOKAHEAD = OCEAN_LOAD_LOOKAHEAD;               // batches in flight ahead of the one being consumed
     constexpr int PER = E / LOAD_BATCHES;
     int jj = j;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        if (e > 0 && (e % PER) == 0) jj = opaque_after(j, A[e - 1].x + B[e - 1].y);
+        if ((e % PER) == 0 && e / PER >= LOOKAHEAD) {
+            constexpr int dummy = 0; (void)dummy;
+            const int d = (e / PER - LOOKAHEAD + 1) * PER - 1;     // last element of the batch LOOKAHEAD back
+            jj = opaque_after(j, A[d].x + B[d].y);
+        }
         // y = jj + e*T.  Every address is written as (uniform base + e-dependent constant)[small lane index]
         // so that the six streams share three lane offsets and the bases stay in SGPRs; only e == 0 can
         // hit the wrap of y2 = (N - y) % N and ym = (y - 1) % N (at jj == 0).
@@ -483,15 +493,36 @@ __device__ __forceinline__ void half_load_AB(const void* __restrict__ h0T_, floa
     }
 }
 
-// grid = 1 + (N/2)/P blocks: block 0 does the Nyquist column (three line FFTs, one per field, spread
-// over the P lines; a fraction of a regular block's work, dispatched first; measured cost 3 us at
-// N = 4096), blocks 1.. the column groups.
+// The same for ONE position (the Nyquist column is done element-wise by a whole workgroup).
+template <int N, bool H16>
+__device__ __forceinline__ void half_AB_at(const void* __restrict__ h0T_, float descale, const float* __restrict__ omegaT,
+                                           uint32_t x, uint32_t y, float time, c32& A, c32& B) {
+    typedef typename Spec<H16>::elem S;
+    const S* h0T = reinterpret_cast<const S*>(h0T_);
+    const uint32_t x2 = (N - x) & (N - 1), y2 = (N - y) & (N - 1);
+    const uint32_t xm = (x - 1u) & (N - 1), ym = (y - 1u) & (N - 1);
+    A = propagate_height(Spec<H16>::load(h0T + (size_t)x * N + y, descale),
+                         Spec<H16>::load(h0T + (size_t)(N - 1 - x) * N + (N - 1 - y), descale), omegaT[(size_t)x * N + y], time);
+    const c32 h2 = propagate_height(Spec<H16>::load(h0T + (size_t)x2 * N + y2, descale),
+                                    Spec<H16>::load(h0T + (size_t)xm * N + ym, descale), omegaT[(size_t)x2 * N + y2], time);
+    B = make_float2(h2.x, -h2.y);
+}
+
+// grid = (N/2)/P blocks of P columns.  The half spectrum has N/2 + 1 distinct columns; the odd one out, the
+// self-paired Nyquist column kx = N/2, is like column 0 Hermitian along y, so both have REAL column transforms
+// and share one complex FFT: line 0 of the workgroup that owns column 0 transforms S0 + i Sn and the
+// intermediate's column 0 holds (column 0, Nyquist column) as (re, im).  That workgroup first evaluates the
+// Nyquist column's three symmetrised spectra element-wise with all its threads (3 N complex in `nyq_spec`,
+// an L2-resident scratch) and line 0 adds them to its inputs field by field.
+// Why not a workgroup of its own: at N = 4096 the 512 column groups are exactly two dispatch rounds of 256
+// one-per-CU workgroups; a 513th ran alone after everything else (tools/timeline.hip: bulk done at 102 us,
+// kernel end at 133 us; a lone workgroup is latency-bound and takes 40 us for a third of the work).
 // __launch_bounds__(.., 4 waves/SIMD when the workgroup is >= 512 threads): 1024 threads per CU, i.e. one
 // 4-line or two 2-line workgroups co-resident (128 VGPRs each).
 template <int N, int E, int P, bool H16>
 __global__ void __launch_bounds__((N / E) * P, ((N / E) * P >= 512) ? 4 : 1)
 k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restrict__ omegaT, c32* __restrict__ inter,
-             float* __restrict__ nyq, const c32* __restrict__ tw, InterLayout lay, float time, float domain_size) {
+             c32* nyq_spec, const c32* __restrict__ tw, InterLayout lay, float time, float domain_size) {
     constexpr int T = N / E;
     constexpr int H2 = P / 2;
     constexpr int CR = CHUNK_R, CW = CHUNK_W;                    // row y of a chunk is y % CR, column x % CW
@@ -504,34 +535,25 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
     c32* lds_line = lds + c * LinePitch<N>::elems;
     const float kscale = OCEAN_PI_F / domain_size;
 
-    if (blockIdx.x == 0) {                                         // uniform: the Nyquist column kx = N/2
-        // line c transforms fields c, c + P, ... (one round for P = 4, two for P = 2); every line runs
-        // the same number of rounds so that the barriers inside fft_line stay uniform
-        c32 A[E], B[E];
-        half_load_AB<N, E, H16>(h0T, descale, omegaT, (uint32_t)(N / 2), j, time, A, B);
+    const int X = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+    if (X == 0) {                                                  // uniform: the Nyquist column's spectra, element-wise
         const float kxn = wave_index_q1((uint32_t)(N / 2), N) * kscale;
-        constexpr int ROUNDS = (3 + P - 1) / P;
+#pragma unroll 1
+        for (int y = tid; y < N; y += T * P) {
+            c32 An, Bn;
+            half_AB_at<N, H16>(h0T, descale, omegaT, (uint32_t)(N / 2), (uint32_t)y, time, An, Bn);
 #pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) {
-            const int fr = c + r * P;
-            const int f = (fr < 3) ? fr : 2;
-            c32 reg[E];
-            half_spectrum<N, E>(f, A, B, kxn, kxn, kscale, opaque_lane(j), reg);
-            if (r > 0) __syncthreads();
-            fft_line<N, E>(reg, j, tw, lds_line);
-            if (fr < 3) {
-#pragma unroll
-                for (int e = 0; e < E; ++e) nyq[(size_t)f * N + j + e * T] = reg[e].x;   // real by symmetry
-            }
+            for (int f = 0; f < 3; ++f) nyq_spec[(size_t)f * N + y] = half_spectrum_at<N>(f, An, Bn, kxn, kxn, kscale, y);
         }
-        return;
+        workgroup_publish();                                       // visible to the other waves of this workgroup
     }
-
-    const int X = xcd_contiguous((int)blockIdx.x - 1, (int)gridDim.x - 1);
+    const bool packs_nyquist = (X == 0) && (c == 0);               // line 0 of that workgroup: column 0 + i * Nyquist
     const uint32_t x = (uint32_t)(X * P + c);                      // kx in [0, N/2)
     const uint32_t x2 = (N - x) & (N - 1);
     c32 A[E], B[E];
+    OCEAN_TL(0);
     half_load_AB<N, E, H16>(h0T, descale, omegaT, x, j, time, A, B);
+    OCEAN_TL(1);
     const float kx1 = wave_index_q1(x, N) * kscale;
     const float kx2 = wave_index_q1(x2, N) * kscale;
 
@@ -544,8 +566,17 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
         c32 reg[E];
         const int jf = opaque_lane(j);
         half_spectrum<N, E>(f, A, B, kx1, kx2, kscale, jf, reg);
+        if (packs_nyquist) {
+            const c32* z = nyq_spec + (size_t)f * N + jf;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const c32 v = z[e * T];
+                reg[e] = make_float2(reg[e].x - v.y, reg[e].y + v.x);   // + i * Sn
+            }
+        }
         if (f > 0) __syncthreads();
         fft_line_to_lds<N, E>(reg, jf, tw, lds_line);
+        OCEAN_TL(2 + 2 * f);
         c32* dst = inter + (size_t)f * lay.fs + (size_t)((X * P) / CW) * lay.sx + (size_t)(i / CR) * lay.sy + (i % CR) * CW +
                    ((X * P) % CW) + 2 * h;
 #pragma unroll
@@ -557,14 +588,14 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
             if constexpr (P == CW) store_float4_nt(o, make_float4(v0.x, v0.y, v1.x, v1.y));
             else *o = make_float4(v0.x, v0.y, v1.x, v1.y);        // half a chunk row: must meet its other half in L2
         }
+        OCEAN_TL(3 + 2 * f);
     }
 }
 
 // Pass 2 of the half-spectrum path: one row per R2-slot; two complex FFTs per row.
 template <int N, int E, int P1, int R2>
 __global__ void __launch_bounds__((N / E) * R2)
-k_half_pass2(const c32* __restrict__ inter, const float* __restrict__ nyq, float4* __restrict__ out,
-             const c32* __restrict__ tw, InterLayout lay) {
+k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32* __restrict__ tw, InterLayout lay) {
     constexpr int T = N / E;
     constexpr int EH = E / 2;                                      // elements of the half spectrum per thread
     static_assert(T % P1 == 0 && (E % 2) == 0, "geometry");
@@ -583,9 +614,9 @@ k_half_pass2(const c32* __restrict__ inter, const float* __restrict__ nyq, float
     }
     const int y = rb * R2 + ll;
     c32* lds_line = lds + ll * LinePitch<N>::elems;
-    const float ny_x = nyq[y], ny_h = nyq[(size_t)N + y], ny_z = nyq[(size_t)2 * N + y];
 
     float keep_h[E];
+    OCEAN_TL(0);
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {                         // 0: height, 1: (disp_x, disp_z)
         const int jf = opaque_lane(j);
@@ -602,7 +633,8 @@ k_half_pass2(const c32* __restrict__ inter, const float* __restrict__ nyq, float
             for (int e = 0; e < EH; ++e) { a[e] = sx_[(size_t)e * (T / P1) * lay.sx]; b[e] = sz_[(size_t)e * (T / P1) * lay.sx]; }
         }
         if (pass > 0) __syncthreads();                             // previous FFT's LDS reads done
-        // rebuild the full row: C[k] = A + iB, C[N-k] = conj(A) + i conj(B); C[0], C[N/2] real pairs
+        // rebuild the full row: C[k] = A + iB, C[N-k] = conj(A) + i conj(B).  Column 0 of the intermediate
+        // holds two real columns, (kx = 0, kx = N/2) as (re, im): C[0] = re(A) + i re(B), C[N/2] = im(A) + i im(B)
         c32* lo = lds_line + lds_pad(jf);                          // lds_pad(jf + e*T) = lds_pad(jf) + e*(T + T/16)
         c32* hi = lds_line + lds_pad(N - jf);                      // lds_pad(N - jf - e*T) = lds_pad(N - jf) - e*(T + T/16)
 #pragma unroll
@@ -612,10 +644,10 @@ k_half_pass2(const c32* __restrict__ inter, const float* __restrict__ nyq, float
             c32 ck = make_float2(ar - bi, ai + br);
             c32 cm = make_float2(ar + bi, br - ai);
             if (e == 0) {
-                const bool dc = (jf == 0);                         // kx = 0: real pair; its mirror slot is the Nyquist bin
+                const bool dc = (jf == 0);                         // kx = 0; its mirror slot is the Nyquist bin
                 if (dc) {
                     ck = make_float2(ar, br);
-                    cm = (pass == 0) ? make_float2(ny_h, 0.0f) : make_float2(ny_x, ny_z);
+                    cm = make_float2(ai, bi);
                 }
                 lo[0] = ck;
                 (dc ? (lds_line + lds_pad(N / 2)) : hi)[0] = cm;
@@ -625,12 +657,14 @@ k_half_pass2(const c32* __restrict__ inter, const float* __restrict__ nyq, float
             }
         }
         __syncthreads();
+        OCEAN_TL(1 + 3 * pass);
         c32 reg[E];
         const c32* g = lds_line + lds_pad(jf);
 #pragma unroll
         for (int e = 0; e < E; ++e) reg[e] = g[e * (T + T / 16)];
         __syncthreads();
         fft_line<N, E>(reg, jf, tw, lds_line);
+        OCEAN_TL(2 + 3 * pass);
         if (pass == 0) {
 #pragma unroll
             for (int e = 0; e < E; ++e) keep_h[e] = reg[e].x;
@@ -642,6 +676,7 @@ k_half_pass2(const c32* __restrict__ inter, const float* __restrict__ nyq, float
                 const float s = (((xo + y) & 1) == 0) ? -0.5f : 0.5f;   // correction.comp:29 and the 1/2 of S(F)
                 store_float4_nt(orow + xo, make_float4(reg[e].x * s, keep_h[e] * s, reg[e].y * s, 0.0f));
             }
+            OCEAN_TL(6);
         }
     }
 }
@@ -673,7 +708,7 @@ template <int N, int PSEL = 0> struct Geo {
     static constexpr int thin_threads = T * R2;
     static constexpr int thin_lds = R2 * line_bytes;
     static constexpr int thin_grid = N / R2;
-    static constexpr int half_grid1 = 1 + (N / 2) / P;             // Nyquist block + column groups
+    static constexpr int half_grid1 = (N / 2) / P;                 // column groups
     static_assert(row_threads <= 1024 && col_threads <= 1024 && frame_threads <= 1024, "workgroup too large");
     static_assert(col_lds <= 160 * 1024 && frame_lds <= 160 * 1024, "LDS budget (gfx950: 160 KiB)");
 };

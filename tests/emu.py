@@ -147,7 +147,7 @@ def frame_half(h0, omega, time, L=1000.0, layout="p2", return_inter=False, spect
     omT = np.ascontiguousarray(omega.T, np.float32)
     sx, sy, fs = half_layout(n, P, layout)
     inter = np.full(3 * fs, np.nan + 1j * np.nan, np.complex64)
-    nyq = np.full(3 * n, np.nan, np.float32)
+    nyq = np.full(6 * n, np.nan, np.float32)           # scratch: the Nyquist column's three spectra
     out = np.full((n, n, 4), np.nan, np.float32)
     tw = twiddles(n)
     assert lib().emu_frame_half(n, int(P), _p(h0T), int(spectrum_fp16), descale, _p(omT), _p(inter), _p(nyq), _p(out), _p(tw),

@@ -70,7 +70,7 @@ template <int N> static int run_pass2_thin(const c32* inter, float4* out, const 
     return 0;
 }
 
-template <int N, int PSEL> static int run_half_p(const void* h0T, int f16, float descale, const float* omT, c32* inter, float* nyq,
+template <int N, int PSEL> static int run_half_p(const void* h0T, int f16, float descale, const float* omT, c32* inter, c32* nyq,
                                                  float4* out, const c32* tw, InterLayout lay, float time, float L) {
     using G = Geo<N, PSEL>;
     if (f16) emu_launch(G::half_grid1, G::frame_threads,
@@ -78,10 +78,10 @@ template <int N, int PSEL> static int run_half_p(const void* h0T, int f16, float
     else emu_launch(G::half_grid1, G::frame_threads,
                     [&] { k_half_pass1<N, G::E, G::P, false>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L); });
     emu_launch(G::thin_grid, G::thin_threads,
-               [&] { k_half_pass2<N, G::E, CHUNK_W, G::R2>(inter, nyq, out, tw, lay); });
+               [&] { k_half_pass2<N, G::E, CHUNK_W, G::R2>(inter, out, tw, lay); });
     return 0;
 }
-template <int N> static int run_half(int psel, const void* h0T, int f16, float descale, const float* omT, c32* inter, float* nyq,
+template <int N> static int run_half(int psel, const void* h0T, int f16, float descale, const float* omT, c32* inter, c32* nyq,
                                      float4* out, const c32* tw, InterLayout lay, float time, float L) {
     if (psel == 2) return run_half_p<N, 2>(h0T, f16, descale, omT, inter, nyq, out, tw, lay, time, L);
     return run_half_p<N, 0>(h0T, f16, descale, omT, inter, nyq, out, tw, lay, time, L);
@@ -124,9 +124,9 @@ int emu_frame_pass2_thin(int n, const float* inter, float* out, const float* tw,
     DISPATCH(n, C_)
 #undef C_
 }
-int emu_frame_half(int n, int psel, const void* h0T, int f16, float descale, const float* omT, float* inter, float* nyq, float* out,
+int emu_frame_half(int n, int psel, const void* h0T, int f16, float descale, const float* omT, float* inter, c32* nyq, float* out,
                    const float* tw, size_t sx, size_t sy, size_t fs, float time, float L) {
-#define C_(N) run_half<N>(psel, h0T, f16, descale, omT, (c32*)inter, nyq, (float4*)out, (const c32*)tw, InterLayout{sx, sy, fs}, time, L)
+#define C_(N) run_half<N>(psel, h0T, f16, descale, omT, (c32*)inter, (c32*)nyq, (float4*)out, (const c32*)tw, InterLayout{sx, sy, fs}, time, L)
     DISPATCH(n, C_)
 #undef C_
 }

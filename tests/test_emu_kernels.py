@@ -115,7 +115,8 @@ def test_emu_fp16_spectrum_config5(ref_inputs_256):
 @pytest.mark.parametrize("P", [4, 2])
 def test_emu_half_intermediate_layout(ref_inputs_256, P):
     """k_half_pass1 writes columns kx < N/2 of FFT_y(2 S(F)) as 4 x 4 chunks (128 bytes), whole or in
-    halves, and the Nyquist column as a real vector."""
+    halves; column 0 carries two real columns, (kx = 0, kx = N/2) as (re, im), and the scratch holds the
+    Nyquist column's three symmetrised spectra."""
     h0, om = ref_inputs_256
     n = 256
     out, inter, nyq, (P_, lay) = emu.frame_half(h0, om, 2.0, return_inter=True, P=P)
@@ -124,6 +125,10 @@ def test_emu_half_intermediate_layout(ref_inputs_256, P):
         Fm = np.conj(np.roll(np.roll(F[::-1, ::-1], 1, axis=0), 1, axis=1))
         G = np.fft.ifft(F + Fm, axis=0) * n                       # 2 S(F), transformed along y
         got = emu.unpack_inter(inter, n, P, lay, f, columns=n // 2)
-        assert_parity(got, G[:, :n // 2], 5e-6, f"half intermediate field {f}")
-        assert_parity(nyq[f * n:(f + 1) * n][:, None], G[:, n // 2].real[:, None], 5e-6, f"nyquist field {f}")
+        want = G[:, :n // 2].copy()
+        assert np.abs(G[:, 0].imag).max() < 1e-9 * np.abs(G).max() and np.abs(G[:, n // 2].imag).max() < 1e-9 * np.abs(G).max()
+        want[:, 0] = G[:, 0].real + 1j * G[:, n // 2].real        # the two real columns share one transform
+        assert_parity(got, want, 5e-6, f"half intermediate field {f}")
+        spec = nyq.view(np.complex64)[f * n:(f + 1) * n]
+        assert_parity(spec[:, None], (F + Fm)[:, n // 2][:, None], 5e-6, f"nyquist spectrum field {f}")
     assert np.isnan(inter.real).sum() >= 3 * (lay[2] - n * n // 2)
