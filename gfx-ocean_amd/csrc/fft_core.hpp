@@ -23,13 +23,17 @@
 
 namespace ocean {
 
-typedef float2 c32;
-
-__device__ __forceinline__ c32 cadd(c32 a, c32 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ c32 csub(c32 a, c32 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ c32 cmul(c32 a, c32 b) {
-    return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
-}
+// c32 (ocean_device_intrinsics.hpp) is a packed (re, im) 2-vector; everything here is written in whole-vector
+// operations so that each line below is ONE v_pk_* instruction (swizzles ride on op_sel, constants in SGPR pairs).
+__device__ __forceinline__ c32 cadd(c32 a, c32 b) { return a + b; }
+__device__ __forceinline__ c32 csub(c32 a, c32 b) { return a - b; }
+__device__ __forceinline__ c32 cadd_i(c32 a, c32 b) { return vfma(yx(b), mk(-1.0f, 1.0f), a); }   // a + i b
+__device__ __forceinline__ c32 csub_i(c32 a, c32 b) { return vfma(yx(b), mk(1.0f, -1.0f), a); }   // a - i b
+__device__ __forceinline__ c32 crot(c32 a) { return yx(a) * mk(-1.0f, 1.0f); }                    // i a
+__device__ __forceinline__ c32 cconj(c32 a) { return a * mk(1.0f, -1.0f); }
+// a * w given w and wr = i w: two instructions; without wr: three, no temporary twiddle
+__device__ __forceinline__ c32 cmul_r(c32 a, c32 w, c32 wr) { return vfma(yy(a), wr, xx(a) * w); }
+__device__ __forceinline__ c32 cmul(c32 a, c32 w) { return vfma(yy(a) * yx(w), mk(-1.0f, 1.0f), xx(a) * w); }
 
 // e^{+2 pi i s / 32}, s in [0,32): exact trivial entries, others rounded from fp64.
 template <int S32> struct W32 {};
@@ -53,23 +57,6 @@ OCEAN_W32(14, -0.9238795325112867f, 0.3826834323650898f)
 OCEAN_W32(15, -0.9807852804032304f, 0.19509032201612825f)
 #undef OCEAN_W32
 
-// a * e^{+2 pi i S / R}  for compile-time S in [0, R/2), R in {2,4,8,16,32}
-template <int R, int S>
-__device__ __forceinline__ c32 mul_wconst(c32 a) {
-    constexpr int s32 = S * (32 / R);
-    if constexpr (s32 == 0) return a;
-    else if constexpr (s32 == 8) return make_float2(-a.y, a.x);              // * i
-    else if constexpr (s32 == 4) {                                            // * (1+i)/sqrt2
-        constexpr float h = 0.7071067811865476f;
-        return make_float2((a.x - a.y) * h, (a.x + a.y) * h);
-    } else if constexpr (s32 == 12) {                                         // * (-1+i)/sqrt2
-        constexpr float h = 0.7071067811865476f;
-        return make_float2(-(a.x + a.y) * h, (a.x - a.y) * h);
-    } else {
-        return cmul(a, make_float2(W32<s32>::c, W32<s32>::s));
-    }
-}
-
 // In-register R-point unnormalised inverse DFT, natural order in and out (DIT recursion).
 template <int R> struct Dft;
 template <> struct Dft<1> {
@@ -85,18 +72,27 @@ template <> struct Dft<4> {
     static __device__ __forceinline__ void run(const c32 (&in)[4], c32 (&out)[4]) {
         const c32 t0 = cadd(in[0], in[2]), t1 = csub(in[0], in[2]);
         const c32 t2 = cadd(in[1], in[3]), t3 = csub(in[1], in[3]);
-        const c32 it3 = make_float2(-t3.y, t3.x);                              // i * t3
         out[0] = cadd(t0, t2);
         out[2] = csub(t0, t2);
-        out[1] = cadd(t1, it3);
-        out[3] = csub(t1, it3);
+        out[1] = cadd_i(t1, t3);
+        out[3] = csub_i(t1, t3);
     }
 };
 template <int R, int S> struct Combine {
     static __device__ __forceinline__ void run(const c32 (&ev)[R / 2], const c32 (&od)[R / 2], c32 (&out)[R]) {
-        const c32 t = mul_wconst<R, S>(od[S]);
-        out[S] = cadd(ev[S], t);
-        out[S + R / 2] = csub(ev[S], t);
+        // out[S] = ev + od * W, out[S + R/2] = ev - od * W,  W = e^{+2 pi i S / R}
+        constexpr int s32 = S * (32 / R);
+        if constexpr (s32 == 0) {
+            out[S] = cadd(ev[S], od[S]);
+            out[S + R / 2] = csub(ev[S], od[S]);
+        } else if constexpr (s32 == 8) {                                        // W = i
+            out[S] = cadd_i(ev[S], od[S]);
+            out[S + R / 2] = csub_i(ev[S], od[S]);
+        } else {
+            const c32 t = cmul_r(od[S], mk(W32<s32>::c, W32<s32>::s), mk(-W32<s32>::s, W32<s32>::c));
+            out[S] = cadd(ev[S], t);
+            out[S + R / 2] = csub(ev[S], t);
+        }
         if constexpr (S + 1 < R / 2) Combine<R, S + 1>::run(ev, od, out);
     }
 };
@@ -127,8 +123,9 @@ __device__ __forceinline__ int lds_pad(int i) { return i + (i >> 4); }
 template <int N> struct LdsLine { static constexpr int elems = N + (N >> 4); };
 
 // a[t] *= w^t, t in [0, R).  For R > 4 the rotation is split in two levels, t = 4*t1 + t2:
-// w^t = (w^4)^t1 * w^t2, so only {w, w^2, w^3, w^4, w^8, w^12} are ever live (12 VGPRs instead of
-// the 30 of a full power table) for 29 complex multiplies per radix-16 butterfly instead of 26.
+// w^t = (w^4)^t1 * w^t2, so only {w, w^2, w^3, w^4, w^8, w^12} are ever live instead of a 15-entry power
+// table.  The three low powers are kept together with their rotated copies i w^t2 (each is used by four
+// products, which then cost two packed instructions); the high powers use the three-instruction product.
 // Product depth <= 5 (w^12 * w^3), i.e. a few ulp on the twiddle.
 template <int R>
 __device__ __forceinline__ void apply_twiddles(c32 (&a)[R], c32 w) {
@@ -142,21 +139,22 @@ __device__ __forceinline__ void apply_twiddles(c32 (&a)[R], c32 w) {
     } else {
         static_assert(R % 4 == 0 && R <= 16, "two-level twiddle split supports R = 8, 16");
         constexpr int R1 = R / 4;
-        const c32 w2 = cmul(w, w);
-        const c32 w3 = cmul(w2, w);
-        const c32 w4 = cmul(w2, w2);
+        const c32 wr = crot(w);
+        const c32 w2 = cmul_r(w, w, wr), w2r = crot(w2);
+        const c32 w3 = cmul_r(w2, w, wr), w3r = crot(w3);
+        const c32 w4 = cmul_r(w2, w2, w2r);
         c32 hi[R1];
-        hi[0] = make_float2(1.0f, 0.0f);
+        hi[0] = mk(1.0f, 0.0f);
         hi[1] = w4;
         if constexpr (R1 > 2) { hi[2] = cmul(w4, w4); hi[3] = cmul(hi[2], w4); }
 #pragma unroll
         for (int t = 1; t < R; ++t) {
             const int t1 = t / 4, t2 = t % 4;
             c32 v = a[t];
+            if (t2 == 1) v = cmul_r(v, w, wr);
+            if (t2 == 2) v = cmul_r(v, w2, w2r);
+            if (t2 == 3) v = cmul_r(v, w3, w3r);
             if (t1 > 0) v = cmul(v, hi[t1]);
-            if (t2 == 1) v = cmul(v, w);
-            if (t2 == 2) v = cmul(v, w2);
-            if (t2 == 3) v = cmul(v, w3);
             a[t] = v;
         }
     }
@@ -169,7 +167,7 @@ template <int N, int E, int R, int NS, class Emit>
 __device__ __forceinline__ void fft_pass(c32 (&reg)[E], int j, const c32* __restrict__ tw, Emit&& emit) {
     constexpr int T = N / E;
     constexpr int U = E / R;
-    c32 w = make_float2(1.0f, 0.0f);
+    c32 w = mk(1.0f, 0.0f);
     if constexpr (NS > 1 && U == 1) w = tw[(j & (NS - 1)) * (N / (NS * R))];
 #pragma unroll
     for (int u = 0; u < U; ++u) {

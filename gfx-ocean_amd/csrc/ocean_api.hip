@@ -298,7 +298,7 @@ int32_t ocean_context_create(int32_t device, int32_t resolution, OceanContext** 
         std::vector<c32> tw((size_t)resolution);
         for (int i = 0; i < resolution; ++i) {
             const double a = 2.0 * M_PI * (double)i / (double)resolution;
-            tw[(size_t)i] = make_float2((float)std::cos(a), (float)std::sin(a));
+            tw[(size_t)i] = mk((float)std::cos(a), (float)std::sin(a));
         }
         CTX_TRY(hipMemcpy(c->tw, tw.data(), tw.size() * sizeof(c32), hipMemcpyHostToDevice));
     }
@@ -363,7 +363,7 @@ int32_t upload_common(OceanContext* ctx, const float* h0_re_im, const float* ome
         else scale_log2 = 14 - (int)std::floor(std::log2(mx));       // max * 2^s in [2^14, 2^15)
         const float up = std::ldexp(1.0f, scale_log2), down = std::ldexp(1.0f, -scale_log2);
         for (size_t i = 0; i < n2; ++i) {                              // the values every kernel will use
-            nat[i] = make_float2(half_bits_to_float(float_to_half_bits(src[i].x * up)) * down,
+            nat[i] = mk(half_bits_to_float(float_to_half_bits(src[i].x * up)) * down,
                                  half_bits_to_float(float_to_half_bits(src[i].y * up)) * down);
         }
     } else {

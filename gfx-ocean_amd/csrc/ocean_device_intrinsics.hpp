@@ -5,6 +5,18 @@
 
 namespace ocean {
 
+// A complex number is a 2-vector of floats living in an even-aligned VGPR pair, so that complex arithmetic
+// maps onto gfx950's packed fp32 instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: two lanes per
+// instruction, swizzles through op_sel): pass 1's phases are VALU-issue-bound (tools/timeline.hip), and the
+// packed form halves the instruction count of the butterflies.  The vector primitives below are the whole
+// interface; tests/hipemu has scalar twins.
+typedef float c32 __attribute__((ext_vector_type(2)));
+__host__ __device__ __forceinline__ c32 mk(float re, float im) { return c32{re, im}; }
+__host__ __device__ __forceinline__ c32 xx(c32 a) { return __builtin_shufflevector(a, a, 0, 0); }
+__host__ __device__ __forceinline__ c32 yy(c32 a) { return __builtin_shufflevector(a, a, 1, 1); }
+__host__ __device__ __forceinline__ c32 yx(c32 a) { return __builtin_shufflevector(a, a, 1, 0); }
+__host__ __device__ __forceinline__ c32 vfma(c32 a, c32 b, c32 c) { return __builtin_elementwise_fma(a, b, c); }
+
 // Returns x unchanged but opaque to GVN/LICM.  The three per-field FFTs of a fused kernel use
 // identical twiddles; without this the compiler keeps ~60 VGPRs of twiddle powers alive across
 // the fields (measured: 195 -> 92 VGPRs for k_frame_pass2<4096>), which spills at the
@@ -104,9 +116,9 @@ __device__ __forceinline__ float cos_rev(float x) { return __builtin_amdgcn_cosf
 // BASELINE config 5: the initial spectrum stored as two fp16 (re, im) per texel, scaled by a power
 // of two; all arithmetic stays fp32.  v_cvt_f32_f16 x2.
 typedef _Float16 ocean_h2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float2 unpack_half2(uint32_t bits, float descale) {
+__device__ __forceinline__ c32 unpack_half2(uint32_t bits, float descale) {
     const ocean_h2 h = __builtin_bit_cast(ocean_h2, bits);
-    return make_float2((float)h.x * descale, (float)h.y * descale);
+    return mk((float)h.x * descale, (float)h.y * descale);
 }
 
 // x is known to be identical in every lane of the wave: move it to an SGPR so that addresses

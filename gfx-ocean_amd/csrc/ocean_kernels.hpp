@@ -49,9 +49,9 @@ __device__ __forceinline__ c32 propagate_height(c32 h0, c32 h0_neg, float omega,
     const float turns = rintf(disp * INV_2PI_HI);
     const float frac = fmaf(disp, INV_2PI_LO, fmaf(disp, INV_2PI_HI, -turns));
     const float s = sin_rev(frac), c = cos_rev(frac);
-    const c32 a = make_float2(h0.x * c - h0.y * s, h0.y * c + h0.x * s);                  // * (c, s)
-    const c32 b = make_float2(h0_neg.x * c + h0_neg.y * s, h0_neg.y * c - h0_neg.x * s);  // * (c,-s)
-    return make_float2(a.x + b.x, a.y + b.y);
+    // h0 (c + i s) + h0_neg (c - i s) = c (h0 + h0_neg) + s * i (h0 - h0_neg): five packed instructions
+    const c32 p = h0 + h0_neg, q = h0 - h0_neg;
+    return vfma(yx(q) * s, mk(-1.0f, 1.0f), p * c);
 }
 // k_norm = k / length(k) if length(k) > 1e-10 else 0   (:64-67)
 __device__ __forceinline__ void k_normalised(float kx, float ky, float& knx, float& kny) {
@@ -68,7 +68,7 @@ __device__ __forceinline__ void k_normalised_fast(float kx, float ky, float& knx
     kny = ky * r;
 }
 // complex_mul(vec2(0, -kn), h) = (kn*h.y, -kn*h.x)   (:70-71)
-__device__ __forceinline__ c32 mul_minus_i_kn(float kn, c32 h) { return make_float2(kn * h.y, -kn * h.x); }
+__device__ __forceinline__ c32 mul_minus_i_kn(float kn, c32 h) { return yx(h) * mk(kn, -kn); }
 
 // ---------------------------------------------------------------------------------------------
 // Staged kernels
@@ -87,12 +87,12 @@ k_propagate(const c32* __restrict__ h0, const float* __restrict__ omega, c32* __
     // index_neg = N*N-1-index (:48); the pair (index, index+1) mirrors to (ineg, ineg-1)
     const uint32_t ineg = total - 1u - index;
     const float4 neg = *reinterpret_cast<const float4*>(h0 + (ineg - 1u));
-    const float2 om = *reinterpret_cast<const float2*>(omega + index);
+    const c32 om = *reinterpret_cast<const c32*>(omega + index);
     const float ky = OCEAN_PI_F * wave_index_q1(gy, un) / domain_size;
     const float kx0 = OCEAN_PI_F * wave_index_q1(gx, un) / domain_size;
     const float kx1 = OCEAN_PI_F * wave_index_q1(gx + 1u, un) / domain_size;
-    const c32 h0v = propagate_height(make_float2(own.x, own.y), make_float2(neg.z, neg.w), om.x, time);
-    const c32 h1v = propagate_height(make_float2(own.z, own.w), make_float2(neg.x, neg.y), om.y, time);
+    const c32 h0v = propagate_height(mk(own.x, own.y), mk(neg.z, neg.w), om.x, time);
+    const c32 h1v = propagate_height(mk(own.z, own.w), mk(neg.x, neg.y), om.y, time);
     float knx0, kny0, knx1, kny1;
     k_normalised(kx0, ky, knx0, kny0);
     k_normalised(kx1, ky, knx1, kny1);
@@ -398,26 +398,28 @@ k_frame_pass2_thin(const c32* __restrict__ inter, float4* __restrict__ out, cons
 // B = conj(H2) and k1 = k_norm(x, y), k2 = k_norm(x2, y2)   (all quirks Q1/Q2 kept):
 //     2 S(H)  = A + B,     2 S(Dx) = i (k2.x B - k1.x A),     2 S(Dz) = i (k2.y B - k1.y A).
 
-// One field's symmetrised column spectrum (times 2) at row y of a column pair (kx1 = k(x), kx2 = k((N-x)%N)).
+// One field's symmetrised column spectrum (times 2) at row y of a column pair; kxv = (k(x), k((N-x)%N)).
+// 2 S(H) = A + B,  2 S(Dx) = i (k2.x B - k1.x A),  2 S(Dz) = i (k2.y B - k1.y A),  k1 = k_norm(x, y),
+// k2 = k_norm((N-x)%N, (N-y)%N) with the Q1 wrap and k * rsqrt(|k|^2) (k_normalised_fast), evaluated for
+// the pair (k1, k2) in the two lanes of packed instructions.
 template <int N>
-__device__ __forceinline__ c32 half_spectrum_at(int f, c32 A, c32 B, float kx1, float kx2, float kscale, int y) {
-    if (f == 1) return make_float2(A.x + B.x, A.y + B.y);
+__device__ __forceinline__ c32 half_spectrum_at(int f, c32 A, c32 B, c32 kxv, float kscale, int y) {
+    if (f == 1) return A + B;
     const int y2 = (N - y) & (N - 1);
-    float knx1, kny1, knx2, kny2;
-    k_normalised_fast(kx1, wave_index_q1((uint32_t)y, N) * kscale, knx1, kny1);
-    k_normalised_fast(kx2, wave_index_q1((uint32_t)y2, N) * kscale, knx2, kny2);
-    const float k1 = (f == 0) ? knx1 : kny1;
-    const float k2 = (f == 0) ? knx2 : kny2;
-    const c32 v = make_float2(k2 * B.x - k1 * A.x, k2 * B.y - k1 * A.y);
-    return make_float2(-v.y, v.x);                                 // i * v
+    const c32 kyv = mk(wave_index_q1((uint32_t)y, N), wave_index_q1((uint32_t)y2, N)) * kscale;
+    const c32 l2 = vfma(kxv, kxv, kyv * kyv);
+    const c32 r = mk((l2.x > 1.0e-20f) ? rsqrtf(l2.x) : 0.0f, (l2.y > 1.0e-20f) ? rsqrtf(l2.y) : 0.0f);
+    const c32 kn = ((f == 0) ? kxv : kyv) * r;                     // (k1, k2) of this field
+    const c32 v = vfma(A, -xx(kn), B * yy(kn));                    // k2 B - k1 A
+    return crot(v);                                                // i * v
 }
 // ... for the E positions of a thread.
 template <int N, int E>
-__device__ __forceinline__ void half_spectrum(int f, const c32 (&A)[E], const c32 (&B)[E], float kx1, float kx2,
-                                              float kscale, int j, c32 (&reg)[E]) {
+__device__ __forceinline__ void half_spectrum(int f, const c32 (&A)[E], const c32 (&B)[E], c32 kxv, float kscale, int j,
+                                              c32 (&reg)[E]) {
     constexpr int T = N / E;
 #pragma unroll
-    for (int e = 0; e < E; ++e) reg[e] = half_spectrum_at<N>(f, A[e], B[e], kx1, kx2, kscale, j + e * T);
+    for (int e = 0; e < E; ++e) reg[e] = half_spectrum_at<N>(f, A[e], B[e], kxv, kscale, j + e * T);
 }
 
 // The initial spectrum in HBM: fp32 complex (8 B/texel), or -- BASELINE config 5 -- two fp16 with
@@ -489,7 +491,7 @@ __device__ __forceinline__ void half_load_AB(const void* __restrict__ h0T_, floa
         }
         A[e] = propagate_height(a, m, w, time);
         const c32 h2 = propagate_height(a2, m2, w2, time);
-        B[e] = make_float2(h2.x, -h2.y);
+        B[e] = cconj(h2);
     }
 }
 
@@ -505,7 +507,7 @@ __device__ __forceinline__ void half_AB_at(const void* __restrict__ h0T_, float 
                          Spec<H16>::load(h0T + (size_t)(N - 1 - x) * N + (N - 1 - y), descale), omegaT[(size_t)x * N + y], time);
     const c32 h2 = propagate_height(Spec<H16>::load(h0T + (size_t)x2 * N + y2, descale),
                                     Spec<H16>::load(h0T + (size_t)xm * N + ym, descale), omegaT[(size_t)x2 * N + y2], time);
-    B = make_float2(h2.x, -h2.y);
+    B = cconj(h2);
 }
 
 // grid = (N/2)/P blocks of P columns.  The half spectrum has N/2 + 1 distinct columns; the odd one out, the
@@ -537,13 +539,13 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
 
     const int X = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
     if (X == 0) {                                                  // uniform: the Nyquist column's spectra, element-wise
-        const float kxn = wave_index_q1((uint32_t)(N / 2), N) * kscale;
+        const c32 kxn = xx(mk(wave_index_q1((uint32_t)(N / 2), N) * kscale, 0.0f));
 #pragma unroll 1
         for (int y = tid; y < N; y += T * P) {
             c32 An, Bn;
             half_AB_at<N, H16>(h0T, descale, omegaT, (uint32_t)(N / 2), (uint32_t)y, time, An, Bn);
 #pragma unroll
-            for (int f = 0; f < 3; ++f) nyq_spec[(size_t)f * N + y] = half_spectrum_at<N>(f, An, Bn, kxn, kxn, kscale, y);
+            for (int f = 0; f < 3; ++f) nyq_spec[(size_t)f * N + y] = half_spectrum_at<N>(f, An, Bn, kxn, kscale, y);
         }
         workgroup_publish();                                       // visible to the other waves of this workgroup
     }
@@ -554,8 +556,7 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
     OCEAN_TL(0);
     half_load_AB<N, E, H16>(h0T, descale, omegaT, x, j, time, A, B);
     OCEAN_TL(1);
-    const float kx1 = wave_index_q1(x, N) * kscale;
-    const float kx2 = wave_index_q1(x2, N) * kscale;
+    const c32 kxv = mk(wave_index_q1(x, N), wave_index_q1(x2, N)) * kscale;
 
     const int h = tid % H2;
     const int i = tid / H2;
@@ -565,13 +566,12 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
     for (int f = 0; f < 3; ++f) {
         c32 reg[E];
         const int jf = opaque_lane(j);
-        half_spectrum<N, E>(f, A, B, kx1, kx2, kscale, jf, reg);
+        half_spectrum<N, E>(f, A, B, kxv, kscale, jf, reg);
         if (packs_nyquist) {
             const c32* z = nyq_spec + (size_t)f * N + jf;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                const c32 v = z[e * T];
-                reg[e] = make_float2(reg[e].x - v.y, reg[e].y + v.x);   // + i * Sn
+                reg[e] = cadd_i(reg[e], z[e * T]);                 // + i * Sn
             }
         }
         if (f > 0) __syncthreads();
@@ -593,8 +593,9 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
 }
 
 // Pass 2 of the half-spectrum path: one row per R2-slot; two complex FFTs per row.
+// __launch_bounds__(256, 4): four workgroups per CU (LDS: 4 x 35 KiB), i.e. at most 128 VGPRs.
 template <int N, int E, int P1, int R2>
-__global__ void __launch_bounds__((N / E) * R2)
+__global__ void __launch_bounds__((N / E) * R2, 4)
 k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32* __restrict__ tw, InterLayout lay) {
     constexpr int T = N / E;
     constexpr int EH = E / 2;                                      // elements of the half spectrum per thread
@@ -639,15 +640,20 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
         c32* hi = lds_line + lds_pad(N - jf);                      // lds_pad(N - jf - e*T) = lds_pad(N - jf) - e*(T + T/16)
 #pragma unroll
         for (int e = 0; e < EH; ++e) {
-            const float ar = a[e].x, ai = a[e].y;
-            const float br = (pass == 0) ? 0.0f : b[e].x, bi = (pass == 0) ? 0.0f : b[e].y;
-            c32 ck = make_float2(ar - bi, ai + br);
-            c32 cm = make_float2(ar + bi, br - ai);
+            c32 ck, cm;
+            if (pass == 0) {
+                ck = a[e];
+                cm = cconj(a[e]);
+            } else {
+                ck = cadd_i(a[e], b[e]);                           // A + i B
+                cm = vfma(yx(b[e]), mk(1.0f, 1.0f), cconj(a[e]));   // conj(A) + i conj(B)
+            }
             if (e == 0) {
                 const bool dc = (jf == 0);                         // kx = 0; its mirror slot is the Nyquist bin
                 if (dc) {
-                    ck = make_float2(ar, br);
-                    cm = make_float2(ai, bi);
+                    const c32 bb = (pass == 0) ? mk(0.0f, 0.0f) : b[e];
+                    ck = mk(a[e].x, bb.x);
+                    cm = mk(a[e].y, bb.y);
                 }
                 lo[0] = ck;
                 (dc ? (lds_line + lds_pad(N / 2)) : hi)[0] = cm;
@@ -674,7 +680,8 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
             for (int e = 0; e < E; ++e) {
                 const int xo = j + e * T;
                 const float s = (((xo + y) & 1) == 0) ? -0.5f : 0.5f;   // correction.comp:29 and the 1/2 of S(F)
-                store_float4_nt(orow + xo, make_float4(reg[e].x * s, keep_h[e] * s, reg[e].y * s, 0.0f));
+                const c32 d = reg[e] * s;
+                store_float4_nt(orow + xo, make_float4(d.x, keep_h[e] * s, d.y, 0.0f));
             }
             OCEAN_TL(6);
         }

@@ -3,6 +3,18 @@
 #include <cmath>
 #include <cstdint>
 namespace ocean {
+// scalar twin of the device's packed 2-vector complex type and its primitives
+struct c32 { float x, y; };
+static inline c32 mk(float re, float im) { return c32{re, im}; }
+static inline c32 operator+(c32 a, c32 b) { return c32{a.x + b.x, a.y + b.y}; }
+static inline c32 operator-(c32 a, c32 b) { return c32{a.x - b.x, a.y - b.y}; }
+static inline c32 operator*(c32 a, c32 b) { return c32{a.x * b.x, a.y * b.y}; }
+static inline c32 operator*(c32 a, float s) { return c32{a.x * s, a.y * s}; }
+static inline c32 operator-(c32 a) { return c32{-a.x, -a.y}; }
+static inline c32 xx(c32 a) { return c32{a.x, a.x}; }
+static inline c32 yy(c32 a) { return c32{a.y, a.y}; }
+static inline c32 yx(c32 a) { return c32{a.y, a.x}; }
+static inline c32 vfma(c32 a, c32 b, c32 c) { return c32{std::fmaf(a.x, b.x, c.x), std::fmaf(a.y, b.y, c.y)}; }
 static inline int opaque_lane(int x) { return x; }
 static inline float ocean_emu_half_to_float(uint16_t h) {
     const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
@@ -14,8 +26,8 @@ static inline float ocean_emu_half_to_float(uint16_t h) {
     else mag = std::ldexp((float)(man | 1024u), exp - 25);
     return sign ? -mag : mag;
 }
-static inline float2 unpack_half2(uint32_t bits, float descale) {
-    return make_float2(ocean_emu_half_to_float((uint16_t)(bits & 0xFFFFu)) * descale,
+static inline c32 unpack_half2(uint32_t bits, float descale) {
+    return mk(ocean_emu_half_to_float((uint16_t)(bits & 0xFFFFu)) * descale,
                        ocean_emu_half_to_float((uint16_t)(bits >> 16)) * descale);
 }
 static inline int wave_uniform(int x) { return x; }
