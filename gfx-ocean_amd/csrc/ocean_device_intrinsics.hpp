@@ -85,26 +85,7 @@ __device__ __forceinline__ void ocean_tl_hwid(unsigned long long* slot) {
         if ((k) == 0) ocean_tl_hwid(ocean_tl + (size_t)blockIdx.x * 16 + 15);  \
     } while (0)
 #else
-#if defined(OCEAN_FENCE_KIND) && OCEAN_FENCE_KIND == 1
-#define OCEAN_TL(k) __builtin_amdgcn_sched_barrier(0)
-#elif defined(OCEAN_FENCE_KIND) && OCEAN_FENCE_KIND == 2
-#define OCEAN_TL(k) asm volatile("" ::: "memory")
-#elif defined(OCEAN_FENCE_KIND) && OCEAN_FENCE_KIND == 3
-#define OCEAN_TL(k) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 0" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#elif defined(OCEAN_FENCE_KIND) && OCEAN_FENCE_KIND == 4
-#define OCEAN_TL(k) asm volatile("s_nop 0" ::: "memory")
-#elif defined(OCEAN_FENCE_KIND) && OCEAN_FENCE_KIND == 6
-#define OCEAN_TL(k) do { int z_ = __builtin_amdgcn_readfirstlane((int)threadIdx.x + (k)); asm volatile("" :: "s"(z_) : "memory"); } while (0)
-#elif defined(OCEAN_FENCE_KIND) && OCEAN_FENCE_KIND == 7
-#define OCEAN_TL(k) do { __builtin_amdgcn_sched_barrier(0); int z_ = __builtin_amdgcn_readfirstlane((int)threadIdx.x + (k)); asm volatile("" :: "s"(z_) : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#elif defined(OCEAN_FENCE_KIND) && OCEAN_FENCE_KIND == 8
-__device__ unsigned long long* ocean_tl;
-#define OCEAN_TL(k) do { unsigned long long v_ = (unsigned long long)(ocean_tl + (size_t)blockIdx.x * 16 + (k)); unsigned lo_ = __builtin_amdgcn_readfirstlane((unsigned)v_), hi_ = __builtin_amdgcn_readfirstlane((unsigned)(v_ >> 32)); asm volatile("" :: "s"(lo_), "s"(hi_) : "memory"); } while (0)
-#elif defined(OCEAN_FENCE_KIND) && OCEAN_FENCE_KIND == 5
-#define OCEAN_TL(k) do { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(t_) :: "memory"); } while (0)
-#else
 #define OCEAN_TL(k)
-#endif
 #endif
 
 // sin / cos of 2*pi*x for x in [-0.5, 0.5] revolutions: the gfx950 transcendental unit

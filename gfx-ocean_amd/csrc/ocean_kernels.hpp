@@ -453,23 +453,12 @@ __device__ __forceinline__ void half_load_AB(const void* __restrict__ h0T_, floa
     // inputs have been consumed (otherwise 16 x 10 input VGPRs are live at once next to A and B and
     // the kernel spills at the 128-VGPR budget of a 1024-thread workgroup; a spill reload in the
     // load phase also drains every outstanding global load, vmcnt being in-order)
-#ifndef OCEAN_LOAD_BATCHES
-#define OCEAN_LOAD_BATCHES 4
-#endif
-#ifndef OCEAN_LOAD_LOOKAHEAD
-#define OCEAN_LOAD_LOOKAHEAD 1
-#endif
-    constexpr int LOAD_BATCHES = OCEAN_LOAD_BATCHES;
-    constexpr int LOOKAHEAD = OCEAN_LOAD_LOOKAHEAD;               // batches in flight ahead of the one being consumed
+    constexpr int LOAD_BATCHES = 4;                                // measured: 2 and 8 spill more; issuing a batch ahead: +8 us
     constexpr int PER = E / LOAD_BATCHES;
     int jj = j;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        if ((e % PER) == 0 && e / PER >= LOOKAHEAD) {
-            constexpr int dummy = 0; (void)dummy;
-            const int d = (e / PER - LOOKAHEAD + 1) * PER - 1;     // last element of the batch LOOKAHEAD back
-            jj = opaque_after(j, A[d].x + B[d].y);
-        }
+        if (e > 0 && (e % PER) == 0) jj = opaque_after(j, A[e - 1].x + B[e - 1].y);
         // y = jj + e*T.  Every address is written as (uniform base + e-dependent constant)[small lane index]
         // so that the six streams share three lane offsets and the bases stay in SGPRs; only e == 0 can
         // hit the wrap of y2 = (N - y) % N and ym = (y - 1) % N (at jj == 0).
