@@ -137,7 +137,8 @@ void* ocean_stream(OceanContext* ctx);                            /* the context
 /* ---- measurement (HIP events on the stream the kernels run on) -------------------------------- */
 /* Runs `frames` frames (time = t0 + i*dt) on the context stream between two events; *out_ms = total. */
 int32_t ocean_time_frames(OceanContext* ctx, int32_t frames, float t0, float dt, float* out_ms);
-/* Per-kernel durations of ONE frame: names/ms arrays of capacity `cap`; returns count via *out_n. */
+/* Per-kernel durations of ONE frame (begin/end timestamps of each dispatch, as rocprofv3 reports them; the
+ * frame runs behind two untimed ones): names/ms arrays of capacity `cap`; returns count via *out_n. */
 int32_t ocean_profile_frame(OceanContext* ctx, float time, int32_t cap, const char** names, float* ms,
                             int32_t* out_n);
 /* Same for the staged 8-dispatch path (propagate, 3 rows, 3 cols, correct). */
