@@ -384,8 +384,9 @@ k_frame_pass2_thin(const c32* __restrict__ inter, float4* __restrict__ out, cons
 // correction.comp:31 keeps only the real part of each inverse transform, and for any complex F
 //     Re(IDFT2(F)) = IDFT2(S(F)),   S(F)[ky][kx] = (F[ky][kx] + conj(F[(-ky)%N][(-kx)%N])) / 2.
 // S(F) is Hermitian, so after the transform along y the columns kx and N-kx are conjugates: pass 1
-// only has to produce columns kx = 0 .. N/2-1 (plus the self-paired Nyquist column N/2, a real
-// N-vector per field), i.e. HALF the column FFTs and 12 instead of 24 bytes/texel of intermediate.
+// only has to produce columns kx = 0 .. N/2-1 (the self-paired Nyquist column N/2, real after the
+// transform, rides in the imaginary part of column 0), i.e. HALF the column FFTs and 12 instead of
+// 24 bytes/texel of intermediate.
 // Pass 2 rebuilds the full rows in LDS (C[kx] = A + iB, C[N-kx] = conj(A) + i conj(B)) and gets
 // two real channels per complex FFT: (disp_x, disp_z) from one, height from the other.
 // Same result as the three complex transforms up to fp32 rounding; the factors 1/2 are applied
