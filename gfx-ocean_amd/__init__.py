@@ -12,12 +12,14 @@ from ._lib import OceanError, build_library, library_path, load_library  # noqa:
 from .ocean import (Correction, CorrectionLocals, Propagation, PropagateLocals,  # noqa: F401
                     DOMAIN_SIZE, RESOLUTION)
 from .fft import Fft  # noqa: F401
-from .render import OceanDevice, OceanRenderer, FIELD_DX, FIELD_DY, FIELD_DZ, FIELD_ALL  # noqa: F401
+from .render import (OceanDevice, OceanRenderer, FIELD_DX, FIELD_DY, FIELD_DZ, FIELD_ALL,  # noqa: F401
+                     QUIRK_Q1, QUIRK_Q2, QUIRKS_REFERENCE)
 from . import bincode, synth  # noqa: F401
 
 __all__ = [
     "OceanError", "build_library", "library_path", "load_library",
     "Correction", "CorrectionLocals", "Propagation", "PropagateLocals", "Fft",
     "OceanDevice", "OceanRenderer", "FIELD_DX", "FIELD_DY", "FIELD_DZ", "FIELD_ALL",
+    "QUIRK_Q1", "QUIRK_Q2", "QUIRKS_REFERENCE",
     "DOMAIN_SIZE", "RESOLUTION", "bincode", "synth",
 ]

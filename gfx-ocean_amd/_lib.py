@@ -22,7 +22,8 @@ SYMBOLS = [
     "ocean_fft_init", "ocean_fft_destroy", "ocean_propagation_init",
     "ocean_propagation_destroy", "ocean_correction_init", "ocean_correction_destroy", "ocean_propagate",
     "ocean_fft_rows", "ocean_fft_cols", "ocean_correct", "ocean_frame", "ocean_frame_ex", "ocean_sync",
-    "ocean_normals", "ocean_read_normals",
+    "ocean_set_quirks", "ocean_quirks",
+    "ocean_normals", "ocean_read_normals", "ocean_positions", "ocean_read_positions",
     "ocean_read_displacement", "ocean_read_field", "ocean_write_field", "ocean_displacement_device_ptr",
     "ocean_bind_displacement", "ocean_stream", "ocean_time_frames", "ocean_profile_frame", "ocean_profile_staged",
 ]
@@ -99,8 +100,12 @@ def load_library():
         "ocean_frame": (i32, [vp, f32, vp]),
         "ocean_frame_ex": (i32, [vp, ctypes.POINTER(PropagateLocalsC), vp]),
         "ocean_sync": (i32, [vp]),
+        "ocean_set_quirks": (i32, [vp, ctypes.c_uint32]),
+        "ocean_quirks": (ctypes.c_uint32, [vp]),
         "ocean_normals": (i32, [vp, i32, vp]),
         "ocean_read_normals": (i32, [vp, vp]),
+        "ocean_positions": (i32, [vp, i32, f32, f32, vp]),
+        "ocean_read_positions": (i32, [vp, vp]),
         "ocean_read_displacement": (i32, [vp, vp]),
         "ocean_read_field": (i32, [vp, i32, vp]),
         "ocean_write_field": (i32, [vp, i32, vp]),

@@ -41,6 +41,9 @@ public:
         check(ocean_upload_spectrum(ctx_, reinterpret_cast<const float*>(h0.data()), omega.data()));
     }
     void frame(float time, void* stream = nullptr) { check(ocean_frame(ctx_, time, stream)); }
+    // SURVEY 8a Q1/Q2 switches; OCEAN_QUIRKS_REFERENCE (default) = the shipped shaders
+    void set_quirks(uint32_t quirks) { check(ocean_set_quirks(ctx_, quirks)); }
+    uint32_t quirks() const { return ocean_quirks(ctx_); }
     void sync() { check(ocean_sync(ctx_)); }
     std::vector<float> read_displacement() {
         std::vector<float> out((size_t)resolution() * resolution() * 4);

@@ -58,10 +58,13 @@ struct OceanContext {
     c32* tw = nullptr;          // e^{+2 pi i k/N}
     float4* out_own = nullptr;  // displacement map (src/render.rs:820-869), linear RGBA32F
     float4* out = nullptr;      // = out_own or the caller's buffer (ocean_bind_displacement)
-    float4* normals = nullptr;  // allocated on first ocean_normals call
+    float4* normals = nullptr;    // allocated on first ocean_normals call
+    float4* positions = nullptr;  // ocean_positions: verts x verts float4, (re)allocated on demand
+    int32_t position_verts = 0;
     bool uploaded = false;
     bool pass2_thin = true;           // OCEAN_PASS2=fat selects the 1024-thread variant (A/B measurements)
     float default_domain = 1000.0f;   // src/render.rs:46
+    uint32_t quirks = OCEAN_QUIRKS_REFERENCE;   // ocean_set_quirks
     std::string err;
 };
 struct OceanFft { uint32_t magic = MAGIC_FFT; OceanContext* ctx = nullptr; };
@@ -211,7 +214,7 @@ hipStream_t pick(OceanContext* c, void* stream) { return stream ? (hipStream_t)s
 void launch_propagate(OceanContext* c, float time, float domain, hipStream_t s) {
     const unsigned grid = (unsigned)(((size_t)c->n * c->n / 2 + 255) / 256);
     hipLaunchKernelGGL(k_propagate, dim3(grid), dim3(256), 0, s, c->h0, c->omega, c->field[OCEAN_FIELD_DY],
-                       c->field[OCEAN_FIELD_DX], c->field[OCEAN_FIELD_DZ], c->n, time, domain);
+                       c->field[OCEAN_FIELD_DX], c->field[OCEAN_FIELD_DZ], c->n, time, domain, c->quirks);
 }
 void launch_correct(OceanContext* c, hipStream_t s) {
     const unsigned grid = (unsigned)(((size_t)c->n * c->n / 2 + 255) / 256);
@@ -221,6 +224,13 @@ void launch_correct(OceanContext* c, hipStream_t s) {
 void launch_rows(OceanContext* c, int f, hipStream_t s) { OCEAN_DISPATCH(c->n, L::rows(c, c->field[f], s)); }
 void launch_cols(OceanContext* c, int f, hipStream_t s) { OCEAN_DISPATCH(c->n, L::cols(c, c->field[f], s)); }
 void launch_frame(OceanContext* c, float time, float domain, hipStream_t s) {
+    if (c->quirks != OCEAN_QUIRKS_REFERENCE) {      // the fused kernels implement the reference's arithmetic only
+        launch_propagate(c, time, domain, s);
+        for (int f = 0; f < 3; ++f) launch_rows(c, f, s);
+        for (int f = 0; f < 3; ++f) launch_cols(c, f, s);
+        launch_correct(c, s);
+        return;
+    }
     OCEAN_DISPATCH(c->n, { L::pass1(c, time, domain, s); L::pass2(c, s); });
 }
 
@@ -233,7 +243,7 @@ int32_t check_launch(OceanContext* c, const char* what) {
 void free_all(OceanContext* c) {
     auto f = [](void* p) { if (p) (void)hipFree(p); };
     f(c->h0); f(c->omega); f(c->field[0]); f(c->field[1]); f(c->field[2]);
-    f(c->h0T); f(c->omegaT); f(c->inter); f(c->nyq); f(c->tw); f(c->out_own); f(c->normals);
+    f(c->h0T); f(c->omegaT); f(c->inter); f(c->nyq); f(c->tw); f(c->out_own); f(c->normals); f(c->positions);
     if (c->ev_a) (void)hipEventDestroy(c->ev_a);
     if (c->ev_b) (void)hipEventDestroy(c->ev_b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -503,6 +513,14 @@ int32_t ocean_frame_ex(OceanContext* ctx, const OceanPropagateLocals* locals, vo
     launch_frame(ctx, locals->time, locals->domain_size, pick(ctx, stream));
     return check_launch(ctx, "k_frame_pass1/2 launch");
 }
+int32_t ocean_set_quirks(OceanContext* ctx, uint32_t quirks) {
+    if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    if (quirks & ~OCEAN_QUIRKS_REFERENCE) return fail(ctx, OCEAN_E_INVALID_ARG, "unknown quirk bits");
+    ctx->quirks = quirks;
+    return OCEAN_OK;
+}
+uint32_t ocean_quirks(const OceanContext* ctx) { return valid(ctx) ? ctx->quirks : 0u; }
+
 int32_t ocean_frame(OceanContext* ctx, float time, void* stream) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
     OceanPropagateLocals l{time, ctx->n, ctx->default_domain};
@@ -526,6 +544,34 @@ int32_t ocean_read_normals(OceanContext* ctx, float* host_xyz0) {
     DeviceGuard guard(ctx->device);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(host_xyz0, ctx->normals, (size_t)ctx->n * ctx->n * sizeof(float4), hipMemcpyDeviceToHost));
+    return OCEAN_OK;
+}
+
+int32_t ocean_positions(OceanContext* ctx, int32_t verts, float offset_x, float offset_z, void* stream) {
+    if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    if (verts < 2 || verts > 16384) return fail(ctx, OCEAN_E_INVALID_ARG, "verts must be in [2, 16384]");
+    DeviceGuard guard(ctx->device);
+    const size_t nv = (size_t)verts * verts;
+    if (ctx->position_verts != verts) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->positions) (void)hipFree(ctx->positions);
+        ctx->positions = nullptr;
+        ctx->position_verts = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->positions, nv * sizeof(float4)));
+        ctx->position_verts = verts;
+    }
+    hipLaunchKernelGGL(k_positions, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, pick(ctx, stream),
+                       (const float4*)ctx->out, ctx->positions, ctx->n, verts, offset_x, offset_z);
+    return check_launch(ctx, "k_positions launch");
+}
+int32_t ocean_read_positions(OceanContext* ctx, float* host_xyz1) {
+    if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    if (!host_xyz1) return fail(ctx, OCEAN_E_INVALID_ARG, "NULL output");
+    if (!ctx->positions) return fail(ctx, OCEAN_E_STATE, "ocean_positions has not been called");
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(host_xyz1, ctx->positions, (size_t)ctx->position_verts * ctx->position_verts * sizeof(float4),
+                           hipMemcpyDeviceToHost));
     return OCEAN_OK;
 }
 
@@ -598,6 +644,8 @@ static int32_t profile_common(OceanContext* ctx, float time, int32_t cap, const 
                              ctx->half ? "k_half_pass2" : (ctx->pass2_thin ? "k_frame_pass2_thin" : "k_frame_pass2")};
     const int count = staged ? 8 : 2;
     if (cap < count) return fail(ctx, OCEAN_E_INVALID_ARG, "capacity too small");
+    if (!staged && ctx->quirks != OCEAN_QUIRKS_REFERENCE)
+        return fail(ctx, OCEAN_E_STATE, "the fused kernels implement the reference quirks only (ocean_set_quirks)");
     DeviceGuard guard(ctx->device);
     hipStream_t s = ctx->stream;
     hipEvent_t ev[9], kev[4];

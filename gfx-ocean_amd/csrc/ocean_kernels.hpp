@@ -35,6 +35,15 @@ __device__ __forceinline__ int xcd_contiguous(int b, int nblocks) {
 __device__ __forceinline__ float wave_index_q1(uint32_t g, uint32_t n) {
     return (float)(uint32_t)(2u * g - n - 1u);
 }
+// Quirk switches of the staged path (include/ocean_hip.h OCEAN_QUIRK_*).  Both set = the reference.
+//   Q1 off: the wave index 2g - N - 1 is evaluated signed (what the shader's author meant).
+//   Q2 off: the "-k" partner of texel g is (N + 1 - g) % N on both axes (k is antisymmetric about (N+1)/2;
+//           the two texels without a partner, g = 0 and 1, pair with each other) and enters conjugated.
+#define OCEAN_QUIRK_Q1 1u
+#define OCEAN_QUIRK_Q2 2u
+__device__ __forceinline__ float wave_index(uint32_t g, uint32_t n, uint32_t quirks) {
+    return (quirks & OCEAN_QUIRK_Q1) ? wave_index_q1(g, n) : (float)((int32_t)(2u * g) - (int32_t)n - 1);
+}
 
 // The per-texel math of propagate.comp:55-71, shared by the staged and the fused kernel.
 // h = h0 * e^{+i w t} + h0[index_neg] * e^{-i w t}   (:55-62; no conjugate, quirk Q2)
@@ -76,7 +85,7 @@ __device__ __forceinline__ c32 mul_minus_i_kn(float kn, c32 h) { return yx(h) * 
 // One thread per 2 texels.  grid = N*N/2/256.
 __global__ void __launch_bounds__(256)
 k_propagate(const c32* __restrict__ h0, const float* __restrict__ omega, c32* __restrict__ height,
-            c32* __restrict__ disp_x, c32* __restrict__ disp_z, int n, float time, float domain_size) {
+            c32* __restrict__ disp_x, c32* __restrict__ disp_z, int n, float time, float domain_size, uint32_t quirks) {
     const uint32_t un = (uint32_t)n;
     const uint32_t pair = blockIdx.x * 256u + threadIdx.x;
     const uint32_t total = un * un;
@@ -84,13 +93,16 @@ k_propagate(const c32* __restrict__ h0, const float* __restrict__ omega, c32* __
     if (index >= total) return;
     const uint32_t gx = index % un, gy = index / un;               // gx even, gx+1 same row
     const float4 own = *reinterpret_cast<const float4*>(h0 + index);
-    // index_neg = N*N-1-index (:48); the pair (index, index+1) mirrors to (ineg, ineg-1)
-    const uint32_t ineg = total - 1u - index;
-    const float4 neg = *reinterpret_cast<const float4*>(h0 + (ineg - 1u));
+    // index_neg = N*N-1-index (:48); the pair (index, index+1) mirrors to (ineg, ineg-1).  With Q2 off the
+    // partners are columns ((N+1-gx)%N, (N-gx)%N) of row (N+1-gy)%N: the same reversed pair, other base.
+    const bool q2 = (quirks & OCEAN_QUIRK_Q2) != 0u;
+    const uint32_t pbase = q2 ? (total - 2u - index) : (((un + 1u - gy) & (un - 1u)) * un + ((un - gx) & (un - 1u)));
+    float4 neg = *reinterpret_cast<const float4*>(h0 + pbase);
+    if (!q2) { neg.y = -neg.y; neg.w = -neg.w; }                   // conjugated partner
     const c32 om = *reinterpret_cast<const c32*>(omega + index);
-    const float ky = OCEAN_PI_F * wave_index_q1(gy, un) / domain_size;
-    const float kx0 = OCEAN_PI_F * wave_index_q1(gx, un) / domain_size;
-    const float kx1 = OCEAN_PI_F * wave_index_q1(gx + 1u, un) / domain_size;
+    const float ky = OCEAN_PI_F * wave_index(gy, un, quirks) / domain_size;
+    const float kx0 = OCEAN_PI_F * wave_index(gx, un, quirks) / domain_size;
+    const float kx1 = OCEAN_PI_F * wave_index(gx + 1u, un, quirks) / domain_size;
     const c32 h0v = propagate_height(mk(own.x, own.y), mk(neg.z, neg.w), om.x, time);
     const c32 h1v = propagate_height(mk(own.z, own.w), mk(neg.x, neg.y), om.y, time);
     float knx0, kny0, knx1, kny1;
@@ -144,6 +156,36 @@ k_normals(const float4* __restrict__ rgba, float4* __restrict__ normals, int n, 
     const float cx = nay * nbz, cy = -nax * nbz, cz = nax * nby;
     const float lc = sqrtf(cx * cx + cy * cy + cz * cz);
     normals[index] = make_float4(cx / lc, cy / lc, cz / lc, 0.0f);
+}
+
+// SURVEY 8f #2 -- the vertex stage's consumer of the map (shader/ocean.vert:21-25) as a compute kernel: the
+// V x V patch grid of src/render.rs:494-508 (a_Pos = (x, 0, z), a_Uv = (x, z) / (V - 1); V = HALF_RESOLUTION
+// = 128 in the reference), the displacement sampled with the reference's sampler (Filter::Linear,
+// WrapMode::Tile, src/render.rs:398: bilinear at texel coordinates uv * N - 0.5 with wrap, weights in fp32),
+// displacement.y /= 3.0, .xz /= 3.5 (:22-23), pos = a_Pos + displacement + (offset.x, 0, offset.y) (:25).
+// One thread per vertex; positions[z * V + x] = (pos.x, pos.y, pos.z, 1).
+__global__ void __launch_bounds__(256)
+k_positions(const float4* __restrict__ rgba, float4* __restrict__ positions, int n, int verts, float offset_x,
+            float offset_z) {
+    const uint32_t index = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t uv_ = (uint32_t)verts;
+    if (index >= uv_ * uv_) return;
+    const uint32_t vx = index % uv_, vz = index / uv_;
+    const float inv = 1.0f / (float)(verts - 1);
+    const float u = (float)vx * inv, v = (float)vz * inv;          // src/render.rs:503-504
+    const float tx = u * (float)n - 0.5f, ty = v * (float)n - 0.5f;
+    const float fx = floorf(tx), fy = floorf(ty);
+    const float wx = tx - fx, wy = ty - fy;
+    const uint32_t mask = (uint32_t)n - 1u;                        // N is a power of two: Tile wrap
+    const uint32_t x0 = (uint32_t)(int32_t)fx & mask, x1 = (x0 + 1u) & mask;
+    const uint32_t y0 = (uint32_t)(int32_t)fy & mask, y1 = (y0 + 1u) & mask;
+    const float4 a = rgba[(size_t)y0 * n + x0], b = rgba[(size_t)y0 * n + x1];
+    const float4 c = rgba[(size_t)y1 * n + x0], d = rgba[(size_t)y1 * n + x1];
+    const float w00 = (1.0f - wx) * (1.0f - wy), w10 = wx * (1.0f - wy), w01 = (1.0f - wx) * wy, w11 = wx * wy;
+    const float dx = a.x * w00 + b.x * w10 + c.x * w01 + d.x * w11;
+    const float dy = a.y * w00 + b.y * w10 + c.y * w01 + d.y * w11;
+    const float dz = a.z * w00 + b.z * w10 + c.z * w01 + d.z * w11;
+    positions[index] = make_float4((float)vx + dx / 3.5f + offset_x, dy / 3.0f, (float)vz + dz / 3.5f + offset_z, 1.0f);
 }
 
 // LDS pitch of one line buffer: padded line + 4 elements so that P adjacent lines do not alias.

@@ -8,6 +8,8 @@ import numpy as np
 
 from ._lib import OCEAN_OK, OceanError, load_library
 from .fft import FIELD_ALL, FIELD_DX, FIELD_DY, FIELD_DZ, Fft
+
+QUIRK_Q1, QUIRK_Q2, QUIRKS_REFERENCE = 1, 2, 3      # include/ocean_hip.h OCEAN_QUIRK_*
 from .ocean import DOMAIN_SIZE, Correction, CorrectionLocals, Propagation, PropagateLocals
 
 
@@ -70,6 +72,16 @@ class OceanDevice:
     def spectrum_scale_log2(self) -> int:
         return int(load_library().ocean_spectrum_scale_log2(self._ctx))
 
+    # -- quirk switches (include/ocean_hip.h OCEAN_QUIRK_*) ---------------------------
+    @property
+    def quirks(self) -> int:
+        return int(load_library().ocean_quirks(self._ctx))
+
+    def set_quirks(self, quirks: int):
+        """QUIRKS_REFERENCE (default) = the shipped shaders; clear QUIRK_Q1 for a signed wave index,
+        QUIRK_Q2 for the conjugated (N+1-g) % N partner.  Non-reference settings run the staged kernels."""
+        self._check(load_library().ocean_set_quirks(self._ctx, int(quirks)))
+
     # -- fused frame ---------------------------------------------------------------------------------
     def frame(self, time: float, domain_size: float = DOMAIN_SIZE, stream=None):
         loc = PropagateLocals(time, self.resolution, domain_size)._c()
@@ -89,6 +101,17 @@ class OceanDevice:
         return out
 
     # -- readback / injection ----------------------------------------------------------------------
+
+    # -- vertex-stage positions (shader/ocean.vert:21-25) ----------------------------------
+    def positions(self, verts: int = 128, offset=(0.0, 0.0), stream=None) -> np.ndarray:
+        """World positions of a verts x verts patch (src/render.rs:494-508) displaced by the current map,
+        sampled bilinearly with wrap as the reference's sampler does.  -> float32 [verts, verts, 4]."""
+        lib = load_library()
+        self._check(lib.ocean_positions(self._ctx, int(verts), float(offset[0]), float(offset[1]), stream))
+        out = np.empty((verts, verts, 4), np.float32)
+        self._check(lib.ocean_read_positions(self._ctx, out.ctypes.data))
+        return out
+
     def read_displacement(self) -> np.ndarray:
         n = self.resolution
         out = np.empty((n, n, 4), dtype=np.float32)

@@ -44,7 +44,11 @@ extern "C" {
     pub fn ocean_frame_ex(ctx: *mut OceanContext, locals: *const OceanPropagateLocals, stream: *mut c_void) -> i32;
     pub fn ocean_normals(ctx: *mut OceanContext, source_channel: i32, stream: *mut c_void) -> i32;
     pub fn ocean_read_normals(ctx: *mut OceanContext, host_xyz0: *mut f32) -> i32;
+    pub fn ocean_positions(ctx: *mut OceanContext, verts: i32, offset_x: f32, offset_z: f32, stream: *mut c_void) -> i32;
+    pub fn ocean_read_positions(ctx: *mut OceanContext, host_xyz1: *mut f32) -> i32;
     pub fn ocean_sync(ctx: *mut OceanContext) -> i32;
+    pub fn ocean_set_quirks(ctx: *mut OceanContext, quirks: u32) -> i32;
+    pub fn ocean_quirks(ctx: *const OceanContext) -> u32;
     pub fn ocean_read_displacement(ctx: *mut OceanContext, host_rgba: *mut f32) -> i32;
     pub fn ocean_read_field(ctx: *mut OceanContext, field: i32, host_re_im: *mut f32) -> i32;
     pub fn ocean_write_field(ctx: *mut OceanContext, field: i32, host_re_im: *const f32) -> i32;

@@ -23,6 +23,11 @@ use std::ffi::CStr;
 use std::fmt;
 use std::ptr;
 
+/// SURVEY 8a quirk switches (include/ocean_hip.h `OCEAN_QUIRK_*`).
+pub const QUIRK_Q1_UINT_WAVE_INDEX: u32 = 1;
+pub const QUIRK_Q2_MIRROR_NO_CONJ: u32 = 2;
+pub const QUIRKS_REFERENCE: u32 = 3;
+
 #[derive(Debug)]
 pub struct OceanError { pub status: i32, pub message: String }
 impl fmt::Display for OceanError {
@@ -49,6 +54,10 @@ impl Device {
     }
     pub fn frame(&self, time: f32) -> Result<(), Box<dyn Error>> {
         self.check(unsafe { ffi::ocean_frame(self.ctx, time, ptr::null_mut()) })
+    }
+    /// SURVEY 8a Q1/Q2 switches; `QUIRKS_REFERENCE` (default) is the shipped shaders' arithmetic.
+    pub fn set_quirks(&self, quirks: u32) -> Result<(), Box<dyn Error>> {
+        self.check(unsafe { ffi::ocean_set_quirks(self.ctx, quirks) })
     }
     pub fn read_displacement(&self, rgba: &mut [f32]) -> Result<(), Box<dyn Error>> {
         self.check(unsafe { ffi::ocean_read_displacement(self.ctx, rgba.as_mut_ptr()) })

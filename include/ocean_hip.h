@@ -115,12 +115,33 @@ int32_t ocean_correct(OceanCorrection* c, const OceanCorrectionLocals* locals, v
 int32_t ocean_frame(OceanContext* ctx, float time, void* stream);
 int32_t ocean_frame_ex(OceanContext* ctx, const OceanPropagateLocals* locals, void* stream);
 
+/* Quirk switches.  Default = OCEAN_QUIRKS_REFERENCE = the shipped shaders' arithmetic.
+ *   Q1 (shader/propagate.comp:45-46,50-53): the wave index 2g - N - 1 is evaluated in uint and wraps for g <= N/2;
+ *      off = signed.
+ *   Q2 (shader/propagate.comp:48,59-62): the "-k" partner is texel N-1-g and is NOT conjugated; off = the partner
+ *      is (N+1-g) % N on both axes (k(g) = -k(N+1-g); g = 0 and 1 pair with each other) and enters conjugated.
+ * Every entry point honours the setting; with a non-reference setting ocean_frame runs the eight staged
+ * dispatches (the fused kernels implement the reference only) and therefore updates the field buffers. */
+#define OCEAN_QUIRK_Q1_UINT_WAVE_INDEX 1u
+#define OCEAN_QUIRK_Q2_MIRROR_NO_CONJ 2u
+#define OCEAN_QUIRKS_REFERENCE 3u
+int32_t ocean_set_quirks(OceanContext* ctx, uint32_t quirks);
+uint32_t ocean_quirks(const OceanContext* ctx);
+
 /* the reference's normal field (shader/ocean.frag:50-66: finite differences of the
  * displacement map with Tile wrap, height_scale 180) as a compute pass over the current
  * displacement map.  source_channel 0 = disp_x (what the reference differentiates, quirk Q5),
  * 1 = height.  Result: float4[N*N] = (n.x, n.y, n.z, 0), read with ocean_read_normals. */
 int32_t ocean_normals(OceanContext* ctx, int32_t source_channel, void* stream);
 int32_t ocean_read_normals(OceanContext* ctx, float* host_xyz0 /* N*N*4 */);
+
+/* the vertex stage's use of the map (shader/ocean.vert:21-25) as a compute pass: a verts x verts
+ * patch grid (src/render.rs:494-508; the reference's HALF_RESOLUTION is 128) with a_Pos = (x, 0, z) and
+ * a_Uv = (x, z) / (verts - 1); the displacement map sampled bilinearly with Tile wrap (src/render.rs:398),
+ * y / 3.0, xz / 3.5, plus the patch offset (src/render.rs:540-551).  Result: float4[verts*verts] = (pos, 1),
+ * index z * verts + x, read with ocean_read_positions. */
+int32_t ocean_positions(OceanContext* ctx, int32_t verts, float offset_x, float offset_z, void* stream);
+int32_t ocean_read_positions(OceanContext* ctx, float* host_xyz1 /* verts*verts*4 */);
 
 int32_t ocean_sync(OceanContext* ctx); /* wait for the context stream (the reference never waits: src/render.rs:1068-1075) */
 

@@ -212,22 +212,36 @@ def frame_literal(h0, omega, time, domain_size=DOMAIN_SIZE, return_stages=False)
 # --------------------------------------------------------------------------
 # Independent fp64 formulation (the tolerance anchor).
 # --------------------------------------------------------------------------
-def propagate_f64(h0, omega, time, domain_size=DOMAIN_SIZE):
+QUIRK_Q1, QUIRK_Q2, QUIRKS_REFERENCE = 1, 2, 3
+
+
+def propagate_f64(h0, omega, time, domain_size=DOMAIN_SIZE, quirks=QUIRKS_REFERENCE):
+    """quirks: bit 0 = Q1 (uint wave index, shader/propagate.comp:45-46), bit 1 = Q2 (partner N-1-g, not
+    conjugated, :48,59-62); both set = the reference.  Off: signed wave index; partner (N+1-g) % N, conjugated
+    (include/ocean_hip.h OCEAN_QUIRK_*)."""
     n = h0.shape[0]
-    xf = wave_vector_q1(n).astype(np.float64)           # Q1 incl. the uint->f32 rounding
+    if quirks & QUIRK_Q1:
+        xf = wave_vector_q1(n).astype(np.float64)       # Q1 incl. the uint->f32 rounding
+    else:
+        xf = 2.0 * np.arange(n, dtype=np.float64) - n - 1
     kx = np.broadcast_to(xf[None, :], (n, n))
     ky = np.broadcast_to(xf[:, None], (n, n))
     d = (omega.astype(np.float32) * np.float32(time)).astype(np.float32).astype(np.float64)
     h0c = h0.astype(np.complex128)
-    h = h0c * np.exp(1j * d) + h0c[::-1, ::-1] * np.exp(-1j * d)
+    if quirks & QUIRK_Q2:
+        partner = h0c[::-1, ::-1]
+    else:
+        p = (n + 1 - np.arange(n)) % n
+        partner = np.conj(h0c[np.ix_(p, p)])
+    h = h0c * np.exp(1j * d) + partner * np.exp(-1j * d)
     ln = np.hypot(kx, ky)                               # pi/L cancels in k/|k|
     return h, (-1j * kx / ln) * h, (-1j * ky / ln) * h
 
 
-def frame_f64(h0, omega, time, domain_size=DOMAIN_SIZE):
+def frame_f64(h0, omega, time, domain_size=DOMAIN_SIZE, quirks=QUIRKS_REFERENCE):
     """N^2 * ifft2 (= unnormalised e^{+i} DFT on both axes), sign, real, pack.  float64 [N,N,4]."""
     n = h0.shape[0]
-    h, dx, dz = propagate_f64(h0, omega, time, domain_size)
+    h, dx, dz = propagate_f64(h0, omega, time, domain_size, quirks)
     g = np.arange(n)
     sign = np.where(((g[None, :] + g[:, None]) % 2) == 0, -1.0, 1.0)
     out = np.zeros((n, n, 4), dtype=np.float64)
@@ -288,6 +302,33 @@ def normals_f64(rgba: np.ndarray, channel: int = 0) -> np.ndarray:
     c /= np.linalg.norm(c, axis=-1, keepdims=True)
     out = np.zeros(rgba.shape[:2] + (4,))
     out[..., :3] = c
+    return out
+
+
+# --------------------------------------------------------------------------
+# 8f #2: vertex-stage positions, shader/ocean.vert:21-25 with the sampler of src/render.rs:398
+# --------------------------------------------------------------------------
+def positions_f64(rgba: np.ndarray, verts: int = 128, offset=(0.0, 0.0)) -> np.ndarray:
+    """pos = a_Pos + texture(map, a_Uv).xyz / (3.5, 3.0, 3.5) + (offset.x, 0, offset.y); a_Pos = (x, 0, z),
+    a_Uv = (x, z) / (verts - 1) (src/render.rs:494-508); Filter::Linear + WrapMode::Tile = bilinear at texel
+    coordinates uv * N - 0.5 with wrap (ideal weights; real samplers quantise them to ~8 bits)."""
+    n = rgba.shape[0]
+    r = rgba.astype(np.float64)
+    g = np.arange(verts, dtype=np.float32) * (np.float32(1.0) / np.float32(verts - 1))   # the kernel's fp32 uv
+    t = g.astype(np.float32) * np.float32(n) - np.float32(0.5)
+    t = t.astype(np.float64)
+    f = np.floor(t)
+    w = t - f
+    i0 = f.astype(np.int64) % n
+    i1 = (i0 + 1) % n
+    X0, X1, WX = i0[None, :], i1[None, :], w[None, :, None]
+    Y0, Y1, WY = i0[:, None], i1[:, None], w[:, None, None]
+    s = (r[Y0, X0] * (1 - WX) * (1 - WY) + r[Y0, X1] * WX * (1 - WY) + r[Y1, X0] * (1 - WX) * WY + r[Y1, X1] * WX * WY)
+    out = np.ones((verts, verts, 4))
+    vx = np.arange(verts, dtype=np.float64)
+    out[..., 0] = vx[None, :] + s[..., 0] / 3.5 + offset[0]
+    out[..., 1] = s[..., 1] / 3.0
+    out[..., 2] = vx[:, None] + s[..., 2] / 3.5 + offset[1]
     return out
 
 

@@ -35,7 +35,7 @@ def lib():
         _LIB.emu_frame_half.argtypes = ([ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_float] + [ctypes.c_void_p] * 5 +
                                         [ctypes.c_size_t] * 3 + [ctypes.c_float] * 2)
         _LIB.emu_fft_lines.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
-        _LIB.emu_propagate.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_float] * 2
+        _LIB.emu_propagate.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_float] * 2 + [ctypes.c_uint32]
         _LIB.emu_correct.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4
     return _LIB
 
@@ -57,12 +57,12 @@ def fft_lines(field, col):
     return f
 
 
-def propagate(h0, omega, time, L=1000.0):
+def propagate(h0, omega, time, L=1000.0, quirks=3):
     n = h0.shape[0]
     h0 = np.ascontiguousarray(h0, np.complex64)
     omega = np.ascontiguousarray(omega, np.float32)
     outs = [np.empty((n, n), np.complex64) for _ in range(3)]
-    assert lib().emu_propagate(n, _p(h0), _p(omega), *map(_p, outs), time, L) == 0
+    assert lib().emu_propagate(n, _p(h0), _p(omega), *map(_p, outs), time, L, quirks) == 0
     return tuple(outs)
 
 
@@ -163,4 +163,13 @@ def normals(rgba, channel=0):
     out = np.empty((n, n, 4), np.float32)
     lib().emu_normals.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
     assert lib().emu_normals(n, _p(rgba), _p(out), int(channel)) == 0
+    return out
+
+
+def positions(rgba, verts=128, offset=(0.0, 0.0)):
+    rgba = np.ascontiguousarray(rgba, np.float32)
+    n = rgba.shape[0]
+    out = np.empty((verts, verts, 4), np.float32)
+    lib().emu_positions.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_float]
+    assert lib().emu_positions(n, _p(rgba), _p(out), int(verts), float(offset[0]), float(offset[1])) == 0
     return out

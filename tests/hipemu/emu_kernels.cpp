@@ -130,14 +130,19 @@ int emu_frame_half(int n, int psel, const void* h0T, int f16, float descale, con
     DISPATCH(n, C_)
 #undef C_
 }
+int emu_positions(int n, const float* rgba, float* positions, int verts, float ox, float oz) {
+    const int grid = (verts * verts + 255) / 256;
+    emu_launch(grid, 256, [&] { k_positions((const float4*)rgba, (float4*)positions, n, verts, ox, oz); });
+    return 0;
+}
 int emu_normals(int n, const float* rgba, float* normals, int channel) {
     const int grid = (n * n + 255) / 256;
     emu_launch(grid, 256, [&] { k_normals((const float4*)rgba, (float4*)normals, n, channel); });
     return 0;
 }
-int emu_propagate(int n, const float* h0, const float* omega, float* h, float* dx, float* dz, float time, float L) {
+int emu_propagate(int n, const float* h0, const float* omega, float* h, float* dx, float* dz, float time, float L, unsigned quirks) {
     const int grid = (n * n / 2 + 255) / 256;
-    emu_launch(grid, 256, [&] { k_propagate((const c32*)h0, omega, (c32*)h, (c32*)dx, (c32*)dz, n, time, L); });
+    emu_launch(grid, 256, [&] { k_propagate((const c32*)h0, omega, (c32*)h, (c32*)dx, (c32*)dz, n, time, L, quirks); });
     return 0;
 }
 int emu_correct(int n, const float* h, const float* dx, const float* dz, float* out) {

@@ -23,6 +23,39 @@ def test_emu_propagate_matches_literal(ref_inputs_256):
             assert oc.parity_errors(a, b)[0].max() <= 1e-6
 
 
+@pytest.mark.parametrize("quirks", [0, 1, 2, 3])
+def test_emu_propagate_quirk_switches(ref_inputs_256, quirks):
+    """Q1 (uint wave index) and Q2 (partner N-1-g, not conjugated) are switchable; 3 = reference."""
+    h0, om = ref_inputs_256
+    got = emu.propagate(h0, om, 2.0, quirks=quirks)
+    ref = oc.propagate_f64(h0, om, 2.0, quirks=quirks)
+    for a, b, name in zip(got, ref, ("height", "disp_x", "disp_z")):
+        assert_parity(a, b, 2e-6, f"quirks={quirks} {name}")
+    if quirks != 3:       # and they do change the result
+        refq = oc.propagate_f64(h0, om, 2.0)
+        assert max(oc.parity_errors(a, b)[0].max() for a, b in zip(got, refq)) > 1e-2
+
+
+def test_quirk_free_spectrum_of_a_hermitian_field_gives_a_real_surface():
+    """With Q1 and Q2 off the propagation is the textbook one: if h0 is Hermitian under the (N+1-g) % N pairing
+    the propagated spectra are too, except on the two self-paired lines g in {0, 1} x anything."""
+    n = 64
+    rng = np.random.default_rng(7)
+    a = (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))).astype(np.complex64)
+    p = (n + 1 - np.arange(n)) % n
+    h0 = ((a + np.conj(a[np.ix_(p, p)])) / 2).astype(np.complex64)
+    om = rng.uniform(0.1, 3.0, (n, n)).astype(np.float32)
+    om = ((om + om[np.ix_(p, p)]) / 2).astype(np.float32)
+    h, dx, dz = oc.propagate_f64(h0, om, 1.5, quirks=0)
+    assert np.abs(h - np.conj(h[np.ix_(p, p)])).max() < 1e-6 * np.abs(h).max()
+    for f in (dx, dz):                                   # k(p(g)) = -k(g) needs g >= 2 on both axes
+        d = (f - np.conj(f[np.ix_(p, p)]))[2:, 2:]
+        assert np.abs(d).max() < 1e-6 * np.abs(f).max()
+    # ... which is not the case with the reference's quirks
+    hq = oc.propagate_f64(h0, om, 1.5)[0]
+    assert np.abs(hq - np.conj(hq[np.ix_(p, p)])).max() > 1e-2 * np.abs(hq).max()
+
+
 @pytest.mark.parametrize("n,col", [(256, 0), (256, 1), (512, 0), (512, 1), (1024, 0), (1024, 1)])
 def test_emu_fft_lines(n, col):
     rng = np.random.default_rng(100 + n + col)
@@ -81,6 +114,19 @@ def test_emu_normals(ref_inputs_256, channel):
     assert np.abs(got - ref).max() <= 2e-6
     assert np.abs(got[..., :3] - oc.normals_f64(rgba, channel)[..., :3]).max() <= 2e-6
     assert np.allclose(np.linalg.norm(got[..., :3], axis=-1), 1.0, atol=1e-6) and np.all(got[..., 3] == 0)
+
+
+@pytest.mark.parametrize("verts,offset", [(128, (0.0, 0.0)), (128, (127.0, 127.0)), (33, (5.0, -2.0))])
+def test_emu_positions(ref_inputs_256, verts, offset):
+    """SURVEY 8f #2: k_positions vs the restatement of shader/ocean.vert:21-25 (bilinear sampler with Tile wrap)."""
+    h0, om = ref_inputs_256
+    rgba = oc.frame_literal(h0, om, 2.0)
+    got = emu.positions(rgba, verts, offset)
+    ref = oc.positions_f64(rgba, verts, offset)
+    assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max() / 8)      # fp32 on coordinates up to ~260
+    assert np.all(got[..., 3] == 1.0)
+    # the last grid line samples uv = 1: wraps onto the first texel column, as the Tile sampler does
+    assert np.abs((got[:, -1, 1] - got[:, 0, 1])).max() < 1e-6
 
 
 @pytest.mark.parametrize("P", [4, 2])

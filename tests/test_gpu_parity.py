@@ -226,6 +226,20 @@ def test_normal_field(r512, ref_inputs, channel):
     assert np.allclose(np.linalg.norm(got[..., :3], axis=-1), 1.0, atol=1e-5)
 
 
+@pytest.mark.parametrize("verts,offset", [(128, (0.0, 0.0)), (128, (127.0, 127.0)), (257, (0.0, 0.0))])
+def test_vertex_positions(r512, ref_inputs, verts, offset):
+    """the vertex stage's positions (shader/ocean.vert:21-25; patch grid and offsets of
+    src/render.rs:494-551) from the current displacement map."""
+    r512.render_fused(2.0)
+    rgba = r512.displacement()
+    got = r512.device.positions(verts, offset)
+    ref = oc.positions_f64(rgba, verts, offset)          # same fp32 map in
+    assert np.abs(got - ref).max() <= 1e-4
+    ref64 = oc.positions_f64(oc.frame_f64(*ref_inputs, 2.0), verts, offset)
+    assert np.abs(got - ref64).max() <= 1e-3             # absolute, on coordinates up to ~260
+    assert np.all(got[..., 3] == 1.0)
+
+
 @pytest.mark.parametrize("n", [512, 8192])
 def test_config5_fp16_spectrum(n, ref_inputs):
     """BASELINE config 5: fp16 spectrum / fp32 accumulate (N = 8192 is the configured size; 512 uses the
@@ -261,6 +275,36 @@ def test_config5_fp16_spectrum(n, ref_inputs):
                 assert np.all(np.abs(out[y, x, :3] - ref) <= TOL * scale), (x, y, out[y, x, :3], ref)
     finally:
         d.destroy()
+
+
+@pytest.mark.parametrize("quirks", [0, 1, 2])
+def test_quirk_switches(ref_inputs, quirks):
+    """Q1/Q2 off through the C ABI; every entry point honours the setting (ocean_frame then runs the
+    staged kernels), and the reference setting is restored bit for bit."""
+    h0, om = ref_inputs
+    r = g.OceanRenderer(512)
+    try:
+        r.upload(h0, om)
+        r.render_fused(3.0)
+        ref_out = r.displacement()
+        r.device.set_quirks(quirks)
+        assert r.device.quirks == quirks
+        want = oc.frame_f64(h0, om, 3.0, quirks=quirks)[..., :3]
+        r.render(3.0)
+        staged = r.displacement()
+        assert_parity(staged[..., :3], want, TOL, f"staged quirks={quirks}")
+        r.render_fused(3.0)
+        assert np.array_equal(r.displacement(), staged)
+        assert oc.parity_errors(staged[..., :3], ref_out[..., :3])[0].max() > 1e-2
+        with pytest.raises(g.OceanError):
+            r.device.profile_frame(0.0)              # the fused kernels are reference-only
+        with pytest.raises(g.OceanError):
+            r.device.set_quirks(4)
+        r.device.set_quirks(g.QUIRKS_REFERENCE)
+        r.render_fused(3.0)
+        assert np.array_equal(r.displacement(), ref_out)
+    finally:
+        r.dispose()
 
 
 def test_time_is_stateless(r512, ref_inputs):

@@ -9,7 +9,7 @@ using namespace ocean;
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void st4(c32* p, float4 v, bool nt) { if (nt) { v4f t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(p)); } else *reinterpret_cast<float4*>(p) = v; }
-__device__ __forceinline__ c32 ld2(const c32* p, bool nt) { if (nt) { v2f t = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(p)); return make_float2(t.x, t.y); } return *p; }
+__device__ __forceinline__ c32 ld2(const c32* p, bool nt) { if (nt) { v2f t = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(p)); return mk(t.x, t.y); } return *p; }
 __device__ __forceinline__ float ld1(const float* p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -96,7 +96,7 @@ x_pass1(const c32* __restrict__ h0T, const float* __restrict__ omegaT, c32* __re
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int y = j + e * T;
-        if (MODE & 2) { const c32 a = ld2(own + y, MODE & 32), m = ld2(mir + (N - 1 - y), MODE & 32); const float w = ld1(om + y, MODE & 32); hs[e] = make_float2(a.x + m.x * w, a.y + m.y); }
+        if (MODE & 2) { const c32 a = ld2(own + y, MODE & 32), m = ld2(mir + (N - 1 - y), MODE & 32); const float w = ld1(om + y, MODE & 32); hs[e] = mk(a.x + m.x * w, a.y + m.y); }
         else hs[e] = propagate_height(ld2(own + y, MODE & 32), ld2(mir + (N - 1 - y), MODE & 32), ld1(om + y, MODE & 32), time);
     }
     c32* out_group = inter + (size_t)X * sx;
@@ -107,7 +107,7 @@ x_pass1(const c32* __restrict__ h0T, const float* __restrict__ omegaT, c32* __re
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             if (f == 1) reg[e] = hs[e];
-            else if (MODE & 2) reg[e] = make_float2(hs[e].y * (float)f, -hs[e].x);
+            else if (MODE & 2) reg[e] = mk(hs[e].y * (float)f, -hs[e].x);
             else {
                 const float ky = wave_index_q1((uint32_t)(jf + e * T), N) * kscale;
                 float knx, kny;
@@ -169,8 +169,8 @@ x_pass2_fat(const c32* __restrict__ inter, float4* __restrict__ out, const c32* 
 #pragma unroll
         for (int q = 0; q < E / 2; ++q) {
             const int x0 = (xi + q * XSTEP) * P + 2 * h;
-            lds_r[lds_pad(x0)] = make_float2(v[q].x, v[q].y);
-            lds_r[lds_pad(x0 + 1)] = make_float2(v[q].z, v[q].w);
+            lds_r[lds_pad(x0)] = mk(v[q].x, v[q].y);
+            lds_r[lds_pad(x0 + 1)] = mk(v[q].z, v[q].w);
         }
         __syncthreads();
         c32 reg[E];
@@ -224,7 +224,7 @@ __device__ __forceinline__ void x_load_AB(const c32* __restrict__ h0T, const flo
         else w2 = (om2 + (N - (e + 1) * T))[T - jj];
         A[e] = propagate_height(a, m, w, time);
         const c32 h2 = propagate_height(a2, m2, w2, time);
-        B[e] = make_float2(h2.x, -h2.y);
+        B[e] = mk(h2.x, -h2.y);
     }
 }
 
@@ -251,8 +251,8 @@ x_half_pass1(const c32* __restrict__ h0T, const float* __restrict__ omegaT, c32*
             const int f = (c < 3) ? c : 2;
             c32 A[E], B[E], reg[E];
             half_load_AB<N, E, false>(h0T, 1.0f, omegaT, (uint32_t)(N / 2), j, time, A, B);
-            const float kxn = wave_index_q1((uint32_t)(N / 2), N) * kscale;
-            half_spectrum<N, E>(f, A, B, kxn, kxn, kscale, j, reg);
+            const c32 kxn = xx(mk(wave_index_q1((uint32_t)(N / 2), N) * kscale, 0.0f));
+            half_spectrum<N, E>(f, A, B, kxn, kscale, j, reg);
             fft_line<N, E>(reg, j, tw, lds_line);
             if (c < 3) {
 #pragma unroll
@@ -272,14 +272,13 @@ x_half_pass1(const c32* __restrict__ h0T, const float* __restrict__ omegaT, c32*
     if (MODE & 4) {
         const c32* own = h0T + (size_t)x * N; const c32* mir = h0T + (size_t)(N - 1 - x) * N; const float* om = omegaT + (size_t)x * N;
 #pragma unroll
-        for (int e = 0; e < E; ++e) { const int y = j + e * T; A[e] = propagate_height(own[y], mir[N - 1 - y], om[y], time); B[e] = make_float2(A[e].x, -A[e].y); }
+        for (int e = 0; e < E; ++e) { const int y = j + e * T; A[e] = propagate_height(own[y], mir[N - 1 - y], om[y], time); B[e] = mk(A[e].x, -A[e].y); }
     } else {
         if (MODE & 512) x_load_AB<N, E, 1>(h0T, omegaT, x, j, time, A, B);
         else if (MODE & 1024) x_load_AB<N, E, 3>(h0T, omegaT, x, j, time, A, B);
         else half_load_AB<N, E, false>(h0T, 1.0f, omegaT, x, j, time, A, B);
     }
-    const float kx1 = wave_index_q1(x, N) * kscale;
-    const float kx2 = wave_index_q1(x2, N) * kscale;
+    const c32 kxv = mk(wave_index_q1(x, N), wave_index_q1(x2, N)) * kscale;
     const int h = tid % H2;
     const int i = tid / H2;
     const c32* l0 = lds + (2 * h) * LinePitch<N>::elems;
@@ -289,7 +288,7 @@ x_half_pass1(const c32* __restrict__ h0T, const float* __restrict__ omegaT, c32*
     for (int f = 0; f < 3; ++f) {
         c32 reg[E];
         const int jf = opaque_lane(j);
-        half_spectrum<N, E>(f, A, B, kx1, kx2, kscale, jf, reg);
+        half_spectrum<N, E>(f, A, B, kxv, kscale, jf, reg);
         if (MODE & 256) { asm volatile("" :: "v"(reg[E - 1].x)); STAMP(2 + 3 * f); }
         if (f > 0) __syncthreads();
         if (MODE & 2) {
@@ -338,7 +337,7 @@ int main() {
     CK(hipMemcpy(omT, r.data(), n2 * 4, hipMemcpyHostToDevice));
     for (int f = 0; f < 3; ++f) CK(hipMemcpy(inter + f * fs, r.data(), n2 * 8, hipMemcpyHostToDevice));
     std::vector<c32> t(N);
-    for (int i = 0; i < N; ++i) t[i] = make_float2((float)cos(2 * M_PI * i / N), (float)sin(2 * M_PI * i / N));
+    for (int i = 0; i < N; ++i) t[i] = mk((float)cos(2 * M_PI * i / N), (float)sin(2 * M_PI * i / N));
     CK(hipMemcpy(tw, t.data(), N * 8, hipMemcpyHostToDevice));
     for (int layout = 0; layout < 2; ++layout) {
         // layout 0: pass-1-contiguous (chunk(X,Y) = X*slab + Y*16); layout 1: pass-2-contiguous (Y*slabY + X*16)
@@ -402,7 +401,7 @@ int main() {
         }
         auto k2 = k_half_pass2<N, G::E, G::P, G::R2>;
         CK(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, G::thin_lds));
-        float ms = time_ms([&] { hipLaunchKernelGGL(k2, dim3(G::thin_grid), dim3(G::thin_threads), G::thin_lds, 0, inter, nyq, out, tw, lh); });
+        float ms = time_ms([&] { hipLaunchKernelGGL(k2, dim3(G::thin_grid), dim3(G::thin_threads), G::thin_lds, 0, inter, out, tw, lh); });
         printf("{\"kernel\":\"half_pass2\",\"ms\":%.4f}\n", ms);
     }
     return 0;
