@@ -91,6 +91,57 @@ def cpu_baseline(n, h0, omega, budget_s=10.0, max_frames=12):
                       f"{hw} hardware threads), radix-2 Stockham with sincosf per butterfly as in the shaders"}
 
 
+def gather_leg(dev, dist, torch, n, n_gpus, rank, steps):
+    """BASELINE config 4 / SURVEY 8e: every tile's RGBA map gathered to rank 0 with one RCCL collective per frame
+    (root ingest N*N*16 B per peer over xGMI).  Two schedules, both reported, neither part of `value`:
+    `ordered`   -- frame and collective on one stream;
+    `overlapped` -- two output buffers; the collective of frame f runs on a second stream while frame f+1 is
+                    computed (the frame is ~0.2 ms, the root's ingest of 7 x 256 MiB ~1.8 ms: the pipeline is
+                    gather-bound and the overlap hides the compute, not the other way round)."""
+    outs = [torch.empty((n, n, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+    dsts = [[torch.empty_like(outs[0]) for _ in range(n_gpus)] if rank == 0 else None for _ in range(2)]
+    cs, gs = torch.cuda.Stream(), torch.cuda.Stream()
+    frame_done = [torch.cuda.Event() for _ in range(2)]
+    gather_done = [torch.cuda.Event() for _ in range(2)]
+
+    def run(count, overlapped):
+        for i in range(count):
+            b = i % 2 if overlapped else 0
+            if overlapped:
+                cs.wait_event(gather_done[b])                       # buffer b is free again (frame i-2 gathered)
+            dev.bind_displacement(outs[b].data_ptr())
+            dev.frame(i / 60.0, stream=cs.cuda_stream)
+            if overlapped:
+                frame_done[b].record(cs)
+                gs.wait_event(frame_done[b])
+                with torch.cuda.stream(gs):
+                    dist.gather(outs[b], dsts[b], dst=0)
+                    gather_done[b].record(gs)
+            else:
+                with torch.cuda.stream(cs):
+                    dist.gather(outs[b], dsts[b], dst=0)
+        torch.cuda.synchronize()
+
+    res = {"steps": steps, "bytes_per_peer_per_frame": n * n * 16,
+           "collective": "torch.distributed.gather (RCCL send/recv group), one per frame"}
+    for name, overlapped in (("ordered", False), ("overlapped", True)):
+        for e in gather_done:
+            e.record(gs)
+        run(3, overlapped)
+        dist.barrier()
+        t0 = time.perf_counter()
+        run(steps, overlapped)
+        ms = (time.perf_counter() - t0) * 1000.0
+        dist.barrier()
+        t = torch.tensor([ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = float(t.item())
+        res[name] = {"ms_per_step": ms / steps, "frames_per_s": n_gpus * 1000.0 * steps / ms,
+                     "root_ingest_GBps": (n_gpus - 1) * n * n * 16 / (ms / steps) / 1e6}
+    dev.bind_displacement(None)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,6 +152,7 @@ def main():
     ap.add_argument("--gather", action="store_true",
                     help="also time frames followed by an RCCL gather of every tile's RGBA map to rank 0 "
                          "(BASELINE config 4; reported separately, never part of `value`)")
+    ap.add_argument("--gather-timeout", type=float, default=180.0, help="seconds before a stuck --gather leg is abandoned")
     ap.add_argument("--profile-frames", type=int, default=20, help="frames averaged for the per-kernel durations")
     args = ap.parse_args()
 
@@ -186,32 +238,17 @@ def main():
 
     gather = None
     if args.gather and dist is not None:
-        # one RCCL collective per frame over xGMI, root ingest N*N*16 B per peer.  The frame
-        # is launched on torch's current stream so that the collective is stream-ordered behind it.
+        import threading
         import torch
-        out = torch.empty((n, n, 4), dtype=torch.float32, device="cuda")
-        dev.bind_displacement(out.data_ptr())
-        dst = [torch.empty_like(out) for _ in range(n_gpus)] if rank == 0 else None
-        ts = torch.cuda.current_stream().cuda_stream
-        gsteps = max(1, min(args.steps, 50))
-        for i in range(3):
-            dev.frame(i / 60.0, stream=ts)
-            dist.gather(out, dst, dst=0)
-        torch.cuda.synchronize(); dist.barrier()
-        g0 = time.perf_counter()
-        for i in range(gsteps):
-            dev.frame(i / 60.0, stream=ts)
-            dist.gather(out, dst, dst=0)
-        torch.cuda.synchronize()
-        g_ms = (time.perf_counter() - g0) * 1000.0
-        dist.barrier()
-        tg = torch.tensor([g_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
-        g_ms = float(tg.item())
-        dev.bind_displacement(None)
-        gather = {"steps": gsteps, "ms_per_step": g_ms / gsteps, "frames_per_s": n_gpus * 1000.0 * gsteps / g_ms,
-                  "root_ingest_GBps": (n_gpus - 1) * n * n * 16 / (g_ms / gsteps) / 1e6,
-                  "collective": "torch.distributed.gather over RCCL, stream-ordered behind each frame"}
+        # a collective that never completes must not take the measured line with it
+        watchdog = threading.Timer(args.gather_timeout, lambda: os._exit(3))
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            gather = gather_leg(dev, dist, torch, n, n_gpus, rank, max(1, min(args.steps, 50)))
+        except Exception as e:  # noqa: BLE001 -- reported, never fatal for the main metric
+            gather = {"error": f"{type(e).__name__}: {e}"}
+        watchdog.cancel()
 
     if rank == 0:
         line = {
