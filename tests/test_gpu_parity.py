@@ -145,6 +145,25 @@ def test_synthetic_against_c_oracle(n):
 
 
 @pytest.mark.parametrize("n", [4096, 8192])
+def test_full_size_against_c_oracle(n):
+    """BASELINE configs 4 and 5 at their full sizes, every texel: the fused frame against the C restatement of
+    the four shaders (fp32, radix-2 Stockham, sincosf per butterfly) on the box's host cores."""
+    h0, om = g.synth.make_inputs(n)
+    cc.set_threads(min(32, cc.max_threads()))            # the strided column pass is fastest on ~32 threads
+    refc = cc.FrameRunner(h0, om).frame(0.75)
+    r = g.OceanRenderer(n)
+    try:
+        r.upload(h0, om)
+        r.render_fused(0.75)
+        fused = r.displacement()
+        nmax, rl2 = assert_parity(fused[..., :3], refc[..., :3], TOL, f"N={n} fused vs C oracle")
+        assert nmax.max() < 2e-5                          # two fp32 paths: expect a few 1e-6
+        assert np.all(fused[..., 3] == 0.0)
+    finally:
+        r.dispose()
+
+
+@pytest.mark.parametrize("n", [4096, 8192])
 def test_full_size_properties(n):
     """BASELINE full sizes through size-independent properties (the oracle would take minutes):
     fused == staged; impulse spectrum -> closed-form plane wave; linearity in h0; FFT of the
