@@ -163,17 +163,19 @@ __device__ __forceinline__ void apply_twiddles(c32 (&a)[R], c32 w) {
 // One pass of radix R over the E registers of thread j.  `emit(pos, padded_pos, value, slot)`
 // receives every output with its line position, its padded LDS index and the register slot it
 // would occupy after the exchange of the last pass.
-template <int N, int E, int R, int NS, class Emit>
+// TWS: stride of the twiddle table (the table holds e^{+2 pi i k / (N*TWS)}: a length-N transform inside a
+// context whose table was made for N*TWS points, see the split kernels of ocean_kernels.hpp).
+template <int N, int E, int R, int NS, int TWS = 1, class Emit>
 __device__ __forceinline__ void fft_pass(c32 (&reg)[E], int j, const c32* __restrict__ tw, Emit&& emit) {
     constexpr int T = N / E;
     constexpr int U = E / R;
     c32 w = mk(1.0f, 0.0f);
-    if constexpr (NS > 1 && U == 1) w = tw[(j & (NS - 1)) * (N / (NS * R))];
+    if constexpr (NS > 1 && U == 1) w = tw[(j & (NS - 1)) * (TWS * (N / (NS * R)))];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int jv = j + u * T;
         const int k = jv & (NS - 1);
-        if constexpr (NS > 1 && U > 1) w = tw[k * (N / (NS * R))];
+        if constexpr (NS > 1 && U > 1) w = tw[k * (TWS * (N / (NS * R)))];
         c32 a[R], b[R];
 #pragma unroll
         for (int t = 0; t < R; ++t) a[t] = reg[u + t * U];
@@ -190,10 +192,10 @@ __device__ __forceinline__ void fft_pass(c32 (&reg)[E], int j, const c32* __rest
 
 // Exchange through one padded LDS line buffer: scatter `reg` outputs of a pass, then gather
 // positions j + e*T.  `bar()` is the workgroup barrier (all threads of the WG call it).
-template <int N, int E, int R, int NS>
+template <int N, int E, int R, int NS, int TWS = 1>
 __device__ __forceinline__ void fft_pass_exchange(c32 (&reg)[E], int j, const c32* __restrict__ tw, c32* lds_line) {
     constexpr int T = N / E;
-    fft_pass<N, E, R, NS>(reg, j, tw, [&](int, int ppos, c32 v, int) { lds_line[ppos] = v; });
+    fft_pass<N, E, R, NS, TWS>(reg, j, tw, [&](int, int ppos, c32 v, int) { lds_line[ppos] = v; });
     __syncthreads();
     // lds_pad(j + e*T) == lds_pad(j) + e*(T + T/16)   (T is a multiple of 16)
     const c32* g = lds_line + lds_pad(j);
@@ -204,7 +206,7 @@ __device__ __forceinline__ void fft_pass_exchange(c32 (&reg)[E], int j, const c3
 // Whole line transform.  On entry reg[e] = x[j + e*T]; on exit reg[e] = X[j + e*T].
 // lds_line: LdsLine<N>::elems c32 owned by this line.  Every thread of the workgroup must call
 // this the same number of times (it contains __syncthreads()).
-template <int N, int E>
+template <int N, int E, int TWS = 1>
 __device__ __forceinline__ void fft_line(c32 (&reg)[E], int j, const c32* __restrict__ tw, c32* lds_line) {
     constexpr int R0 = Plan<N, E>::first_radix();
     constexpr int Q = Plan<N, E>::full_passes();
@@ -212,29 +214,29 @@ __device__ __forceinline__ void fft_line(c32 (&reg)[E], int j, const c32* __rest
     int ns = 1;
     (void)ns;
     if constexpr (R0 > 1) {
-        fft_pass_exchange<N, E, R0, 1>(reg, j, tw, lds_line);
+        fft_pass_exchange<N, E, R0, 1, TWS>(reg, j, tw, lds_line);
         __syncthreads();   // WAR: next scatter reuses the buffer
     }
     constexpr int NS1 = R0;                  // after the optional small pass
     if constexpr (Q == 1) {
         c32 out[E];
-        fft_pass<N, E, E, NS1>(reg, j, tw, [&](int, int, c32 v, int slot) { out[slot] = v; });
+        fft_pass<N, E, E, NS1, TWS>(reg, j, tw, [&](int, int, c32 v, int slot) { out[slot] = v; });
 #pragma unroll
         for (int e = 0; e < E; ++e) reg[e] = out[e];
     } else {
-        fft_pass_exchange<N, E, E, NS1>(reg, j, tw, lds_line);
+        fft_pass_exchange<N, E, E, NS1, TWS>(reg, j, tw, lds_line);
         constexpr int NS2 = NS1 * E;
         if constexpr (Q == 2) {
             c32 out[E];
-            fft_pass<N, E, E, NS2>(reg, j, tw, [&](int, int, c32 v, int slot) { out[slot] = v; });
+            fft_pass<N, E, E, NS2, TWS>(reg, j, tw, [&](int, int, c32 v, int slot) { out[slot] = v; });
 #pragma unroll
             for (int e = 0; e < E; ++e) reg[e] = out[e];
         } else {
             __syncthreads();
-            fft_pass_exchange<N, E, E, NS2>(reg, j, tw, lds_line);
+            fft_pass_exchange<N, E, E, NS2, TWS>(reg, j, tw, lds_line);
             constexpr int NS3 = NS2 * E;
             c32 out[E];
-            fft_pass<N, E, E, NS3>(reg, j, tw, [&](int, int, c32 v, int slot) { out[slot] = v; });
+            fft_pass<N, E, E, NS3, TWS>(reg, j, tw, [&](int, int, c32 v, int slot) { out[slot] = v; });
 #pragma unroll
             for (int e = 0; e < E; ++e) reg[e] = out[e];
         }
@@ -244,26 +246,26 @@ __device__ __forceinline__ void fft_line(c32 (&reg)[E], int j, const c32* __rest
 // Same transform, but the final pass scatters into the LDS line (padded positions) and the
 // function returns after a barrier: lds_line[lds_pad(n)] = X[n] for the whole line.  Used when
 // the global store wants a different thread->element mapping than the FFT's (chunked layouts).
-template <int N, int E>
+template <int N, int E, int TWS = 1>
 __device__ __forceinline__ void fft_line_to_lds(c32 (&reg)[E], int j, const c32* __restrict__ tw, c32* lds_line) {
     constexpr int R0 = Plan<N, E>::first_radix();
     constexpr int Q = Plan<N, E>::full_passes();
     static_assert(Q >= 2 && Q <= 3, "unsupported N/E combination");
     if constexpr (R0 > 1) {
-        fft_pass_exchange<N, E, R0, 1>(reg, j, tw, lds_line);
+        fft_pass_exchange<N, E, R0, 1, TWS>(reg, j, tw, lds_line);
         __syncthreads();
     }
     constexpr int NS1 = R0;
-    fft_pass_exchange<N, E, E, NS1>(reg, j, tw, lds_line);
+    fft_pass_exchange<N, E, E, NS1, TWS>(reg, j, tw, lds_line);
     __syncthreads();
     constexpr int NS2 = NS1 * E;
     if constexpr (Q == 2) {
-        fft_pass<N, E, E, NS2>(reg, j, tw, [&](int, int ppos, c32 v, int) { lds_line[ppos] = v; });
+        fft_pass<N, E, E, NS2, TWS>(reg, j, tw, [&](int, int ppos, c32 v, int) { lds_line[ppos] = v; });
     } else {
-        fft_pass_exchange<N, E, E, NS2>(reg, j, tw, lds_line);
+        fft_pass_exchange<N, E, E, NS2, TWS>(reg, j, tw, lds_line);
         __syncthreads();
         constexpr int NS3 = NS2 * E;
-        fft_pass<N, E, E, NS3>(reg, j, tw, [&](int, int ppos, c32 v, int) { lds_line[ppos] = v; });
+        fft_pass<N, E, E, NS3, TWS>(reg, j, tw, [&](int, int ppos, c32 v, int) { lds_line[ppos] = v; });
     }
     __syncthreads();
 }

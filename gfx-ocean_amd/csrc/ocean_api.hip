@@ -53,6 +53,7 @@ struct OceanContext {
     InterLayout lay_h{0, 0, 0};   // three complex fields, columns 0..N/2-1     (half-spectrum path)
     c32* nyq = nullptr;           // scratch of the half-spectrum path: the Nyquist column's 3 spectra, 3 x N complex
     bool half = true;             // OCEAN_ALGO=c2c selects the three-complex-transform frame (A/B)
+    bool split = false;           // lines as two interleaved N/2 transforms (N = 8192; OCEAN_SPLIT=0/1 for A/B)
     int P = 0;                    // chunk width of the c2c path (fixed per N)
     int Ph = 0;                   // chunk width = lines per pass-1 workgroup of the half-spectrum path (2 or 4)
     c32* tw = nullptr;          // e^{+2 pi i k/N}
@@ -141,12 +142,37 @@ template <int N> struct Launch {
         e = hipFuncSetAttribute((const void*)k_half_pass1<N, H::E, H::P, true>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, H::frame_lds);
         if (e != hipSuccess) return e;
-        return hipFuncSetAttribute((const void*)k_half_pass2<N, H::E, CHUNK_W, H::R2>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, H::thin_lds);
+        e = hipFuncSetAttribute((const void*)k_half_pass2<N, H::E, CHUNK_W, H::R2>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, H::thin_lds);
+        if (e != hipSuccess) return e;
+        if constexpr (H::can_split) {
+            e = hipFuncSetAttribute((const void*)k_half_pass1_split<N, H::E, H::P, false>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, H::split_lds1);
+            if (e != hipSuccess) return e;
+            e = hipFuncSetAttribute((const void*)k_half_pass1_split<N, H::E, H::P, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, H::split_lds1);
+            if (e != hipSuccess) return e;
+            e = hipFuncSetAttribute((const void*)k_half_pass2_split<N, H::E, CHUNK_W>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, H::split_lds2);
+        }
+        return e;
     }
     template <int PSEL> static void half_pass1(OceanContext* c, float time, float domain, hipStream_t s, Timing t) {
         using H = Geo<N, PSEL>;
         const float descale = std::ldexp(1.0f, -c->scale_log2);
+        if constexpr (H::can_split) {
+            if (c->split) {
+                if (c->h0_f16)
+                    launch(k_half_pass1_split<N, H::E, H::P, true>, dim3(H::half_grid1), dim3(H::frame_threads),
+                           H::split_lds1, s, t, (const void*)c->h0T, descale, (const float*)c->omegaT, c->inter, c->nyq,
+                           (const c32*)c->tw, c->lay_h, time, domain);
+                else
+                    launch(k_half_pass1_split<N, H::E, H::P, false>, dim3(H::half_grid1), dim3(H::frame_threads),
+                           H::split_lds1, s, t, (const void*)c->h0T, 1.0f, (const float*)c->omegaT, c->inter, c->nyq,
+                           (const c32*)c->tw, c->lay_h, time, domain);
+                return;
+            }
+        }
         if (c->h0_f16)
             launch(k_half_pass1<N, H::E, H::P, true>, dim3(H::half_grid1), dim3(H::frame_threads), H::frame_lds, s, t,
                    (const void*)c->h0T, descale, (const float*)c->omegaT, c->inter, c->nyq, (const c32*)c->tw, c->lay_h,
@@ -158,6 +184,13 @@ template <int N> struct Launch {
     }
     template <int PSEL> static void half_pass2(OceanContext* c, hipStream_t s, Timing t) {
         using H = Geo<N, PSEL>;
+        if constexpr (H::can_split) {
+            if (c->split) {
+                launch(k_half_pass2_split<N, H::E, CHUNK_W>, dim3(N), dim3(H::split_threads2), H::split_lds2, s, t,
+                       (const c32*)c->inter, c->out, (const c32*)c->tw, c->lay_h);
+                return;
+            }
+        }
         launch(k_half_pass2<N, H::E, CHUNK_W, H::R2>, dim3(H::thin_grid), dim3(H::thin_threads), H::thin_lds, s, t,
                (const c32*)c->inter, c->out, (const c32*)c->tw, c->lay_h);
     }
@@ -294,6 +327,9 @@ int32_t ocean_context_create(int32_t device, int32_t resolution, OceanContext** 
         c->lay = make((size_t)resolution);
         c->lay_h = make((size_t)resolution / 2);
         if (const char* a = std::getenv("OCEAN_ALGO")) c->half = (std::strcmp(a, "c2c") != 0);
+        // N = 8192 = 2 * 16^3 has no three-pass plan: its lines run as two interleaved 4096-point transforms
+        c->split = (resolution > 4096);
+        if (const char* sp = std::getenv("OCEAN_SPLIT")) c->split = (std::atoi(sp) != 0) && c->Ph == 2 && resolution >= 512;
     }
     auto bail = [&](hipError_t err, const char* what) {
         const int32_t code = hip_fail(nullptr, err, what);

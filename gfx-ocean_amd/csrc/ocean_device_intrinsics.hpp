@@ -17,6 +17,13 @@ __host__ __device__ __forceinline__ c32 yy(c32 a) { return __builtin_shufflevect
 __host__ __device__ __forceinline__ c32 yx(c32 a) { return __builtin_shufflevector(a, a, 1, 0); }
 __host__ __device__ __forceinline__ c32 vfma(c32 a, c32 b, c32 c) { return __builtin_elementwise_fma(a, b, c); }
 
+// Two consecutive complex numbers (16 bytes) / two consecutive packed-half2 spectrum entries (8 bytes) / two floats
+// that are only element-aligned: the structs carry the weaker alignment so that the compiler still emits ONE
+// global_load_dwordx4 / dwordx2 (gfx950 global loads need dword alignment only).
+struct __attribute__((aligned(8))) c32_pair { c32 a, b; };
+struct __attribute__((aligned(4))) u32_pair { uint32_t a, b; };
+struct __attribute__((aligned(4))) f32_pair { float a, b; };
+
 // Returns x unchanged but opaque to GVN/LICM.  The three per-field FFTs of a fused kernel use
 // identical twiddles; without this the compiler keeps ~60 VGPRs of twiddle powers alive across
 // the fields (measured: 195 -> 92 VGPRs for k_frame_pass2<4096>), which spills at the

@@ -457,12 +457,14 @@ __device__ __forceinline__ c32 half_spectrum_at(int f, c32 A, c32 B, c32 kxv, fl
     return crot(v);                                                // i * v
 }
 // ... for the E positions of a thread.
-template <int N, int E>
+// (S, par): the thread's positions are y = S * (j + e * T) + par, T = N / (E * S) -- S = 1 for a whole line,
+// S = 2 for one parity of a line split in two half-length transforms (k_half_pass1_split).
+template <int N, int E, int S = 1>
 __device__ __forceinline__ void half_spectrum(int f, const c32 (&A)[E], const c32 (&B)[E], c32 kxv, float kscale, int j,
-                                              c32 (&reg)[E]) {
-    constexpr int T = N / E;
+                                              c32 (&reg)[E], int par = 0) {
+    constexpr int T = N / (E * S);
 #pragma unroll
-    for (int e = 0; e < E; ++e) reg[e] = half_spectrum_at<N>(f, A[e], B[e], kxv, kscale, j + e * T);
+    for (int e = 0; e < E; ++e) reg[e] = half_spectrum_at<N>(f, A[e], B[e], kxv, kscale, S * (j + e * T) + par);
 }
 
 // The initial spectrum in HBM: fp32 complex (8 B/texel), or -- BASELINE config 5 -- two fp16 with
@@ -471,27 +473,35 @@ template <bool H16> struct Spec;
 template <> struct Spec<false> {
     typedef c32 elem;
     static __device__ __forceinline__ c32 load(const elem* p, float) { return *p; }
+    static __device__ __forceinline__ void load2(const elem* p, float, c32& a, c32& b) {       // p[0], p[1] in one load
+        const c32_pair v = *reinterpret_cast<const c32_pair*>(p);
+        a = v.a; b = v.b;
+    }
 };
 template <> struct Spec<true> {
     typedef uint32_t elem;
     static __device__ __forceinline__ c32 load(const elem* p, float descale) { return unpack_half2(*p, descale); }
+    static __device__ __forceinline__ void load2(const elem* p, float descale, c32& a, c32& b) {
+        const u32_pair v = *reinterpret_cast<const u32_pair*>(p);
+        a = unpack_half2(v.a, descale); b = unpack_half2(v.b, descale);
+    }
 };
 
 // A = H(y, x), B = conj(H((-y)%N, (-x)%N)) for the E positions of a thread on column x.
-template <int N, int E, bool H16>
+template <int N, int E, bool H16, int S = 1>
 __device__ __forceinline__ void half_load_AB(const void* __restrict__ h0T_, float descale, const float* __restrict__ omegaT,
-                                             uint32_t x, int j, float time, c32 (&A)[E], c32 (&B)[E]) {
-    typedef typename Spec<H16>::elem S;
-    constexpr int T = N / E;
-    const S* h0T = reinterpret_cast<const S*>(h0T_);
+                                             uint32_t x, int j, float time, c32 (&A)[E], c32 (&B)[E], int par = 0) {
+    typedef typename Spec<H16>::elem Sp;
+    constexpr int T = N / (E * S);                                 // threads per (sub-)line; y = S * (jj + e*T) + par
+    const Sp* h0T = reinterpret_cast<const Sp*>(h0T_);
     const uint32_t x2 = (N - x) & (N - 1);
     const uint32_t xm = (x - 1u) & (N - 1);
-    const S* own = h0T + (size_t)x * N;
-    const S* mir = h0T + (size_t)(N - 1 - x) * N;
-    const S* own2 = h0T + (size_t)x2 * N;
-    const S* mir2 = h0T + (size_t)xm * N;
-    const float* om = omegaT + (size_t)x * N;
-    const float* om2 = omegaT + (size_t)x2 * N;
+    const Sp* own = h0T + (size_t)x * N + par;
+    const Sp* mir = h0T + (size_t)(N - 1 - x) * N - par;
+    const Sp* own2 = h0T + (size_t)x2 * N - par;
+    const Sp* mir2 = h0T + (size_t)xm * N + par;
+    const float* om = omegaT + (size_t)x * N + par;
+    const float* om2 = omegaT + (size_t)x2 * N - par;
     // LOAD_BATCHES batches: a batch's 6 loads per element are issued only after the previous batch's
     // inputs have been consumed (otherwise 16 x 10 input VGPRs are live at once next to A and B and
     // the kernel spills at the 128-VGPR budget of a 1024-thread workgroup; a spill reload in the
@@ -502,24 +512,25 @@ __device__ __forceinline__ void half_load_AB(const void* __restrict__ h0T_, floa
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         if (e > 0 && (e % PER) == 0) jj = opaque_after(j, A[e - 1].x + B[e - 1].y);
-        // y = jj + e*T.  Every address is written as (uniform base + e-dependent constant)[small lane index]
-        // so that the six streams share three lane offsets and the bases stay in SGPRs; only e == 0 can
-        // hit the wrap of y2 = (N - y) % N and ym = (y - 1) % N (at jj == 0).
-        const c32 a = Spec<H16>::load((own + e * T) + jj, descale);
-        const c32 m = Spec<H16>::load((mir + (N - (e + 1) * T)) + (T - 1 - jj), descale);   // mir[N - 1 - y]
-        const float w = (om + e * T)[jj];
+        // y = S*(jj + e*T) + par.  Every address is written as (uniform base + e-dependent constant)[small lane
+        // index] so that the six streams share three lane offsets and the bases stay in SGPRs; only e == 0 can
+        // hit the wrap of y2 = (N - y) % N and ym = (y - 1) % N (at y == 0).
+        const c32 a = Spec<H16>::load((own + S * e * T) + S * jj, descale);
+        const c32 m = Spec<H16>::load((mir + (N - 1 - S * (e + 1) * T + S)) + S * (T - 1 - jj), descale);   // mir[N - 1 - y]
+        const float w = (om + S * e * T)[S * jj];
         c32 a2, m2;
         float w2;
         if (e == 0) {
-            const int y2 = (N - jj) & (N - 1);
-            const int ym = (jj - 1) & (N - 1);
-            a2 = Spec<H16>::load(own2 + y2, descale);
-            m2 = Spec<H16>::load(mir2 + ym, descale);
-            w2 = om2[y2];
+            const int y0 = S * jj + par;
+            const int y2 = (N - y0) & (N - 1);
+            const int ym = (y0 - 1) & (N - 1);
+            a2 = Spec<H16>::load(h0T + (size_t)x2 * N + y2, descale);
+            m2 = Spec<H16>::load(h0T + (size_t)xm * N + ym, descale);
+            w2 = (omegaT + (size_t)x2 * N)[y2];
         } else {
-            a2 = Spec<H16>::load((own2 + (N - (e + 1) * T)) + (T - jj), descale);   // own2[N - y]
-            m2 = Spec<H16>::load((mir2 + (e * T - 1)) + jj, descale);               // mir2[y - 1]
-            w2 = (om2 + (N - (e + 1) * T))[T - jj];
+            a2 = Spec<H16>::load((own2 + (N - S * (e + 1) * T)) + S * (T - jj), descale);   // own2[N - y]
+            m2 = Spec<H16>::load((mir2 + (S * e * T - 1)) + S * jj, descale);               // mir2[y - 1]
+            w2 = (om2 + (N - S * (e + 1) * T))[S * (T - jj)];
         }
         A[e] = propagate_height(a, m, w, time);
         const c32 h2 = propagate_height(a2, m2, w2, time);
@@ -624,6 +635,160 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
     }
 }
 
+// Loads for the split geometry: sub-line thread (p, j) finally needs A, B at y = 2 (j + e TS) + p, e < E -- a
+// stride-2 pattern that halves the bytes per load instruction and cost +14 us on the load phase at N = 8192.
+// Instead thread (p, j) loads BOTH parities (16 contiguous bytes per stream) for e in [8p, 8p + 8), propagates
+// them, keeps its own parity and hands the other one to its partner (p ^ 1, j) through LDS (free during the
+// load phase): one 16-byte write and read per element, once per workgroup.
+template <int N, int E, bool H16, int THREADS>
+__device__ __forceinline__ void half_load_AB_pairs(const void* __restrict__ h0T_, float descale,
+                                                   const float* __restrict__ omegaT, uint32_t x, int j, int p, int tid,
+                                                   float time, float4* xchg, c32 (&A)[E], c32 (&B)[E]) {
+    typedef typename Spec<H16>::elem Sp;
+    constexpr int TS = N / (2 * E);                                // threads per sub-line
+    constexpr int EH = E / 2;
+    const Sp* h0T = reinterpret_cast<const Sp*>(h0T_);
+    const uint32_t x2 = (N - x) & (N - 1);
+    const uint32_t xm = (x - 1u) & (N - 1);
+    const int e0 = EH * p;                                         // this thread loads m = j + (e0 + t) TS, t < EH
+    const Sp* own = h0T + (size_t)x * N + 2 * e0 * TS;             // pair at 2m
+    const Sp* mir = h0T + (size_t)(N - 1 - x) * N - 2 * e0 * TS;   // pair at N - 2 - 2m
+    const Sp* own2 = h0T + (size_t)x2 * N - 2 * e0 * TS;           // pair at N - 1 - 2m
+    const Sp* mir2 = h0T + (size_t)xm * N + 2 * e0 * TS;           // pair at 2m - 1
+    const float* om = omegaT + (size_t)x * N + 2 * e0 * TS;
+    const float* om2 = omegaT + (size_t)x2 * N - 2 * e0 * TS;
+    c32 mineA[EH], mineB[EH];
+    constexpr int PER = 2;                                         // iterations per load batch (4 elements, as half_load_AB)
+    int jj = j;
+#pragma unroll
+    for (int t = 0; t < EH; ++t) {
+        if (t > 0 && (t % PER) == 0) jj = opaque_after(j, mineA[t - 1].x + mineB[t - 1].y);
+        c32 a0, a1, m0, m1, b0, b1, n0, n1;                        // own, mirror, own2, mirror2 for y0 = 2m, y1 = 2m + 1
+        float w0, w1, v0, v1;
+        Spec<H16>::load2((own + 2 * t * TS) + 2 * jj, descale, a0, a1);
+        Spec<H16>::load2((mir + (N - 2 * (t + 1) * TS)) + 2 * (TS - 1 - jj), descale, m1, m0);   // mir[N-2-2m], mir[N-1-2m]
+        { const f32_pair w = *reinterpret_cast<const f32_pair*>((om + 2 * t * TS) + 2 * jj); w0 = w.a; w1 = w.b; }
+        if (t == 0) {                                              // m may be 0: y2 = (N - y) % N and ym = (y - 1) % N wrap
+            const int y0 = 2 * (jj + e0 * TS), y1 = y0 + 1;
+            const int y20 = (N - y0) & (N - 1), y21 = (N - y1) & (N - 1);
+            const int ym0 = (y0 - 1) & (N - 1), ym1 = y0;
+            const Sp* r2 = h0T + (size_t)x2 * N;
+            const Sp* rm = h0T + (size_t)xm * N;
+            const float* o2 = omegaT + (size_t)x2 * N;
+            b0 = Spec<H16>::load(r2 + y20, descale); b1 = Spec<H16>::load(r2 + y21, descale);
+            n0 = Spec<H16>::load(rm + ym0, descale); n1 = Spec<H16>::load(rm + ym1, descale);
+            v0 = o2[y20]; v1 = o2[y21];
+        } else {
+            Spec<H16>::load2((own2 + (N - 1 - 2 * (t + 1) * TS)) + 2 * (TS - jj), descale, b1, b0);   // own2[N-1-2m], own2[N-2m]
+            Spec<H16>::load2((mir2 + (2 * t * TS - 1)) + 2 * jj, descale, n0, n1);                      // mir2[2m-1], mir2[2m]
+            const f32_pair w = *reinterpret_cast<const f32_pair*>((om2 + (N - 1 - 2 * (t + 1) * TS)) + 2 * (TS - jj));
+            v1 = w.a; v0 = w.b;
+        }
+        const c32 Aev = propagate_height(a0, m0, w0, time), Aod = propagate_height(a1, m1, w1, time);
+        const c32 Bev = cconj(propagate_height(b0, n0, v0, time)), Bod = cconj(propagate_height(b1, n1, v1, time));
+        mineA[t] = p ? Aod : Aev;
+        mineB[t] = p ? Bod : Bev;
+        const c32 sA = p ? Aev : Aod, sB = p ? Bev : Bod;
+        xchg[t * THREADS + tid] = make_float4(sA.x, sA.y, sB.x, sB.y);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < EH; ++t) {
+        const float4 r = xchg[t * THREADS + (tid ^ TS)];
+        const c32 rA = mk(r.x, r.y), rB = mk(r.z, r.w);
+        A[t] = p ? rA : mineA[t];
+        B[t] = p ? rB : mineB[t];
+        A[EH + t] = p ? mineA[t] : rA;
+        B[EH + t] = p ? mineB[t] : rB;
+    }
+    __syncthreads();                                               // the exchange buffer is the FFT's line buffer next
+}
+
+// The same pass for lines too long for a three-pass plan (N = 8192 = 2 * 16^3): every column is transformed
+// as TWO interleaved half-length lines (decimation in time: E = DFT_{N/2}(x[2m]), O = DFT_{N/2}(x[2m+1])), which
+// have the geometry of the N/2 kernel (2P sub-lines of N/(2E) threads, three passes, same LDS), and the last
+// radix-2 step X[k] = E[k] + W^k O[k], X[k + N/2] = E[k] - W^k O[k] (W = e^{+2 pi i / N}) is done by the
+// threads that read the lines out of LDS for the chunk stores.  Replaces a leading radix-2 pass with its own
+// LDS exchange and barriers (run 16: FFT phases 14 / 10 / 13 us per field at 8192 against 6 / 6 / 7.5 for the
+// same amount of data at 4096).
+template <int N, int E, int P, bool H16>
+__global__ void __launch_bounds__((N / E) * P, ((N / E) * P >= 512) ? 4 : 1)
+k_half_pass1_split(const void* __restrict__ h0T, float descale, const float* __restrict__ omegaT, c32* __restrict__ inter,
+                   c32* nyq_spec, const c32* __restrict__ tw, InterLayout lay, float time, float domain_size) {
+    constexpr int M = N / 2;                                       // sub-transform length
+    constexpr int TS = M / E;                                      // threads per sub-line
+    constexpr int THREADS = 2 * P * TS;
+    constexpr int CR = CHUNK_R, CW = CHUNK_W;
+    static_assert(P == 2 && CW % P == 0 && M % THREADS == 0, "split geometry");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    c32* lds = reinterpret_cast<c32*>(smem);
+    const int tid = threadIdx.x;
+    const int l = (TS >= 64) ? wave_uniform(tid / TS) : (tid / TS);   // sub-line: column l / 2, parity l % 2
+    const int c = l >> 1, par = l & 1;
+    const int j = tid % TS;
+    c32* lds_line = lds + l * LinePitch<M>::elems;
+    const float kscale = OCEAN_PI_F / domain_size;
+
+    const int X = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+    if (X == 0) {                                                  // uniform: the Nyquist column's spectra, element-wise
+        const c32 kxn = xx(mk(wave_index_q1((uint32_t)(N / 2), N) * kscale, 0.0f));
+#pragma unroll 1
+        for (int y = tid; y < N; y += THREADS) {
+            c32 An, Bn;
+            half_AB_at<N, H16>(h0T, descale, omegaT, (uint32_t)(N / 2), (uint32_t)y, time, An, Bn);
+#pragma unroll
+            for (int f = 0; f < 3; ++f) nyq_spec[(size_t)f * N + y] = half_spectrum_at<N>(f, An, Bn, kxn, kscale, y);
+        }
+        workgroup_publish();
+    }
+    const bool packs_nyquist = (X == 0) && (c == 0);               // both parities of column 0 carry the Nyquist column
+    const uint32_t x = (uint32_t)(X * P + c);
+    const uint32_t x2 = (N - x) & (N - 1);
+    c32 A[E], B[E];
+    OCEAN_TL(0);
+    static_assert(E / 2 * THREADS * (int)sizeof(float4) <= 2 * P * LinePitch<M>::elems * (int)sizeof(c32), "exchange fits the line buffers");
+    half_load_AB_pairs<N, E, H16, THREADS>(h0T, descale, omegaT, x, j, par, tid, time, reinterpret_cast<float4*>(smem), A, B);
+    OCEAN_TL(1);
+    const c32 kxv = mk(wave_index_q1(x, N), wave_index_q1(x2, N)) * kscale;
+
+    const c32* e0 = lds;                                           // column 0: even, odd; column 1: even, odd
+    const c32* o0 = lds + LinePitch<M>::elems;
+    const c32* e1 = lds + 2 * LinePitch<M>::elems;
+    const c32* o1 = lds + 3 * LinePitch<M>::elems;
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+        c32 reg[E];
+        const int jf = opaque_lane(j);
+        half_spectrum<N, E, 2>(f, A, B, kxv, kscale, jf, reg, par);
+        if (packs_nyquist) {
+            const c32* z = nyq_spec + (size_t)f * N + 2 * jf + par;
+#pragma unroll
+            for (int e = 0; e < E; ++e) reg[e] = cadd_i(reg[e], z[2 * e * TS]);   // + i * Sn
+        }
+        if (f > 0) __syncthreads();
+        fft_line_to_lds<M, E, 2>(reg, jf, tw, lds_line);           // tw holds e^{2 pi i k / N}: stride 2 for length N/2
+        OCEAN_TL(2 + 2 * f);
+        const int tf = opaque_lane(tid);
+        c32* dst = inter + (size_t)f * lay.fs + (size_t)((X * P) / CW) * lay.sx + (size_t)(tf / CR) * lay.sy + (tf % CR) * CW +
+                   ((X * P) % CW);
+#pragma unroll
+        for (int q = 0; q < M / THREADS; ++q) {
+            const int k = tf + q * THREADS;                        // rows k and k + M
+            const c32 w = tw[k];
+            const c32 wr = crot(w);
+            const int pk = lds_pad(k);
+            const c32 t0 = cmul_r(o0[pk], w, wr), t1 = cmul_r(o1[pk], w, wr);
+            const c32 u0 = e0[pk], u1 = e1[pk];
+            const c32 lo0 = u0 + t0, hi0 = u0 - t0, lo1 = u1 + t1, hi1 = u1 - t1;
+            float4* olo = reinterpret_cast<float4*>(dst + (size_t)q * (THREADS / CR) * lay.sy);
+            float4* ohi = reinterpret_cast<float4*>(dst + (size_t)(q * (THREADS / CR) + M / CR) * lay.sy);
+            *olo = make_float4(lo0.x, lo0.y, lo1.x, lo1.y);        // half a chunk row: meets its other half in L2
+            *ohi = make_float4(hi0.x, hi0.y, hi1.x, hi1.y);
+        }
+        OCEAN_TL(3 + 2 * f);
+    }
+}
+
 // Pass 2 of the half-spectrum path: one row per R2-slot; two complex FFTs per row.
 // __launch_bounds__(256, 4): four workgroups per CU (LDS: 4 x 35 KiB), i.e. at most 128 VGPRs.
 template <int N, int E, int P1, int R2>
@@ -720,6 +885,116 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
     }
 }
 
+// Pass 2 for the split geometry (N = 8192): the row is rebuilt in LDS as two interleaved half-length lines
+// (C[2m] and C[2m+1]), each transformed by N/(2E) threads in three passes, and the final radix-2 step is done by
+// the thread that owns outputs n and n + N/2 in the epilogue (see k_half_pass1_split).  One row per workgroup.
+template <int N, int E, int P1>
+__global__ void __launch_bounds__(N / E, ((N / E) >= 512) ? 2 : 1)
+k_half_pass2_split(const c32* __restrict__ inter, float4* __restrict__ out, const c32* __restrict__ tw, InterLayout lay) {
+    constexpr int M = N / 2;
+    constexpr int T = N / E;                                       // threads per row
+    constexpr int TS = M / E;                                      // threads per sub-line
+    constexpr int EH = E / 2;
+    constexpr int CR = CHUNK_R;
+    static_assert(P1 == CHUNK_W && T % P1 == 0 && (E % 2) == 0 && T == 2 * TS, "geometry");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    c32* lds = reinterpret_cast<c32*>(smem);
+    const int tid = threadIdx.x;
+    const int par = (TS >= 64) ? wave_uniform(tid / TS) : (tid / TS);   // the sub-line this thread transforms
+    const int j = tid % TS;
+    constexpr int S = CR;                                          // workgroups sharing a chunk line: same XCD
+    int rb = blockIdx.x;
+    if ((gridDim.x % (8 * S)) == 0) {
+        const int xcd = rb & 7, slot = rb >> 3;
+        rb = ((slot / S) * 8 + xcd) * S + (slot % S);
+    }
+    const int y = rb;
+    c32* line0 = lds;
+    c32* line1 = lds + LinePitch<M>::elems;
+    c32* my_line = par ? line1 : line0;
+
+    float keep_lo[EH], keep_hi[EH];
+    OCEAN_TL(0);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {                         // 0: height, 1: (disp_x, disp_z)
+        const int tf = opaque_lane(tid);                           // loads: kx = tf + e*T, e < E/2
+        const size_t off = (size_t)(y / CR) * lay.sy + (size_t)(tf / P1) * lay.sx + (y % CR) * P1 + (tf % P1);
+        c32 a[EH], b[EH];
+        if (pass == 0) {
+            const c32* src = inter + (size_t)1 * lay.fs + off;
+#pragma unroll
+            for (int e = 0; e < EH; ++e) a[e] = src[(size_t)e * (T / P1) * lay.sx];
+        } else {
+            const c32* sx_ = inter + off;
+            const c32* sz_ = inter + (size_t)2 * lay.fs + off;
+#pragma unroll
+            for (int e = 0; e < EH; ++e) { a[e] = sx_[(size_t)e * (T / P1) * lay.sx]; b[e] = sz_[(size_t)e * (T / P1) * lay.sx]; }
+        }
+        if (pass > 0) __syncthreads();
+        // C[kx] goes to sub-line kx & 1 at index kx >> 1; kx = tf + e*T keeps its parity (T is even).  Its mirror
+        // C[N - kx] has the same parity and index N/2 - (kx >> 1) - (kx & 1).
+        const int kp = tf & 1, m0 = tf >> 1;
+        c32* base = kp ? line1 : line0;
+        c32* lo = base + lds_pad(m0);                              // + e * (T/2 + T/32)
+        c32* hi = base + lds_pad(M - m0 - kp);                     // - e * (T/2 + T/32)
+#pragma unroll
+        for (int e = 0; e < EH; ++e) {
+            c32 ck, cm;
+            if (pass == 0) {
+                ck = a[e];
+                cm = cconj(a[e]);
+            } else {
+                ck = cadd_i(a[e], b[e]);
+                cm = vfma(yx(b[e]), mk(1.0f, 1.0f), cconj(a[e]));
+            }
+            if (e == 0) {
+                const bool dc = (tf == 0);                         // kx = 0 -> (even, 0); its mirror slot is the Nyquist bin (even, N/4)
+                if (dc) {
+                    const c32 bb = (pass == 0) ? mk(0.0f, 0.0f) : b[e];
+                    ck = mk(a[e].x, bb.x);
+                    cm = mk(a[e].y, bb.y);
+                }
+                lo[0] = ck;
+                (dc ? (line0 + lds_pad(M / 2)) : hi)[0] = cm;
+            } else {
+                lo[e * (T / 2 + T / 32)] = ck;
+                hi[-e * (T / 2 + T / 32)] = cm;
+            }
+        }
+        __syncthreads();
+        OCEAN_TL(1 + 3 * pass);
+        c32 reg[E];
+        const int jf = opaque_lane(j);
+        const c32* g = my_line + lds_pad(jf);
+#pragma unroll
+        for (int e = 0; e < E; ++e) reg[e] = g[e * (TS + TS / 16)];
+        __syncthreads();
+        fft_line_to_lds<M, E, 2>(reg, jf, tw, my_line);
+        OCEAN_TL(2 + 3 * pass);
+        // radix-2 combine: X[n] = E[n] + W^n O[n], X[n + N/2] = E[n] - W^n O[n]; n = tf + q*T
+        float4* orow = out + (size_t)y * N;
+        const float sgn = (((tf + y) & 1) == 0) ? -0.5f : 0.5f;    // correction.comp:29 and the 1/2 of S(F); T and N/2 are even
+#pragma unroll
+        for (int q = 0; q < EH; ++q) {
+            const int n = tf + q * T;
+            const int pn = lds_pad(n);
+            const c32 w = tw[n];
+            const c32 t = cmul(line1[pn], w);
+            const c32 u = line0[pn];
+            const c32 xl = u + t, xh = u - t;
+            if (pass == 0) {
+                keep_lo[q] = xl.x;
+                keep_hi[q] = xh.x;
+            } else {
+                const c32 dl = xl * sgn, dh = xh * sgn;
+                store_float4_nt(orow + n, make_float4(dl.x, keep_lo[q] * sgn, dl.y, 0.0f));
+                store_float4_nt(orow + n + M, make_float4(dh.x, keep_hi[q] * sgn, dh.y, 0.0f));
+            }
+        }
+        if (pass == 1) OCEAN_TL(6);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Launch geometry per resolution -- the single source for the API (ocean_api.hip) and for the
 // host emulation harness (tests/hipemu).
@@ -748,6 +1023,11 @@ template <int N, int PSEL = 0> struct Geo {
     static constexpr int thin_lds = R2 * line_bytes;
     static constexpr int thin_grid = N / R2;
     static constexpr int half_grid1 = (N / 2) / P;                 // column groups
+    // split geometry (lines as two interleaved N/2 transforms; k_half_pass1_split / k_half_pass2_split)
+    static constexpr bool can_split = (P == 2) && (N >= 512);
+    static constexpr int split_lds1 = 2 * P * LinePitch<N / 2>::elems * (int)sizeof(c32);
+    static constexpr int split_lds2 = 2 * LinePitch<N / 2>::elems * (int)sizeof(c32);
+    static constexpr int split_threads2 = T;
     static_assert(row_threads <= 1024 && col_threads <= 1024 && frame_threads <= 1024, "workgroup too large");
     static_assert(col_lds <= 160 * 1024 && frame_lds <= 160 * 1024, "LDS budget (gfx950: 160 KiB)");
 };

@@ -134,9 +134,10 @@ def quantize_f16(h0):
     return (bits[..., 0] | (bits[..., 1] << 16)).astype(np.uint32), deq, s
 
 
-def frame_half(h0, omega, time, L=1000.0, layout="p2", return_inter=False, spectrum_fp16=False, P=None):
+def frame_half(h0, omega, time, L=1000.0, layout="p2", return_inter=False, spectrum_fp16=False, P=None, split=False):
+    """split=True: every line as two interleaved N/2 transforms (the N = 8192 geometry, P = 2)."""
     n = h0.shape[0]
-    P = P or lib().emu_frame_p(n)
+    P = 2 if split else (P or lib().emu_frame_p(n))
     descale = 1.0
     if spectrum_fp16:
         packed, _, s = quantize_f16(h0)
@@ -150,7 +151,7 @@ def frame_half(h0, omega, time, L=1000.0, layout="p2", return_inter=False, spect
     nyq = np.full(6 * n, np.nan, np.float32)           # scratch: the Nyquist column's three spectra
     out = np.full((n, n, 4), np.nan, np.float32)
     tw = twiddles(n)
-    assert lib().emu_frame_half(n, int(P), _p(h0T), int(spectrum_fp16), descale, _p(omT), _p(inter), _p(nyq), _p(out), _p(tw),
+    assert lib().emu_frame_half(n, 22 if split else int(P), _p(h0T), int(spectrum_fp16), descale, _p(omT), _p(inter), _p(nyq), _p(out), _p(tw),
                                 sx, sy, fs, time, L) == 0
     if return_inter:
         return out, inter, nyq, (P, (sx, sy, fs))

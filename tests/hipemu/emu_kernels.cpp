@@ -81,8 +81,23 @@ template <int N, int PSEL> static int run_half_p(const void* h0T, int f16, float
                [&] { k_half_pass2<N, G::E, CHUNK_W, G::R2>(inter, out, tw, lay); });
     return 0;
 }
+template <int N> static int run_half_split(const void* h0T, int f16, float descale, const float* omT, c32* inter, c32* nyq,
+                                           float4* out, const c32* tw, InterLayout lay, float time, float L) {
+    using G = Geo<N, 2>;
+    static_assert(G::can_split, "split geometry");
+    if (f16) emu_launch(G::half_grid1, G::frame_threads,
+                        [&] { k_half_pass1_split<N, G::E, G::P, true>(h0T, descale, omT, inter, nyq, tw, lay, time, L); });
+    else emu_launch(G::half_grid1, G::frame_threads,
+                    [&] { k_half_pass1_split<N, G::E, G::P, false>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L); });
+    emu_launch(N, G::split_threads2, [&] { k_half_pass2_split<N, G::E, CHUNK_W>(inter, out, tw, lay); });
+    return 0;
+}
 template <int N> static int run_half(int psel, const void* h0T, int f16, float descale, const float* omT, c32* inter, c32* nyq,
                                      float4* out, const c32* tw, InterLayout lay, float time, float L) {
+    if (psel == 22) {                                   // P = 2 with the split geometry
+        if constexpr (N >= 512) return run_half_split<N>(h0T, f16, descale, omT, inter, nyq, out, tw, lay, time, L);
+        else return -3;
+    }
     if (psel == 2) return run_half_p<N, 2>(h0T, f16, descale, omT, inter, nyq, out, tw, lay, time, L);
     return run_half_p<N, 0>(h0T, f16, descale, omT, inter, nyq, out, tw, lay, time, L);
 }

@@ -15,6 +15,9 @@ static inline c32 xx(c32 a) { return c32{a.x, a.x}; }
 static inline c32 yy(c32 a) { return c32{a.y, a.y}; }
 static inline c32 yx(c32 a) { return c32{a.y, a.x}; }
 static inline c32 vfma(c32 a, c32 b, c32 c) { return c32{std::fmaf(a.x, b.x, c.x), std::fmaf(a.y, b.y, c.y)}; }
+struct c32_pair { c32 a, b; };
+struct u32_pair { uint32_t a, b; };
+struct f32_pair { float a, b; };
 static inline int opaque_lane(int x) { return x; }
 static inline float ocean_emu_half_to_float(uint16_t h) {
     const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;

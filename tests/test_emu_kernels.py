@@ -116,6 +116,33 @@ def test_emu_normals(ref_inputs_256, channel):
     assert np.allclose(np.linalg.norm(got[..., :3], axis=-1), 1.0, atol=1e-6) and np.all(got[..., 3] == 0)
 
 
+@pytest.mark.parametrize("n", [512, 1024])
+def test_emu_split_line_geometry(n, ref_inputs):
+    """The N = 8192 kernels (every line as two interleaved N/2 transforms, last radix-2 step at read-out) at sizes
+    the emulation can run: same frame and same intermediate as the plain kernels."""
+    if n == 512:
+        h0, om = ref_inputs
+    else:
+        import gfx_ocean_amd as g
+        h0, om = g.synth.make_inputs(n)
+    out, inter, _, (P, lay) = emu.frame_half(h0, om, 2.5, return_inter=True, split=True)
+    ref = oc.frame_f64(h0, om, 2.5)
+    assert_parity(out[..., :3], ref[..., :3], 5e-6, f"split frame n={n}")
+    assert np.all(out[..., 3] == 0.0)
+    plain, inter_p, _, _ = emu.frame_half(h0, om, 2.5, return_inter=True, P=2)
+    for f in range(3):
+        a = emu.unpack_inter(inter, n, P, lay, f, columns=n // 2)
+        b = emu.unpack_inter(inter_p, n, 2, lay, f, columns=n // 2)
+        assert_parity(a, b, 5e-6, f"split intermediate field {f}")
+
+
+def test_emu_split_fp16_spectrum(ref_inputs):
+    h0, om = ref_inputs
+    _, deq, _ = emu.quantize_f16(h0)
+    out = emu.frame_half(h0, om, 1.0, spectrum_fp16=True, split=True)
+    assert_parity(out[..., :3], oc.frame_f64(deq, om, 1.0)[..., :3], 5e-6, "split fp16")
+
+
 @pytest.mark.parametrize("verts,offset", [(128, (0.0, 0.0)), (128, (127.0, 127.0)), (33, (5.0, -2.0))])
 def test_emu_positions(ref_inputs_256, verts, offset):
     """SURVEY 8f #2: k_positions vs the restatement of shader/ocean.vert:21-25 (bilinear sampler with Tile wrap)."""
