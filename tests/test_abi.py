@@ -65,6 +65,17 @@ def test_cpp_host_mirror_compiles_and_links(so_path, tmp_path):
     assert subprocess.call([exe]) == 0
 
 
+def test_header_is_plain_c_and_links_from_c(so_path, tmp_path):
+    """include/ocean_hip.h under gcc -std=c99 -pedantic, and a C program against the library (error paths only)."""
+    exe = str(tmp_path / "c_abi_check")
+    libdir = os.path.dirname(so_path)
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c_abi_check.c"), "-o", exe,
+                           "-L", libdir, "-locean_hip", "-Wl,-rpath," + libdir,
+                           "-L", "/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    assert subprocess.call([exe]) == 0
+
+
 def test_rust_shim_lists_every_symbol():
     """The uncompiled Rust shim (no cargo in this image) must at least bind every exported symbol."""
     with open(os.path.join(ROOT, "gfx-ocean_amd", "rust", "src", "ffi.rs")) as f:
