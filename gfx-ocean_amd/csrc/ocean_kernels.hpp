@@ -553,6 +553,22 @@ __device__ __forceinline__ void half_AB_at(const void* __restrict__ h0T_, float 
     B = cconj(h2);
 }
 
+// The Nyquist column's three symmetrised spectra, element-wise by all THREADS threads of ONE workgroup, into the
+// scratch `nyq_spec` (3 N complex), then published to the other waves of the workgroup.
+template <int N, bool H16, int THREADS>
+__device__ __forceinline__ void nyquist_spectra(const void* __restrict__ h0T, float descale, const float* __restrict__ omegaT,
+                                                c32* nyq_spec, int tid, float time, float kscale) {
+    const c32 kxn = xx(mk(wave_index_q1((uint32_t)(N / 2), N) * kscale, 0.0f));
+#pragma unroll 1
+    for (int y = tid; y < N; y += THREADS) {
+        c32 An, Bn;
+        half_AB_at<N, H16>(h0T, descale, omegaT, (uint32_t)(N / 2), (uint32_t)y, time, An, Bn);
+#pragma unroll
+        for (int f = 0; f < 3; ++f) nyq_spec[(size_t)f * N + y] = half_spectrum_at<N>(f, An, Bn, kxn, kscale, y);
+    }
+    workgroup_publish();
+}
+
 // grid = (N/2)/P blocks of P columns.  The half spectrum has N/2 + 1 distinct columns; the odd one out, the
 // self-paired Nyquist column kx = N/2, is like column 0 Hermitian along y, so both have REAL column transforms
 // and share one complex FFT: line 0 of the workgroup that owns column 0 transforms S0 + i Sn and the
@@ -581,17 +597,7 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
     const float kscale = OCEAN_PI_F / domain_size;
 
     const int X = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
-    if (X == 0) {                                                  // uniform: the Nyquist column's spectra, element-wise
-        const c32 kxn = xx(mk(wave_index_q1((uint32_t)(N / 2), N) * kscale, 0.0f));
-#pragma unroll 1
-        for (int y = tid; y < N; y += T * P) {
-            c32 An, Bn;
-            half_AB_at<N, H16>(h0T, descale, omegaT, (uint32_t)(N / 2), (uint32_t)y, time, An, Bn);
-#pragma unroll
-            for (int f = 0; f < 3; ++f) nyq_spec[(size_t)f * N + y] = half_spectrum_at<N>(f, An, Bn, kxn, kscale, y);
-        }
-        workgroup_publish();                                       // visible to the other waves of this workgroup
-    }
+    if (X == 0) nyquist_spectra<N, H16, T * P>(h0T, descale, omegaT, nyq_spec, tid, time, kscale);   // uniform branch
     const bool packs_nyquist = (X == 0) && (c == 0);               // line 0 of that workgroup: column 0 + i * Nyquist
     const uint32_t x = (uint32_t)(X * P + c);                      // kx in [0, N/2)
     const uint32_t x2 = (N - x) & (N - 1);
@@ -730,17 +736,7 @@ k_half_pass1_split(const void* __restrict__ h0T, float descale, const float* __r
     const float kscale = OCEAN_PI_F / domain_size;
 
     const int X = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
-    if (X == 0) {                                                  // uniform: the Nyquist column's spectra, element-wise
-        const c32 kxn = xx(mk(wave_index_q1((uint32_t)(N / 2), N) * kscale, 0.0f));
-#pragma unroll 1
-        for (int y = tid; y < N; y += THREADS) {
-            c32 An, Bn;
-            half_AB_at<N, H16>(h0T, descale, omegaT, (uint32_t)(N / 2), (uint32_t)y, time, An, Bn);
-#pragma unroll
-            for (int f = 0; f < 3; ++f) nyq_spec[(size_t)f * N + y] = half_spectrum_at<N>(f, An, Bn, kxn, kscale, y);
-        }
-        workgroup_publish();
-    }
+    if (X == 0) nyquist_spectra<N, H16, THREADS>(h0T, descale, omegaT, nyq_spec, tid, time, kscale);   // uniform branch
     const bool packs_nyquist = (X == 0) && (c == 0);               // both parities of column 0 carry the Nyquist column
     const uint32_t x = (uint32_t)(X * P + c);
     const uint32_t x2 = (N - x) & (N - 1);
