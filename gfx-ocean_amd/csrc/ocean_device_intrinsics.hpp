@@ -95,6 +95,9 @@ __device__ __forceinline__ void ocean_tl_hwid(unsigned long long* slot) {
 #define OCEAN_TL(k)
 #endif
 
+// 4-byte load with the non-temporal hint (read-once streams; see load_omega in ocean_kernels.hpp).
+__device__ __forceinline__ float load_float_nt(const float* p) { return __builtin_nontemporal_load(p); }
+
 // sin / cos of 2*pi*x for x in [-0.5, 0.5] revolutions: the gfx950 transcendental unit
 // (v_sin_f32 / v_cos_f32 take their argument in revolutions).  Measured max abs error on that
 // interval: 1.25e-7 (tools/sincos_acc.hip; ocml's sincospif: 5.2e-8) at 2 instructions instead of ~45.

@@ -495,7 +495,7 @@ template <> struct Spec<true> {
 // stays cache-resident from frame to frame; the hint on ALL loads was +6% slower.
 template <int N>
 __device__ __forceinline__ float load_omega(const float* p) {
-    if constexpr (N >= 4096) return __builtin_nontemporal_load(p);
+    if constexpr (N >= 4096) return load_float_nt(p);
     else return *p;
 }
 #define OCEAN_OMEGA_LOAD(p) load_omega<N>(p)

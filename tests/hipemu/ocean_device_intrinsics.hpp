@@ -37,6 +37,7 @@ static inline int wave_uniform(int x) { return x; }
 static inline float sin_rev(float x) { return (float)std::sin(6.283185307179586 * (double)x); }
 static inline float cos_rev(float x) { return (float)std::cos(6.283185307179586 * (double)x); }
 static inline void store_float4_nt(float4* p, float4 v) { *p = v; }
+static inline float load_float_nt(const float* p) { return *p; }
 static inline int opaque_after(int x, float) { return x; }
 static inline void workgroup_publish() { __syncthreads(); }       // the emulation's barrier is a full fence
 }  // namespace ocean
