@@ -6,14 +6,26 @@ the three fields -> sign correction + RGBA pack (the fused 2-launch path, `ocean
 omega already resident in HBM.  Tiles are independent, so N GPUs = N tiles per step
 and no data-path collective ("weak" scaling).  One JSON line on rank 0.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 4096]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
-        --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 4096] [--spectrum f32|f16]
+
+With --gpus N > 1 and no WORLD_SIZE in the environment the script launches its own N ranks (one process
+per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set for each, 127.0.0.1 rendezvous); under
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it uses the ranks it is given.
+Either way rank 0 prints exactly one line with "n_gpus": N.
+
+For N > 1 the line also carries BASELINE config 4's final gather ("gather": tile maps collected on rank 0 with
+one RCCL collective per frame, ordered and double-buffered/overlapped; never part of `value`).
+
+`--plumbing` (tests only): the same launcher, rendezvous, barrier, MAX-reduce and gather bookkeeping with the
+gloo backend on CPU tensors and NO device work -- `value` is null and the line says "plumbing": true.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -22,15 +34,16 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
-# Algorithmic bytes per texel of each fused kernel (DESIGN.md "Kernels"):
-#   pass1: read h0 8 + omega 4, write 3 complex fields 24            = 36
-#   pass2: read 3 complex fields 24, write RGBA32F 16                = 40   (frame total 76)
-KERNEL_BYTES_PER_TEXEL = {"pass1": 36.0, "pass2": 40.0}
-# Bytes the shipped half-spectrum algorithm itself has to move: only columns
-# kx < N/2 of the three fields cross between the passes (12 B/texel instead of 24).
-#   pass1: read h0 10 + omega 4 (lines x, x-1, N-x, N-1-x), write 12     = 26
-#   pass2: read 12, write RGBA32F 16                                      = 28   (frame total 54)
-HALF_BYTES_PER_TEXEL = {"pass1": 26.0, "pass2": 28.0}
+# Bytes per texel (of the N^2 frame) each fused kernel of the shipped half-spectrum algorithm has to move
+#  -- what `roofline.achieved` is computed from:
+#   pass1: read h0 10 (lines x, x-1, N-x, N-1-x: 10 distinct lines per 4 columns of the half spectrum; 5 when
+#          the spectrum is stored as fp16 pairs) + omega 4, write the half-spectrum intermediate 12
+#   pass2: read 12, write RGBA32F 16
+MOVED_BYTES_PER_TEXEL = {"f32": {"pass1": 26.0, "pass2": 28.0}, "f16": {"pass1": 21.0, "pass2": 28.0}}
+# The contract accounting of SURVEY.md 8d (three complex 2-D transforms per frame, B_frame = 76 N^2; 72 N^2 with
+# an fp16-stored spectrum): reported next to the real bytes as `contract_*`, never as `achieved`.
+#   pass1: read h0 8 (4) + omega 4, write 3 complex fields 24; pass2: read 24, write RGBA32F 16
+CONTRACT_BYTES_PER_TEXEL = {"f32": {"pass1": 36.0, "pass2": 40.0}, "f16": {"pass1": 32.0, "pass2": 40.0}}
 
 
 def pass_of(kernel_name):
@@ -44,11 +57,12 @@ def aggregate(values_ms, n_gpus, steps):
     return {"ms_per_step": ms_per_step, "value": n_gpus * 1000.0 / ms_per_step}
 
 
-def measured_traffic(n, kernel_name):
+def measured_traffic(n, kernel_name, spectrum="f32"):
     """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and
     WRITE_SIZE are collected in separate runs of this same command, never inside the timed bench;
     gfx950 correction 2*FETCH_SIZE + WRITE_SIZE -- DESIGN.md 7).  None if no pass exists for this N."""
-    path = os.path.join(ROOT, "profiles", f"hbm_traffic_n{n}.json")
+    suffix = "" if spectrum == "f32" else "_f16"
+    path = os.path.join(ROOT, "profiles", f"hbm_traffic_n{n}{suffix}.json")
     try:
         with open(path) as f:
             rec = json.load(f)["kernels"]
@@ -62,11 +76,23 @@ def tile_seed(n, rank):
     return n + rank     # tile r of a multi-GPU run uses seed N + r
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(n, h0, omega, budget_s=10.0, max_frames=12):
     """The C restatement of the reference shaders (oracle/, kind "port") timed on this box's host
     cores on a bounded sample of the same workload: whole frames of the same N until ~budget_s.
     The thread count is the best of {all hardware threads, half, 64, 32, 16} on one probe frame each
-    (the strided column pass does not scale to 256 SMT threads on a 2-socket box)."""
+    (the strided column pass does not scale to 256 SMT threads on a 2-socket box); the 1-thread time of one
+    frame is reported beside it when a frame fits the budget (N <= 4096)."""
     from oracle import c_oracle as cc          # cpu_baseline leg: the oracle as the measured CPU path
     cc.build()
     runner = cc.FrameRunner(h0, omega)
@@ -85,61 +111,209 @@ def cpu_baseline(n, h0, omega, budget_s=10.0, max_frames=12):
         runner.frame(frames / 60.0)
         frames += 1
     dt = time.perf_counter() - t0
+    one = None
+    if n <= 4096:
+        cc.set_threads(1)
+        t1 = time.perf_counter()
+        runner.frame(0.25)
+        one = time.perf_counter() - t1
+        cc.set_threads(best)
     return {"value": frames / dt, "unit": "frames/s", "cores": best, "kind": "port",
+            "one_thread_s_per_frame": one, "cpu_model": cpu_model(), "hardware_threads": hw,
             "sample": f"{frames} whole frames at N={n} ({dt:.1f} s), OpenMP over lines with {best} threads "
                       f"(best of probes {{{', '.join(f'{k}: {v:.2f} s' for k, v in probes.items())}}}, "
-                      f"{hw} hardware threads), radix-2 Stockham with sincosf per butterfly as in the shaders"}
+                      f"{hw} hardware threads, {cpu_model()}), radix-2 Stockham with sincosf per butterfly as in "
+                      f"the shaders" + (f"; 1 thread: {one:.2f} s per frame" if one is not None else "")}
 
 
-def gather_leg(dev, dist, torch, n, n_gpus, rank, steps):
-    """BASELINE config 4 / SURVEY 8e: every tile's RGBA map gathered to rank 0 with one RCCL collective per frame
-    (root ingest N*N*16 B per peer over xGMI).  Two schedules, both reported, neither part of `value`:
-    `ordered`   -- frame and collective on one stream;
+# ------------------------------------------------------------------------------------------------------
+# Final gather (BASELINE config 4 / SURVEY 8e).  The schedule is written against a tiny runtime interface so
+# that the CPU plumbing mode runs the SAME bookkeeping (buffer rotation, event order, collective calls) on
+# gloo tensors: GpuRuntime = torch.cuda streams/events + the HIP frame; PlumbingRuntime = in-order no-ops
+# that log what was asked of them.
+# ------------------------------------------------------------------------------------------------------
+class GpuRuntime:
+    def __init__(self, torch, dev):
+        self.torch, self.dev = torch, dev
+
+    def empty_tile(self, n):
+        return self.torch.empty((n, n, 4), dtype=self.torch.float32, device="cuda")
+
+    def stream(self, name):
+        return self.torch.cuda.Stream()
+
+    def event(self, name):
+        return self.torch.cuda.Event()
+
+    def wait(self, stream, event):
+        stream.wait_event(event)
+
+    def record(self, event, stream):
+        event.record(stream)
+
+    def on(self, stream):
+        return self.torch.cuda.stream(stream)
+
+    def frame(self, out, t, stream):
+        self.dev.bind_displacement(out.data_ptr())
+        self.dev.frame(t, stream=stream.cuda_stream)
+
+    def unbind(self):
+        self.dev.bind_displacement(None)
+
+    def synchronize(self):
+        self.torch.cuda.synchronize()
+
+    def scalar(self, v):
+        return self.torch.tensor([v], dtype=self.torch.float64, device="cuda")
+
+
+class PlumbingRuntime:
+    """CPU stand-in used by `--plumbing` (tests/test_dist.py): no device, no frame; every call is logged."""
+
+    class _Named:
+        def __init__(self, name):
+            self.name = name
+
+    class _Ctx:
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    def __init__(self, torch, rank):
+        self.torch, self.rank, self.log = torch, rank, []
+
+    def empty_tile(self, n):
+        return self.torch.zeros((n, n, 4), dtype=self.torch.float32)
+
+    def stream(self, name):
+        return self._Named(name)
+
+    def event(self, name):
+        return self._Named(name)
+
+    def wait(self, stream, event):
+        self.log.append(("wait", stream.name, event.name))
+
+    def record(self, event, stream):
+        self.log.append(("record", event.name, stream.name))
+
+    def on(self, stream):
+        self.log.append(("on", stream.name))
+        return self._Ctx()
+
+    def frame(self, out, t, stream):
+        out.fill_(float(self.rank + 1))            # a recognisable tile: rank r writes r + 1
+        self.log.append(("frame", stream.name, id(out)))
+
+    def unbind(self):
+        pass
+
+    def synchronize(self):
+        pass
+
+    def scalar(self, v):
+        return self.torch.tensor([v], dtype=self.torch.float64)
+
+
+def gather_leg(rt, dist, n, n_gpus, rank, steps, warm=3):
+    """Every tile's RGBA map gathered to rank 0 with one collective per frame (root ingest N*N*16 B per peer
+    over xGMI).  Two schedules, both reported, neither part of `value`:
+    `ordered`    -- frame and collective on one stream;
     `overlapped` -- two output buffers; the collective of frame f runs on a second stream while frame f+1 is
                     computed (the frame is ~0.2 ms, the root's ingest of 7 x 256 MiB ~1.8 ms: the pipeline is
                     gather-bound and the overlap hides the compute, not the other way round)."""
-    outs = [torch.empty((n, n, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
-    dsts = [[torch.empty_like(outs[0]) for _ in range(n_gpus)] if rank == 0 else None for _ in range(2)]
-    cs, gs = torch.cuda.Stream(), torch.cuda.Stream()
-    frame_done = [torch.cuda.Event() for _ in range(2)]
-    gather_done = [torch.cuda.Event() for _ in range(2)]
+    outs = [rt.empty_tile(n) for _ in range(2)]
+    dsts = [[rt.empty_tile(n) for _ in range(n_gpus)] if rank == 0 else None for _ in range(2)]
+    cs, gs = rt.stream("compute"), rt.stream("gather")
+    frame_done = [rt.event(f"frame_done{b}") for b in range(2)]
+    gather_done = [rt.event(f"gather_done{b}") for b in range(2)]
 
     def run(count, overlapped):
         for i in range(count):
             b = i % 2 if overlapped else 0
             if overlapped:
-                cs.wait_event(gather_done[b])                       # buffer b is free again (frame i-2 gathered)
-            dev.bind_displacement(outs[b].data_ptr())
-            dev.frame(i / 60.0, stream=cs.cuda_stream)
+                rt.wait(cs, gather_done[b])                         # buffer b is free again (frame i-2 gathered)
+            rt.frame(outs[b], i / 60.0, cs)
             if overlapped:
-                frame_done[b].record(cs)
-                gs.wait_event(frame_done[b])
-                with torch.cuda.stream(gs):
+                rt.record(frame_done[b], cs)
+                rt.wait(gs, frame_done[b])
+                with rt.on(gs):
                     dist.gather(outs[b], dsts[b], dst=0)
-                    gather_done[b].record(gs)
+                    rt.record(gather_done[b], gs)
             else:
-                with torch.cuda.stream(cs):
+                with rt.on(cs):
                     dist.gather(outs[b], dsts[b], dst=0)
-        torch.cuda.synchronize()
+        rt.synchronize()
 
     res = {"steps": steps, "bytes_per_peer_per_frame": n * n * 16,
            "collective": "torch.distributed.gather (RCCL send/recv group), one per frame"}
     for name, overlapped in (("ordered", False), ("overlapped", True)):
         for e in gather_done:
-            e.record(gs)
-        run(3, overlapped)
+            rt.record(e, gs)
+        run(warm, overlapped)
         dist.barrier()
         t0 = time.perf_counter()
         run(steps, overlapped)
         ms = (time.perf_counter() - t0) * 1000.0
         dist.barrier()
-        t = torch.tensor([ms], dtype=torch.float64, device="cuda")
+        t = rt.scalar(ms)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ms = float(t.item())
         res[name] = {"ms_per_step": ms / steps, "frames_per_s": n_gpus * 1000.0 * steps / ms,
                      "root_ingest_GBps": (n_gpus - 1) * n * n * 16 / (ms / steps) / 1e6}
-    dev.bind_displacement(None)
+    rt.unbind()
+    if rank == 0:       # what arrived: one scalar per peer tile (checked by the plumbing test; cheap on the GPU)
+        res["peer_tile_first_texel"] = [float(d.reshape(-1)[0].item()) for d in dsts[(steps - 1) % 2]]
     return res
+
+
+# ------------------------------------------------------------------------------------------------------
+# Self-launch: `python bench.py --gpus N` without a launcher spawns N ranks of this same script.
+# ------------------------------------------------------------------------------------------------------
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n_ranks, argv, timeout_s):
+    """One child process per rank (rank r on GPU r); rank 0's stdout is ours, the others only have stderr.
+    Returns the worst exit code.  Children are addressed by PID only (never by pattern)."""
+    port = free_port()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OCEAN_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on these hosts (RCCL needs it)
+        out = None if r == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out))
+    deadline = time.time() + timeout_s
+    worst = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                rc = p.poll()
+                if rc is not None:
+                    pending.remove(p)
+                    worst = max(worst, abs(rc))
+                    if rc != 0:                       # one rank failed: the others would wait on it forever
+                        for q in pending:
+                            q.terminate()
+            if time.time() > deadline:
+                for q in pending:
+                    q.kill()
+                print(f"# bench.py: ranks still running after {timeout_s:.0f} s were killed", file=sys.stderr)
+                return 124
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return worst
 
 
 def main():
@@ -148,13 +322,23 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--n", type=int, default=4096, help="tile edge (power of two, 256..8192)")
+    ap.add_argument("--spectrum", choices=("f32", "f16"), default="f32",
+                    help="storage of the initial spectrum in HBM (f16 = BASELINE config 5: scaled fp16 pairs, fp32 arithmetic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather", action="store_true",
-                    help="also time frames followed by an RCCL gather of every tile's RGBA map to rank 0 "
-                         "(BASELINE config 4; reported separately, never part of `value`)")
-    ap.add_argument("--gather-timeout", type=float, default=180.0, help="seconds before a stuck --gather leg is abandoned")
+    ap.add_argument("--gather", dest="gather", action="store_true", default=None,
+                    help="time frames followed by an RCCL gather of every tile's RGBA map to rank 0 (BASELINE config 4; "
+                         "reported separately, never part of `value`).  Default: on when more than one rank runs")
+    ap.add_argument("--no-gather", dest="gather", action="store_false")
+    ap.add_argument("--gather-steps", type=int, default=30)
+    ap.add_argument("--gather-timeout", type=float, default=120.0, help="seconds before a stuck gather leg is abandoned")
     ap.add_argument("--profile-frames", type=int, default=20, help="frames averaged for the per-kernel durations")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launch: seconds before the ranks are killed")
+    ap.add_argument("--plumbing", action="store_true",
+                    help="tests only: launcher + rendezvous + reductions + gather bookkeeping on gloo/CPU, no device work")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:], args.launch_timeout))
 
     # The JSON line must be the only thing on stdout.  Native libraries (RCCL's banner and WARN lines,
     # written from its own threads) print to fd 1, so keep a private handle on the real stdout and
@@ -166,9 +350,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    n = args.n
     dist = None
+    torch = None
     # OCEAN_BENCH_FORCE_DIST=1 exercises the torch.distributed / RCCL plumbing at world size 1 (1-GPU boxes)
-    if world > 1 or os.environ.get("OCEAN_BENCH_FORCE_DIST") == "1":
+    if world > 1 or os.environ.get("OCEAN_BENCH_FORCE_DIST") == "1" or args.plumbing:
         # torch first: libocean_hip.so then binds to the HIP runtime torch loaded (same soname)
         import torch
         import torch.distributed as dist
@@ -177,22 +363,45 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.plumbing:
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     n_gpus = world if world > 1 else 1
     if args.gpus != n_gpus and rank == 0:
-        print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; using {n_gpus}", file=sys.stderr)
+        print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; the line reports n_gpus={n_gpus}", file=sys.stderr)
+    want_gather = (n_gpus > 1) if args.gather is None else args.gather
 
     import gfx_ocean_amd as g
-    n = args.n
-    h0, omega = g.synth.make_inputs(n, seed=tile_seed(n, rank))
+    seed = tile_seed(n, rank)
+    line = None
+
+    if args.plumbing:
+        # ---- launcher / rendezvous / reduction / gather bookkeeping only; nothing is measured -----------------
+        rt = PlumbingRuntime(torch, rank)
+        dist.barrier()
+        wall_ms = 1.0 + rank                                   # rank r "took" r + 1 ms: the MAX must pick the last rank
+        t = rt.scalar(wall_ms)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        seeds = [None] * world
+        dist.all_gather_object(seeds, seed)
+        gather = gather_leg(rt, dist, min(n, 64), n_gpus, rank, max(1, min(args.gather_steps, 4)), warm=1) if want_gather else None
+        if rank == 0:
+            line = {"metric": "plumbing only (no device work)", "value": None, "unit": "frames/s", "n_gpus": n_gpus,
+                    "steps": args.steps, "warmup": args.warmup, "plumbing": True, "max_rank_ms": float(t.item()),
+                    "seeds": seeds, "gather": gather, "gather_log": rt.log}
+            print(json.dumps(line), file=json_out, flush=True)
+        dist.destroy_process_group()
+        return
+
+    h0, omega = g.synth.make_inputs(n, seed=seed)
     dev = g.OceanDevice(n, device_ordinal=local_rank)
-    dev.upload_spectrum(h0, omega)
+    dev.upload_spectrum(h0, omega, spectrum_fp16=(args.spectrum == "f16"))
 
     def barrier():
         dev.sync()
         if dist is not None:
-            import torch
             torch.cuda.synchronize()
             dist.barrier()
 
@@ -206,7 +415,6 @@ def main():
     barrier()
 
     if dist is not None:
-        import torch
         t = torch.tensor([wall_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         all_ms = [float(t.item())]
@@ -214,61 +422,84 @@ def main():
         all_ms = [wall_ms]
     agg = aggregate(all_ms, n_gpus, args.steps)
 
-    # per-kernel durations, live, HIP events on the stream the kernels run on
+    # per-kernel durations, live, HIP events bound to the dispatches on the stream the kernels run on
     acc = {}
     for i in range(args.profile_frames):
         for name, ms in dev.profile_frame(i / 60.0):
             acc[name] = acc.get(name, 0.0) + ms
+    moved, contract = MOVED_BYTES_PER_TEXEL[args.spectrum], CONTRACT_BYTES_PER_TEXEL[args.spectrum]
     kernels = []
     for name, total in acc.items():
         avg_ms = total / args.profile_frames
-        b = KERNEL_BYTES_PER_TEXEL[pass_of(name)] * n * n
-        rec = {"name": name, "avg_ms": avg_ms, "algorithmic_bytes": b, "GBps": b / avg_ms / 1e6}
-        if "half" in name:
-            hb = HALF_BYTES_PER_TEXEL[pass_of(name)] * n * n
-            rec.update({"half_spectrum_bytes": hb, "half_spectrum_GBps": hb / avg_ms / 1e6})
-        kernels.append(rec)
+        b = moved[pass_of(name)] * n * n
+        cb = contract[pass_of(name)] * n * n
+        kernels.append({"name": name, "avg_ms": avg_ms, "algorithmic_bytes": b, "GBps": b / avg_ms / 1e6,
+                        "frac": b / avg_ms / 1e6 / HBM_PEAK_GBS, "contract_bytes": cb, "contract_GBps": cb / avg_ms / 1e6,
+                        "contract_frac": cb / avg_ms / 1e6 / HBM_PEAK_GBS, "traffic": measured_traffic(n, name, args.spectrum)})
     dom = max(kernels, key=lambda k: k["avg_ms"])
+    frame_ms = event_ms / args.steps
+    fb, fcb = sum(moved.values()) * n * n, sum(contract.values()) * n * n
     roofline = {"bound": "hbm", "kernel": dom["name"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": measured_traffic(n, dom["name"]),
+                "frac": dom["frac"], "traffic": dom["traffic"],
                 "algorithmic_bytes_per_launch": dom["algorithmic_bytes"], "avg_launch_ms": dom["avg_ms"],
+                "accounting": f"achieved = bytes the shipped half-spectrum algorithm must move ({moved['pass1']:.0f} + "
+                              f"{moved['pass2']:.0f} B/texel) / kernel time; contract_* = SURVEY 8d's three-complex-"
+                              f"transform accounting ({contract['pass1']:.0f} + {contract['pass2']:.0f} B/texel) / the same time",
+                "contract_achieved": dom["contract_GBps"], "contract_frac": dom["contract_frac"],
                 "kernels": kernels,
-                "frame": {"algorithmic_bytes": 76.0 * n * n, "GBps": 76.0 * n * n / (event_ms / args.steps) / 1e6,
-                          "frac": 76.0 * n * n / (event_ms / args.steps) / 1e6 / HBM_PEAK_GBS}}
-
-    gather = None
-    if args.gather and dist is not None:
-        import threading
-        import torch
-        # a collective that never completes must not take the measured line with it
-        watchdog = threading.Timer(args.gather_timeout, lambda: os._exit(3))
-        watchdog.daemon = True
-        watchdog.start()
-        try:
-            gather = gather_leg(dev, dist, torch, n, n_gpus, rank, max(1, min(args.steps, 50)))
-        except Exception as e:  # noqa: BLE001 -- reported, never fatal for the main metric
-            gather = {"error": f"{type(e).__name__}: {e}"}
-        watchdog.cancel()
+                "frame": {"algorithmic_bytes": fb, "GBps": fb / frame_ms / 1e6, "frac": fb / frame_ms / 1e6 / HBM_PEAK_GBS,
+                          "contract_bytes": fcb, "contract_GBps": fcb / frame_ms / 1e6,
+                          "contract_frac": fcb / frame_ms / 1e6 / HBM_PEAK_GBS}}
 
     if rank == 0:
+        spec_txt = "fp32 spectrum" if args.spectrum == "f32" else "fp16-stored spectrum (scaled pairs), fp32 arithmetic and intermediate"
         line = {
             "metric": "ocean frames/sec (propagate + 3x 2-D iFFT + correction, one NxN tile per GPU)",
             "value": agg["value"], "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": agg["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"N={n} tile per GPU, fused frame (2 launches: propagate + column pass, row pass + "
-                                   f"correction), height+disp_x+disp_z; algorithmic bytes counted as for 3 complex "
-                                   f"iFFTs/frame (76 B/texel, SURVEY 8d), computed with the half-spectrum real-output "
-                                   f"algorithm (54 B/texel actually moved); seed N+rank",
-                       "n": n, "tiles": n_gpus, "parallelism": f"tile-parallel x{n_gpus}, no data-path collective",
-                       "gpu_event_ms_per_step": event_ms / args.steps},
+            "config": {"workload": f"N={n} tile per GPU, {spec_txt}, fused frame (2 launches: propagate + column pass, "
+                                   f"row pass + correction), height+disp_x+disp_z; half-spectrum real-output algorithm: "
+                                   f"{sum(moved.values()):.0f} B/texel moved ({sum(contract.values()):.0f} B/texel on the "
+                                   f"three-complex-transform accounting of SURVEY 8d); seed N+rank",
+                       "n": n, "spectrum": args.spectrum, "tiles": n_gpus,
+                       "parallelism": f"tile-parallel x{n_gpus}, no data-path collective",
+                       "gpu_event_ms_per_step": frame_ms},
             "roofline": roofline,
         }
-        if gather is not None:
-            line["gather"] = gather
-        if n_gpus == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(n, h0, omega)
-        print(json.dumps(line), file=json_out, flush=True)
+
+    emitted = threading.Event()
+
+    def emit(extra=None):
+        """Print the one line (rank 0) exactly once."""
+        if emitted.is_set():
+            return
+        emitted.set()
+        if rank == 0:
+            if extra:
+                line.update(extra)
+            print(json.dumps(line), file=json_out, flush=True)
+
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(n, h0, omega)
+
+    if want_gather and dist is not None:
+        # A collective that never completes must not take the measured line with it: on timeout rank 0 prints the
+        # line without the leg and every rank leaves.
+        def abandon():
+            emit({"gather": {"error": f"abandoned after {args.gather_timeout:.0f} s"}})
+            os._exit(0)
+        watchdog = threading.Timer(args.gather_timeout, abandon)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            gather = gather_leg(GpuRuntime(torch, dev), dist, n, n_gpus, rank, max(1, args.gather_steps))
+        except Exception as e:  # noqa: BLE001 -- reported, never fatal for the main metric
+            gather = {"error": f"{type(e).__name__}: {e}"}
+        watchdog.cancel()
+        emit({"gather": gather})
+    else:
+        emit()
     dev.destroy()
     if dist is not None:
         dist.destroy_process_group()

@@ -1,13 +1,25 @@
-"""Importable alias of the ``gfx-ocean_amd/`` package directory (a hyphen cannot be imported).
+"""gfx_ocean_amd -- MI355X-native ocean height-field path (propagate -> 2-D iFFT -> correction).
 
-``import gfx_ocean_amd`` executes ``gfx-ocean_amd/__init__.py`` with this module's
-``__path__`` pointing at that directory, so ``gfx_ocean_amd.ocean`` is
-``gfx-ocean_amd/ocean.py`` and so on.  No code lives here.
+Host-side mirror of the reference's private ``ocean`` / ``fft`` modules
+(src/ocean.rs, src/fft.rs) and of the compute slice of ``Renderer`` (src/render.rs),
+over the C ABI in ``include/ocean_hip.h`` (HIP kernels in ``csrc/``).
+
+There is no CPU fallback: importing works anywhere, but creating an
+``OceanDevice`` raises ``OceanError`` if ``libocean_hip.so`` is missing or no
+gfx950 device is present.
 """
-import os as _os
+from ._lib import OceanError, build_library, library_path, load_library  # noqa: F401
+from .ocean import (Correction, CorrectionLocals, Propagation, PropagateLocals,  # noqa: F401
+                    DOMAIN_SIZE, RESOLUTION)
+from .fft import Fft  # noqa: F401
+from .render import (OceanDevice, OceanRenderer, FIELD_DX, FIELD_DY, FIELD_DZ, FIELD_ALL,  # noqa: F401
+                     QUIRK_Q1, QUIRK_Q2, QUIRKS_REFERENCE)
+from . import bincode, synth  # noqa: F401
 
-_REAL = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "gfx-ocean_amd")
-__path__ = [_REAL]
-with open(_os.path.join(_REAL, "__init__.py")) as _f:
-    exec(compile(_f.read(), _os.path.join(_REAL, "__init__.py"), "exec"))
-del _f
+__all__ = [
+    "OceanError", "build_library", "library_path", "load_library",
+    "Correction", "CorrectionLocals", "Propagation", "PropagateLocals", "Fft",
+    "OceanDevice", "OceanRenderer", "FIELD_DX", "FIELD_DY", "FIELD_DZ", "FIELD_ALL",
+    "QUIRK_Q1", "QUIRK_Q2", "QUIRKS_REFERENCE",
+    "DOMAIN_SIZE", "RESOLUTION", "bincode", "synth",
+]

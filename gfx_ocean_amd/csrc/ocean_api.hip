@@ -11,8 +11,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/ocean_hip.h"
@@ -30,6 +32,16 @@ constexpr uint32_t MAGIC_PRO = 0x4F50524F;
 constexpr uint32_t MAGIC_COR = 0x4F434F52;
 
 bool supported_n(int n) { return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096 || n == 8192; }
+
+// Every handle the library has handed out and not yet destroyed.  A handle is checked against this set before it
+// is dereferenced, so a stage object used after ocean_context_destroy, a double destroy or a stray pointer gets
+// OCEAN_E_INVALID_ARG instead of a read of freed memory (the reference has the same life-cycle rule -- stages
+// are destroyed before the device, src/render.rs:1383-1438 -- but enforces nothing).
+std::mutex g_live_mu;
+std::unordered_set<const void*> g_live;
+void live_add(const void* p) { std::lock_guard<std::mutex> l(g_live_mu); g_live.insert(p); }
+void live_remove(const void* p) { std::lock_guard<std::mutex> l(g_live_mu); g_live.erase(p); }
+bool live(const void* p) { if (!p) return false; std::lock_guard<std::mutex> l(g_live_mu); return g_live.count(p) != 0; }
 
 }  // namespace
 
@@ -88,7 +100,8 @@ int32_t hip_fail(OceanContext* ctx, hipError_t e, const char* what) {
         if (e_ != hipSuccess) return hip_fail((ctx), e_, #expr);        \
     } while (0)
 
-bool valid(const OceanContext* c) { return c && c->magic == MAGIC_CTX; }
+bool valid(const OceanContext* c) { return live(c) && c->magic == MAGIC_CTX; }
+template <class H> bool valid_stage(const H* h, uint32_t magic) { return live(h) && h->magic == magic && valid(h->ctx); }
 
 struct DeviceGuard {
     int prev = -1;
@@ -117,6 +130,7 @@ template <int N> struct Launch {
         e = hipFuncSetAttribute((const void*)k_fft_lines<N, G::E, G::COL_LPW, true>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, G::col_lds);
         if (e != hipSuccess) return e;
+#ifdef OCEAN_AB   // A/B builds only (tools/ab_variants.sh): the three-complex-transform frame and the other line counts
         e = hipFuncSetAttribute((const void*)k_frame_pass1<N, G::E, G::P>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, G::frame_lds);
         if (e != hipSuccess) return e;
@@ -132,20 +146,38 @@ template <int N> struct Launch {
         if (e != hipSuccess) return e;
         if constexpr (N <= 4096) e = prepare_half<2>();
         return e;
+#else
+        return prepare_half<default_psel()>();
+#endif
     }
+    // Lines per pass-1 workgroup of the shipped frame, per size (measured best): 2 where two
+    // co-resident workgroups pay (512, 2048) and where 4 lines do not fit (8192), else 4.
+    static constexpr int default_psel() { return (N == 512 || N == 2048 || N > 4096) ? 2 : 4; }
+    static constexpr bool default_split() { return N > 4096; }
+    // Which (plain, split) kernel pairs exist in this build: everything selectable in an A/B build, only the
+    // size's default in the shipped one (no untested kernel ships).
+#ifdef OCEAN_AB
+    template <int PSEL> static constexpr bool plain_built() { return true; }
+    template <int PSEL> static constexpr bool split_built() { return Geo<N, PSEL>::can_split; }
+#else
+    template <int PSEL> static constexpr bool plain_built() { return !default_split(); }
+    template <int PSEL> static constexpr bool split_built() { return default_split() && Geo<N, PSEL>::can_split; }
+#endif
     template <int PSEL> static hipError_t prepare_half() {
         using H = Geo<N, PSEL>;
-        hipError_t e;
-        e = hipFuncSetAttribute((const void*)k_half_pass1<N, H::E, H::P, false>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, H::frame_lds);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)k_half_pass1<N, H::E, H::P, true>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, H::frame_lds);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)k_half_pass2<N, H::E, CHUNK_W, H::R2>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, H::thin_lds);
-        if (e != hipSuccess) return e;
-        if constexpr (H::can_split) {
+        hipError_t e = hipSuccess;
+        if constexpr (plain_built<PSEL>()) {
+            e = hipFuncSetAttribute((const void*)k_half_pass1<N, H::E, H::P, false>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, H::frame_lds);
+            if (e != hipSuccess) return e;
+            e = hipFuncSetAttribute((const void*)k_half_pass1<N, H::E, H::P, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, H::frame_lds);
+            if (e != hipSuccess) return e;
+            e = hipFuncSetAttribute((const void*)k_half_pass2<N, H::E, CHUNK_W, H::R2>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, H::thin_lds);
+            if (e != hipSuccess) return e;
+        }
+        if constexpr (split_built<PSEL>()) {
             e = hipFuncSetAttribute((const void*)k_half_pass1_split<N, H::E, H::P, false>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, H::split_lds1);
             if (e != hipSuccess) return e;
@@ -160,7 +192,7 @@ template <int N> struct Launch {
     template <int PSEL> static void half_pass1(OceanContext* c, float time, float domain, hipStream_t s, Timing t) {
         using H = Geo<N, PSEL>;
         const float descale = std::ldexp(1.0f, -c->scale_log2);
-        if constexpr (H::can_split) {
+        if constexpr (split_built<PSEL>()) {
             if (c->split) {
                 if (c->h0_f16)
                     launch(k_half_pass1_split<N, H::E, H::P, true>, dim3(H::half_grid1), dim3(H::frame_threads),
@@ -173,26 +205,29 @@ template <int N> struct Launch {
                 return;
             }
         }
-        if (c->h0_f16)
-            launch(k_half_pass1<N, H::E, H::P, true>, dim3(H::half_grid1), dim3(H::frame_threads), H::frame_lds, s, t,
-                   (const void*)c->h0T, descale, (const float*)c->omegaT, c->inter, c->nyq, (const c32*)c->tw, c->lay_h,
-                   time, domain);
-        else
-            launch(k_half_pass1<N, H::E, H::P, false>, dim3(H::half_grid1), dim3(H::frame_threads), H::frame_lds, s, t,
-                   (const void*)c->h0T, 1.0f, (const float*)c->omegaT, c->inter, c->nyq, (const c32*)c->tw, c->lay_h,
-                   time, domain);
+        if constexpr (plain_built<PSEL>()) {
+            if (c->h0_f16)
+                launch(k_half_pass1<N, H::E, H::P, true>, dim3(H::half_grid1), dim3(H::frame_threads), H::frame_lds, s, t,
+                       (const void*)c->h0T, descale, (const float*)c->omegaT, c->inter, c->nyq, (const c32*)c->tw,
+                       c->lay_h, time, domain);
+            else
+                launch(k_half_pass1<N, H::E, H::P, false>, dim3(H::half_grid1), dim3(H::frame_threads), H::frame_lds, s, t,
+                       (const void*)c->h0T, 1.0f, (const float*)c->omegaT, c->inter, c->nyq, (const c32*)c->tw,
+                       c->lay_h, time, domain);
+        }
     }
     template <int PSEL> static void half_pass2(OceanContext* c, hipStream_t s, Timing t) {
         using H = Geo<N, PSEL>;
-        if constexpr (H::can_split) {
+        if constexpr (split_built<PSEL>()) {
             if (c->split) {
                 launch(k_half_pass2_split<N, H::E, CHUNK_W>, dim3(N), dim3(H::split_threads2), H::split_lds2, s, t,
                        (const c32*)c->inter, c->out, (const c32*)c->tw, c->lay_h);
                 return;
             }
         }
-        launch(k_half_pass2<N, H::E, CHUNK_W, H::R2>, dim3(H::thin_grid), dim3(H::thin_threads), H::thin_lds, s, t,
-               (const c32*)c->inter, c->out, (const c32*)c->tw, c->lay_h);
+        if constexpr (plain_built<PSEL>())
+            launch(k_half_pass2<N, H::E, CHUNK_W, H::R2>, dim3(H::thin_grid), dim3(H::thin_threads), H::thin_lds, s, t,
+                   (const c32*)c->inter, c->out, (const c32*)c->tw, c->lay_h);
     }
     static void rows(OceanContext* c, c32* data, hipStream_t s) {
         hipLaunchKernelGGL((k_fft_lines<N, G::E, G::ROW_LPW, false>), dim3(G::row_grid), dim3(G::row_threads),
@@ -203,6 +238,7 @@ template <int N> struct Launch {
                            G::col_lds, s, data, c->tw);
     }
     static void pass1(OceanContext* c, float time, float domain, hipStream_t s, Timing t = Timing()) {
+#ifdef OCEAN_AB
         if (c->half) {
             if constexpr (N <= 4096) { if (c->Ph == 2) { half_pass1<2>(c, time, domain, s, t); return; } }
             half_pass1<0>(c, time, domain, s, t);
@@ -210,8 +246,12 @@ template <int N> struct Launch {
         }
         launch(k_frame_pass1<N, G::E, G::P>, dim3(G::frame_grid), dim3(G::frame_threads), G::frame_lds, s, t,
                (const c32*)c->h0T, (const float*)c->omegaT, c->inter, (const c32*)c->tw, c->lay, time, domain);
+#else
+        half_pass1<default_psel()>(c, time, domain, s, t);
+#endif
     }
     static void pass2(OceanContext* c, hipStream_t s, Timing t = Timing()) {
+#ifdef OCEAN_AB
         if (c->half) {
             if constexpr (N <= 4096) { if (c->Ph == 2) { half_pass2<2>(c, s, t); return; } }
             half_pass2<0>(c, s, t);
@@ -226,6 +266,9 @@ template <int N> struct Launch {
         }
         launch(k_frame_pass2_thin<N, G::E, CHUNK_W, G::R2>, dim3(G::thin_grid), dim3(G::thin_threads), G::thin_lds, s, t,
                (const c32*)c->inter, c->out, (const c32*)c->tw, c->lay);
+#else
+        half_pass2<default_psel()>(c, s, t);
+#endif
     }
 };
 
@@ -301,17 +344,28 @@ int32_t ocean_context_create(int32_t device, int32_t resolution, OceanContext** 
     if (!c) return fail(nullptr, OCEAN_E_OOM, "host allocation failed");
     c->device = device;
     c->n = resolution;
-    if (const char* v = std::getenv("OCEAN_PASS2")) c->pass2_thin = (std::strcmp(v, "fat") != 0);
     DeviceGuard guard(device);
     const size_t n2 = (size_t)resolution * resolution;
     c->P = frame_p(resolution);
     {
         // Chunks are 4 x 4 complex (128 B); chunk (X, Y) at X*sx + Y*sy, +32 elements
         // (256 B) of padding per slab so that the strided side of the hand-off does not revisit one channel.
-        // pass-2-contiguous (default): the chunks of one chunk row are adjacent; OCEAN_INTER_LAYOUT=p1
-        // selects pass-1-contiguous (A/B).
-        const char* v = std::getenv("OCEAN_INTER_LAYOUT");
-        const bool p1 = v && std::strcmp(v, "p1") == 0;
+        // Pass-2-contiguous: the chunks of one chunk row are adjacent.
+        bool p1 = false;
+        // lines per pass-1 workgroup of the half-spectrum path: measured best per size (run 14): two
+        // co-resident 2-line workgroups win where the intermediate is cache-resident (512, 2048) and
+        // are the only option at 8192; one 4-line workgroup wins at 4096 (whole-chunk non-temporal stores).
+        OCEAN_DISPATCH(resolution, { c->Ph = L::default_psel(); c->split = L::default_split(); });
+#ifdef OCEAN_AB
+        // A/B builds (tools/ab_variants.sh) read their variant from the environment; the shipped library has no
+        // environment-dependent behaviour.
+        if (const char* v = std::getenv("OCEAN_PASS2")) c->pass2_thin = (std::strcmp(v, "fat") != 0);
+        if (const char* v = std::getenv("OCEAN_INTER_LAYOUT")) p1 = std::strcmp(v, "p1") == 0;   // pass-1-contiguous
+        if (const char* pe = std::getenv("OCEAN_P")) { const int pv = std::atoi(pe); if (pv == 2 || (pv == 4 && resolution <= 4096)) c->Ph = pv; }
+        if (const char* a = std::getenv("OCEAN_ALGO")) c->half = (std::strcmp(a, "c2c") != 0);
+        // N = 8192 = 2 * 16^3 has no three-pass plan: its lines run as two interleaved 4096-point transforms
+        if (const char* sp = std::getenv("OCEAN_SPLIT")) c->split = (std::atoi(sp) != 0) && c->Ph == 2 && resolution >= 512;
+#endif
         auto make = [&](size_t columns) {
             InterLayout l{0, 0, 0};
             const size_t gx = columns / CHUNK_W, gy = (size_t)resolution / CHUNK_R;
@@ -319,17 +373,8 @@ int32_t ocean_context_create(int32_t device, int32_t resolution, OceanContext** 
             else { l.sx = 16; l.sy = gx * 16 + 32; l.fs = l.sy * gy; }
             return l;
         };
-        // lines per pass-1 workgroup of the half-spectrum path: measured best per size (run 14): two
-        // co-resident 2-line workgroups win where the intermediate is cache-resident (512, 2048) and
-        // are the only option at 8192; one 4-line workgroup wins at 4096 (whole-chunk non-temporal stores).
-        c->Ph = (resolution == 512 || resolution == 2048 || resolution > 4096) ? 2 : 4;
-        if (const char* pe = std::getenv("OCEAN_P")) { const int pv = std::atoi(pe); if (pv == 2 || (pv == 4 && resolution <= 4096)) c->Ph = pv; }
         c->lay = make((size_t)resolution);
         c->lay_h = make((size_t)resolution / 2);
-        if (const char* a = std::getenv("OCEAN_ALGO")) c->half = (std::strcmp(a, "c2c") != 0);
-        // N = 8192 = 2 * 16^3 has no three-pass plan: its lines run as two interleaved 4096-point transforms
-        c->split = (resolution > 4096);
-        if (const char* sp = std::getenv("OCEAN_SPLIT")) c->split = (std::atoi(sp) != 0) && c->Ph == 2 && resolution >= 512;
     }
     auto bail = [&](hipError_t err, const char* what) {
         const int32_t code = hip_fail(nullptr, err, what);
@@ -346,7 +391,11 @@ int32_t ocean_context_create(int32_t device, int32_t resolution, OceanContext** 
     for (int f = 0; f < 3; ++f) CTX_TRY(hipMalloc((void**)&c->field[f], n2 * sizeof(c32)));
     CTX_TRY(hipMalloc((void**)&c->h0T, n2 * sizeof(c32)));
     CTX_TRY(hipMalloc((void**)&c->omegaT, n2 * sizeof(float)));
+    #ifdef OCEAN_AB
     CTX_TRY(hipMalloc((void**)&c->inter, 3 * c->lay.fs * sizeof(c32)));
+#else
+    CTX_TRY(hipMalloc((void**)&c->inter, 3 * c->lay_h.fs * sizeof(c32)));
+#endif
     CTX_TRY(hipMalloc((void**)&c->nyq, 3 * (size_t)resolution * sizeof(c32)));
     CTX_TRY(hipMalloc((void**)&c->out_own, n2 * sizeof(float4)));
     CTX_TRY(hipMalloc((void**)&c->tw, (size_t)resolution * sizeof(c32)));
@@ -365,12 +414,14 @@ int32_t ocean_context_create(int32_t device, int32_t resolution, OceanContext** 
         if (pe != hipSuccess) return bail(pe, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     }
 #undef CTX_TRY
+    live_add(c);
     *out_ctx = c;
     return OCEAN_OK;
 }
 
 void ocean_context_destroy(OceanContext* ctx) {
     if (!valid(ctx)) return;
+    live_remove(ctx);
     DeviceGuard guard(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     free_all(ctx);
@@ -475,10 +526,11 @@ int32_t ocean_fft_init(OceanContext* ctx, OceanFft** out) {
     OceanFft* f = new (std::nothrow) OceanFft();
     if (!f) return fail(ctx, OCEAN_E_OOM, "host allocation failed");
     f->ctx = ctx;
+    live_add(f);
     *out = f;
     return OCEAN_OK;
 }
-void ocean_fft_destroy(OceanFft* fft) { if (fft && fft->magic == MAGIC_FFT) { fft->magic = 0; delete fft; } }
+void ocean_fft_destroy(OceanFft* fft) { if (live(fft) && fft->magic == MAGIC_FFT) { live_remove(fft); fft->magic = 0; delete fft; } }
 
 int32_t ocean_propagation_init(OceanContext* ctx, OceanPropagation** out) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
@@ -486,10 +538,11 @@ int32_t ocean_propagation_init(OceanContext* ctx, OceanPropagation** out) {
     OceanPropagation* p = new (std::nothrow) OceanPropagation();
     if (!p) return fail(ctx, OCEAN_E_OOM, "host allocation failed");
     p->ctx = ctx;
+    live_add(p);
     *out = p;
     return OCEAN_OK;
 }
-void ocean_propagation_destroy(OceanPropagation* p) { if (p && p->magic == MAGIC_PRO) { p->magic = 0; delete p; } }
+void ocean_propagation_destroy(OceanPropagation* p) { if (live(p) && p->magic == MAGIC_PRO) { live_remove(p); p->magic = 0; delete p; } }
 
 int32_t ocean_correction_init(OceanContext* ctx, OceanCorrection** out) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
@@ -497,14 +550,15 @@ int32_t ocean_correction_init(OceanContext* ctx, OceanCorrection** out) {
     OceanCorrection* c = new (std::nothrow) OceanCorrection();
     if (!c) return fail(ctx, OCEAN_E_OOM, "host allocation failed");
     c->ctx = ctx;
+    live_add(c);
     *out = c;
     return OCEAN_OK;
 }
-void ocean_correction_destroy(OceanCorrection* c) { if (c && c->magic == MAGIC_COR) { c->magic = 0; delete c; } }
+void ocean_correction_destroy(OceanCorrection* c) { if (live(c) && c->magic == MAGIC_COR) { live_remove(c); c->magic = 0; delete c; } }
 
 // ---- dispatches ---------------------------------------------------------------------------------
 int32_t ocean_propagate(OceanPropagation* p, const OceanPropagateLocals* locals, void* stream) {
-    if (!p || p->magic != MAGIC_PRO || !valid(p->ctx)) return OCEAN_E_INVALID_ARG;
+    if (!valid_stage(p, MAGIC_PRO)) return OCEAN_E_INVALID_ARG;
     OceanContext* c = p->ctx;
     if (!locals) return fail(c, OCEAN_E_INVALID_ARG, "locals is NULL");
     if (locals->resolution != c->n) return fail(c, OCEAN_E_INVALID_ARG, "PropagateLocals.resolution != context resolution");
@@ -516,7 +570,7 @@ int32_t ocean_propagate(OceanPropagation* p, const OceanPropagateLocals* locals,
 }
 
 static int32_t fft_pass_common(OceanFft* fft, int32_t field, void* stream, bool cols) {
-    if (!fft || fft->magic != MAGIC_FFT || !valid(fft->ctx)) return OCEAN_E_INVALID_ARG;
+    if (!valid_stage(fft, MAGIC_FFT)) return OCEAN_E_INVALID_ARG;
     OceanContext* c = fft->ctx;
     if (field != OCEAN_FIELD_ALL && (field < 0 || field > 2)) return fail(c, OCEAN_E_INVALID_ARG, "bad field selector");
     DeviceGuard guard(c->device);
@@ -530,7 +584,7 @@ int32_t ocean_fft_rows(OceanFft* fft, int32_t field, void* stream) { return fft_
 int32_t ocean_fft_cols(OceanFft* fft, int32_t field, void* stream) { return fft_pass_common(fft, field, stream, true); }
 
 int32_t ocean_correct(OceanCorrection* cor, const OceanCorrectionLocals* locals, void* stream) {
-    if (!cor || cor->magic != MAGIC_COR || !valid(cor->ctx)) return OCEAN_E_INVALID_ARG;
+    if (!valid_stage(cor, MAGIC_COR)) return OCEAN_E_INVALID_ARG;
     OceanContext* c = cor->ctx;
     if (!locals) return fail(c, OCEAN_E_INVALID_ARG, "locals is NULL");
     if (locals->resolution != (uint32_t)c->n) return fail(c, OCEAN_E_INVALID_ARG, "CorrectionLocals.resolution != context resolution");
@@ -684,8 +738,18 @@ static int32_t profile_common(OceanContext* ctx, float time, int32_t cap, const 
         return fail(ctx, OCEAN_E_STATE, "the fused kernels implement the reference quirks only (ocean_set_quirks)");
     DeviceGuard guard(ctx->device);
     hipStream_t s = ctx->stream;
-    hipEvent_t ev[9], kev[4];
-    for (int i = 0; i <= count; ++i) HIP_TRY(ctx, hipEventCreate(&ev[i]));
+    struct Events {                                // destroyed on every exit path (HIP_TRY returns early)
+        hipEvent_t e[13] = {};
+        int n = 0;
+        hipError_t add(int count) {
+            for (int i = 0; i < count; ++i) { hipError_t r = hipEventCreate(&e[n]); if (r != hipSuccess) return r; ++n; }
+            return hipSuccess;
+        }
+        ~Events() { for (int i = 0; i < n; ++i) (void)hipEventDestroy(e[i]); }
+    } bag;
+    HIP_TRY(ctx, bag.add(count + 1 + (staged ? 0 : 4)));
+    hipEvent_t* ev = bag.e;                        // count + 1 stream events
+    hipEvent_t* kev = bag.e + count + 1;           // fused: begin/end of the two dispatches
     HIP_TRY(ctx, hipEventRecord(ev[0], s));
     if (staged) {
         launch_propagate(ctx, time, ctx->default_domain, s);
@@ -697,7 +761,6 @@ static int32_t profile_common(OceanContext* ctx, float time, int32_t cap, const 
     } else {
         // the fused kernels are timed by events bound to their own dispatches (see launch())
         // behind two untimed frames, so that the timed one runs in the steady state of a frame loop
-        for (int i = 0; i < 4; ++i) HIP_TRY(ctx, hipEventCreate(&kev[i]));
         for (int w = 0; w < 2; ++w) launch_frame(ctx, time, ctx->default_domain, s);
         OCEAN_DISPATCH(ctx->n, L::pass1(ctx, time, ctx->default_domain, s, Timing{kev[0], kev[1]}));
         OCEAN_DISPATCH(ctx->n, L::pass2(ctx, s, Timing{kev[2], kev[3]}));
@@ -709,8 +772,6 @@ static int32_t profile_common(OceanContext* ctx, float time, int32_t cap, const 
         if (staged) HIP_TRY(ctx, hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
         else HIP_TRY(ctx, hipEventElapsedTime(&ms[i], kev[2 * i], kev[2 * i + 1]));
     }
-    for (int i = 0; i <= count; ++i) (void)hipEventDestroy(ev[i]);
-    if (!staged) for (int i = 0; i < 4; ++i) (void)hipEventDestroy(kev[i]);
     *out_n = count;
     return check_launch(ctx, "profile");
 }

@@ -171,8 +171,8 @@ k_positions(const float4* __restrict__ rgba, float4* __restrict__ positions, int
     const uint32_t uv_ = (uint32_t)verts;
     if (index >= uv_ * uv_) return;
     const uint32_t vx = index % uv_, vz = index / uv_;
-    const float inv = 1.0f / (float)(verts - 1);
-    const float u = (float)vx * inv, v = (float)vz * inv;          // src/render.rs:503-504
+    const float den = (float)(verts - 1);
+    const float u = (float)vx / den, v = (float)vz / den;          // `(x as f32) / (V - 1) as f32`, src/render.rs:503-504
     const float tx = u * (float)n - 0.5f, ty = v * (float)n - 0.5f;
     const float fx = floorf(tx), fy = floorf(ty);
     const float wx = tx - fx, wy = ty - fy;

@@ -55,6 +55,8 @@ class _Stage:
     def _handle(self):
         if not self._h:
             raise OceanError(-5, f"{type(self).__name__} used after destroy()")
+        if not self.device.alive:
+            raise OceanError(-5, f"{type(self).__name__} used after its OceanDevice was destroyed")
         return self._h
 
 

@@ -32,7 +32,13 @@ class OceanDevice:
         if status != OCEAN_OK:
             raise OceanError(status, (load_library().ocean_last_error(self._ctx) or b"").decode())
 
+    @property
+    def alive(self) -> bool:
+        return bool(self._ctx)
+
     def destroy(self):
+        """Frees the device buffers.  Stage objects created from this device refuse further use (their
+        `_handle()` checks `alive`; the C ABI additionally rejects handles of a destroyed context)."""
         if self._ctx:
             load_library().ocean_context_destroy(self._ctx)
             self._ctx = None
@@ -92,11 +98,11 @@ class OceanDevice:
         """Finite-difference normals of the current displacement map; channel 0 = disp_x as the
         reference does (quirk Q5), 1 = height.  -> float32 [N, N, 4] = (n.x, n.y, n.z, 0)."""
         lib = load_library()
-        self._check(lib.ocean_normals(self._ctx, int(source_channel), stream))
+        if stream is not None:    # checked BEFORE anything is launched: the readback synchronises the context stream only
+            raise OceanError(-1, "normals(): pass stream=None (the readback synchronises the context stream)")
+        self._check(lib.ocean_normals(self._ctx, int(source_channel), None))
         n = self.resolution
         out = np.empty((n, n, 4), dtype=np.float32)
-        if stream is not None:
-            raise OceanError(-1, "normals(): pass stream=None (the readback synchronises the context stream)")
         self._check(lib.ocean_read_normals(self._ctx, out.ctypes.data))
         return out
 
@@ -107,7 +113,9 @@ class OceanDevice:
         """World positions of a verts x verts patch (src/render.rs:494-508) displaced by the current map,
         sampled bilinearly with wrap as the reference's sampler does.  -> float32 [verts, verts, 4]."""
         lib = load_library()
-        self._check(lib.ocean_positions(self._ctx, int(verts), float(offset[0]), float(offset[1]), stream))
+        if stream is not None:    # same rule as normals(): the readback below waits for the context stream only
+            raise OceanError(-1, "positions(): pass stream=None (the readback synchronises the context stream)")
+        self._check(lib.ocean_positions(self._ctx, int(verts), float(offset[0]), float(offset[1]), None))
         out = np.empty((verts, verts, 4), np.float32)
         self._check(lib.ocean_read_positions(self._ctx, out.ctypes.data))
         return out

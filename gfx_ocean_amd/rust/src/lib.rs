@@ -49,9 +49,23 @@ impl Device {
         if st == 0 { Ok(()) } else { Err(Box::new(error(self.ctx, st))) }
     }
     /// bincode-decoded `Vec<[f32; 2]>` / `Vec<f32>` exactly as src/render.rs:769-771, :808-810 produce them.
+    /// The C ABI reads exactly N*N complex and N*N real values: anything else is rejected here, so the safe
+    /// function cannot read past a short slice.
     pub fn upload_spectrum(&self, spectrum: &[[f32; 2]], omega: &[f32]) -> Result<(), Box<dyn Error>> {
+        let n2 = self.texels()?;
+        if spectrum.len() != n2 || omega.len() != n2 {
+            return Err(Box::new(OceanError { status: -1, message: format!(
+                "upload_spectrum: expected {} spectrum and omega entries, got {} and {}", n2, spectrum.len(), omega.len()) }));
+        }
         self.check(unsafe { ffi::ocean_upload_spectrum(self.ctx, spectrum.as_ptr() as *const f32, omega.as_ptr()) })
     }
+    /// Resolution of the context (the reference's RESOLUTION, src/render.rs:44).
+    pub fn resolution(&self) -> Result<usize, Box<dyn Error>> {
+        let n = unsafe { ffi::ocean_resolution(self.ctx) };
+        if n <= 0 { return Err(Box::new(error(self.ctx, n))); }
+        Ok(n as usize)
+    }
+    fn texels(&self) -> Result<usize, Box<dyn Error>> { let n = self.resolution()?; Ok(n * n) }
     pub fn frame(&self, time: f32) -> Result<(), Box<dyn Error>> {
         self.check(unsafe { ffi::ocean_frame(self.ctx, time, ptr::null_mut()) })
     }
@@ -59,7 +73,13 @@ impl Device {
     pub fn set_quirks(&self, quirks: u32) -> Result<(), Box<dyn Error>> {
         self.check(unsafe { ffi::ocean_set_quirks(self.ctx, quirks) })
     }
+    /// Writes N*N RGBA32F texels; the slice must hold exactly N*N*4 floats.
     pub fn read_displacement(&self, rgba: &mut [f32]) -> Result<(), Box<dyn Error>> {
+        let want = self.texels()? * 4;
+        if rgba.len() != want {
+            return Err(Box::new(OceanError { status: -1, message: format!(
+                "read_displacement: expected a slice of {} floats, got {}", want, rgba.len()) }));
+        }
         self.check(unsafe { ffi::ocean_read_displacement(self.ctx, rgba.as_mut_ptr()) })
     }
     pub fn raw(&self) -> *mut ffi::OceanContext { self.ctx }

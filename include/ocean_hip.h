@@ -5,7 +5,7 @@
  * (src/lib.rs:38-39) and for the 190-line dispatch block of `Renderer::render`
  * (src/render.rs:1101-1310).  Plain pointers and sizes only: a Rust shim binds
  * these with `extern "C"` (INTEGRATION.md shows the stub), Python binds them
- * with ctypes (gfx-ocean_amd/_lib.py), C++ through host/ocean.hpp.
+ * with ctypes (gfx_ocean_amd/_lib.py), C++ through host/ocean.hpp.
  *
  * Conventions
  *   - Every call returns an int32_t status (OCEAN_OK = 0, negative = error) and

@@ -3,7 +3,7 @@
  * (1) the second CPU oracle and (2) the timed "reference path on host cores"
  * baseline (bench.py cpu_baseline, kind "port").
  *
- * TEST INFRASTRUCTURE ONLY: nothing under gfx-ocean_amd/ links or loads this.
+ * TEST INFRASTRUCTURE ONLY: nothing under gfx_ocean_amd/ links or loads this.
  * PARITY UNPINNED by the reference's own tests (it has none and cannot be built
  * here: Rust + gfx-hal + Vulkan absent) -- see oracle/ocean_oracle.py header
  * for what pins it instead.

@@ -2,7 +2,7 @@
 
 TEST INFRASTRUCTURE ONLY.  Only ``tests/``, ``__graft_entry__.smoke()`` and
 ``bench.py``'s ``cpu_baseline`` leg may import this module; the product path
-(``gfx-ocean_amd/``) never does and fails loudly when its HIP library is missing.
+(``gfx_ocean_amd/``) never does and fails loudly when its HIP library is missing.
 
 PARITY PINNING.  The reference has no tests, no golden outputs and no CPU path, and it cannot
 be built or run in the build container (Rust + gfx-hal + Vulkan are absent), so parity is
@@ -314,7 +314,7 @@ def positions_f64(rgba: np.ndarray, verts: int = 128, offset=(0.0, 0.0)) -> np.n
     coordinates uv * N - 0.5 with wrap (ideal weights; real samplers quantise them to ~8 bits)."""
     n = rgba.shape[0]
     r = rgba.astype(np.float64)
-    g = np.arange(verts, dtype=np.float32) * (np.float32(1.0) / np.float32(verts - 1))   # the kernel's fp32 uv
+    g = np.arange(verts, dtype=np.float32) / np.float32(verts - 1)   # `(x as f32) / (V - 1) as f32`, src/render.rs:503-504
     t = g.astype(np.float32) * np.float32(n) - np.float32(0.5)
     t = t.astype(np.float64)
     f = np.floor(t)

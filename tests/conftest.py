@@ -16,6 +16,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _gpu_present() -> bool:
+    """A ROCm compute device node exists.  (On a GPU box the tests must RUN, never skip: a present device that
+    fails to initialise is an error, not a skip -- the product has no CPU fallback.)"""
+    return os.path.exists("/dev/kfd")
+
+
+def pytest_collection_modifyitems(config, items):
+    if _gpu_present():
+        return
+    skip = pytest.mark.skip(reason="no ROCm device node (/dev/kfd) in this container; run on the GPU box")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def ref_inputs():
     """The reference's own 512x512 inputs (data/spectrum.bin, data/omega.bin)."""

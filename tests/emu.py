@@ -9,8 +9,8 @@ _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _SO = os.path.join(_ROOT, "tests", "hipemu", "libocean_emu.so")
 _SRC = [os.path.join(_ROOT, "tests", "hipemu", "emu_kernels.cpp"),
         os.path.join(_ROOT, "tests", "hipemu", "hip", "hip_runtime.h"),
-        os.path.join(_ROOT, "gfx-ocean_amd", "csrc", "ocean_kernels.hpp"),
-        os.path.join(_ROOT, "gfx-ocean_amd", "csrc", "fft_core.hpp"),
+        os.path.join(_ROOT, "gfx_ocean_amd", "csrc", "ocean_kernels.hpp"),
+        os.path.join(_ROOT, "gfx_ocean_amd", "csrc", "fft_core.hpp"),
         os.path.join(_ROOT, "tests", "hipemu", "ocean_device_intrinsics.hpp")]
 _LIB = None
 
@@ -20,7 +20,7 @@ def build(force=False):
     if force or stale:
         subprocess.check_call([
             "g++", "-std=c++20", "-O1", "-pthread", "-shared", "-fPIC",
-            "-I", os.path.join(_ROOT, "tests", "hipemu"), "-I", os.path.join(_ROOT, "gfx-ocean_amd", "csrc"),
+            "-I", os.path.join(_ROOT, "tests", "hipemu"), "-I", os.path.join(_ROOT, "gfx_ocean_amd", "csrc"),
             _SRC[0], "-o", _SO])
 
 

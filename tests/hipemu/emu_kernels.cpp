@@ -1,6 +1,6 @@
 // Runs the product's kernel templates on the CPU (one std::thread per GPU thread, std::barrier for
 // __syncthreads) so that the non-GPU test tier can check them against the oracle.
-// Build: g++ -std=c++20 -O1 -pthread -shared -fPIC -I tests/hipemu -I gfx-ocean_amd/csrc ...
+// Build: g++ -std=c++20 -O1 -pthread -shared -fPIC -I tests/hipemu -I gfx_ocean_amd/csrc ...
 #include <barrier>
 #include <functional>
 #include <memory>

@@ -1,5 +1,5 @@
 // Host emulation of the small slice of the HIP device language that
-// gfx-ocean_amd/csrc/{fft_core,ocean_kernels}.hpp use.  TEST INFRASTRUCTURE ONLY: it lets the
+// gfx_ocean_amd/csrc/{fft_core,ocean_kernels}.hpp use.  TEST INFRASTRUCTURE ONLY: it lets the
 // CPU test-suite execute the *unmodified* kernel sources (index algebra, LDS exchanges, barriers)
 // with one OS thread per GPU thread.  It is never part of the product build, which is hipcc/gfx950 only.
 #pragma once

@@ -1,4 +1,4 @@
-// Host stand-in for gfx-ocean_amd/csrc/ocean_device_intrinsics.hpp (CPU emulation build only).
+// Host stand-in for gfx_ocean_amd/csrc/ocean_device_intrinsics.hpp (CPU emulation build only).
 #pragma once
 #include <cmath>
 #include <cstdint>

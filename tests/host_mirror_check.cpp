@@ -1,5 +1,5 @@
 // Compile-only check of the C++ host mirror against the C ABI (run by tests/test_abi.py).
-#include "../gfx-ocean_amd/csrc/host/ocean.hpp"
+#include "../gfx_ocean_amd/csrc/host/ocean.hpp"
 int main(int argc, char**) {
     if (argc > 1000) {   // never executed in the CPU tier: it only has to compile and link
         ocean_host::Device d(512);

@@ -56,7 +56,7 @@ def test_null_handles_are_rejected_not_crashed(so_path):
 
 
 def test_cpp_host_mirror_compiles_and_links(so_path, tmp_path):
-    """gfx-ocean_amd/csrc/host/ocean.hpp (the C++ mirror of mod ocean / mod fft) against the C ABI."""
+    """gfx_ocean_amd/csrc/host/ocean.hpp (the C++ mirror of mod ocean / mod fft) against the C ABI."""
     exe = str(tmp_path / "host_mirror_check")
     libdir = os.path.dirname(so_path)
     subprocess.check_call(["g++", "-std=c++17", os.path.join(ROOT, "tests", "host_mirror_check.cpp"), "-o", exe,
@@ -78,7 +78,7 @@ def test_header_is_plain_c_and_links_from_c(so_path, tmp_path):
 
 def test_rust_shim_lists_every_symbol():
     """The uncompiled Rust shim (no cargo in this image) must at least bind every exported symbol."""
-    with open(os.path.join(ROOT, "gfx-ocean_amd", "rust", "src", "ffi.rs")) as f:
+    with open(os.path.join(ROOT, "gfx_ocean_amd", "rust", "src", "ffi.rs")) as f:
         src = f.read()
     bound = sorted(set(re.findall(r"pub fn (ocean_[a-z_0-9]+)\(", src)))
     assert bound == header_symbols()

@@ -1,37 +1,19 @@
-"""Multi-GPU path on CPU: world-size-2 gloo run of the bench's rank logic (tile seeds, barrier,
-MAX-over-ranks timing, whole-job aggregation).  The data path has no collective (tiles are
-independent), so this is all the N > 1 logic there is."""
+"""Multi-GPU path on CPU: the REAL launcher entry of bench.py with world size 2 on gloo.
+
+`python bench.py --gpus 2 --plumbing` goes through exactly what a 2-GPU run goes through -- self-launch of one
+process per rank (or the ranks torch.distributed.run provides), 127.0.0.1 rendezvous, barrier, MAX-over-ranks
+reduction, per-rank tile seeds, and the final-gather schedule of BASELINE config 4 (`gather_leg`: buffer
+rotation, event order, one collective per frame) -- with CPU tensors and no device work.  The data path itself has
+no collective (tiles are independent)."""
 import json
 import os
 import subprocess
 import sys
 
-import numpy as np
-
 import bench
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-_WORKER = r"""
-import json, os, sys, time
-sys.path.insert(0, sys.argv[1])
-import torch, torch.distributed as dist
-import bench, gfx_ocean_amd as g
-rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-dist.init_process_group(backend="gloo")
-n = 256
-h0, om = g.synth.make_inputs(n, seed=bench.tile_seed(n, rank))
-wall_ms = 10.0 * (rank + 1)                       # pretend rank r took 10(r+1) ms for 5 steps
-t = torch.tensor([wall_ms], dtype=torch.float64)
-dist.barrier()
-dist.all_reduce(t, op=dist.ReduceOp.MAX)
-agg = bench.aggregate([float(t.item())], world, 5)
-sums = [None] * world
-dist.all_gather_object(sums, float(abs(h0).sum()))
-if rank == 0:
-    print("RESULT " + json.dumps({"agg": agg, "sums": sums}))
-dist.destroy_process_group()
-"""
+BENCH = os.path.join(ROOT, "bench.py")
 
 
 def test_aggregate_is_whole_job_over_slowest_rank():
@@ -43,16 +25,72 @@ def test_tile_seeds_differ_per_rank():
     assert bench.tile_seed(4096, 0) == 4096 and bench.tile_seed(4096, 3) == 4099
 
 
-def test_two_rank_gloo_run(tmp_path):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    worker = tmp_path / "worker.py"
-    worker.write_text(_WORKER)
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29533", str(worker), ROOT],
+def test_byte_accounting_tables():
+    """54 B/texel moved (49 with an fp16-stored spectrum) vs 76 (72) on the contract accounting, DESIGN 4.3 / SURVEY 8d."""
+    assert sum(bench.MOVED_BYTES_PER_TEXEL["f32"].values()) == 54.0
+    assert sum(bench.MOVED_BYTES_PER_TEXEL["f16"].values()) == 49.0
+    assert sum(bench.CONTRACT_BYTES_PER_TEXEL["f32"].values()) == 76.0
+    assert sum(bench.CONTRACT_BYTES_PER_TEXEL["f16"].values()) == 72.0
+
+
+def _check_two_rank_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, f"exactly one line on stdout, got {len(lines)}: {stdout[-2000:]}"
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["plumbing"] is True and r["value"] is None
+    assert r["max_rank_ms"] == 2.0                              # rank r reports r + 1 ms: MAX over ranks
+    assert r["seeds"] == [bench.tile_seed(4096, 0), bench.tile_seed(4096, 1)]      # distinct tiles per rank
+    g = r["gather"]
+    n = 64
+    assert g["bytes_per_peer_per_frame"] == n * n * 16
+    assert g["peer_tile_first_texel"] == [1.0, 2.0]             # rank r's tile (filled with r + 1) arrived in slot r
+    for leg in ("ordered", "overlapped"):
+        assert g[leg]["ms_per_step"] > 0 and g[leg]["frames_per_s"] > 0
+    return r
+
+
+def _overlapped_schedule_is_double_buffered(log, steps):
+    """The last `steps` frames of the log are the timed overlapped run: frame i uses buffer i % 2, waits for
+    gather_done[i % 2] before computing, and its gather waits for frame_done[i % 2] on the gather stream."""
+    frames = [k for k, e in enumerate(log) if e[0] == "frame"]
+    tail = frames[-steps:]
+    bufs = []
+    for i, k in enumerate(tail):
+        b = i % 2
+        assert log[k - 1] == ["wait", "compute", f"gather_done{b}"], (i, log[k - 1])
+        assert log[k + 1] == ["record", f"frame_done{b}", "compute"]
+        assert log[k + 2] == ["wait", "gather", f"frame_done{b}"]
+        assert log[k + 3] == ["on", "gather"]
+        assert log[k + 4] == ["record", f"gather_done{b}", "gather"]
+        bufs.append(log[k][2])
+    assert len(set(bufs[0::2])) == 1 and len(set(bufs[1::2])) == 1 and bufs[0] != bufs[1]   # two buffers, alternating
+
+
+def test_plain_gpus_2_self_launches_two_ranks():
+    """VERDICT r01 #1: `python bench.py --gpus 2` with no launcher must itself run two ranks and print one line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--plumbing", "--gather-steps", "4"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
-    line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][0]
-    r = json.loads(line[7:])
-    assert r["agg"]["ms_per_step"] == 4.0                 # slowest rank: 20 ms / 5 steps
-    assert r["agg"]["value"] == 2 * 1000.0 / 4.0           # two tiles per step
-    assert not np.isclose(r["sums"][0], r["sums"][1])      # different tiles on different ranks
+    r = _check_two_rank_line(p.stdout)
+    _overlapped_schedule_is_double_buffered(r["gather_log"], 4)
+
+
+def test_two_ranks_under_torch_distributed_run():
+    """The driver's launch line: python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", BENCH, "--gpus", "2", "--plumbing",
+                        "--gather-steps", "3"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    _check_two_rank_line(p.stdout)
+
+
+def test_failed_rank_fails_the_launch():
+    """A rank that dies takes the launch down with a non-zero exit code instead of hanging the others."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--n", "300"],      # no GPU here + bad N: every rank fails
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode != 0
+    assert not [l for l in p.stdout.splitlines() if l.strip().startswith("{")]   # and no fabricated line

@@ -1,4 +1,4 @@
-"""The product's kernel sources (gfx-ocean_amd/csrc/*.hpp) executed on the CPU by the host
+"""The product's kernel sources (gfx_ocean_amd/csrc/*.hpp) executed on the CPU by the host
 emulation harness (tests/hipemu) and compared with the oracle: index algebra, plans, LDS
 exchanges, chunked intermediate layout, quirks.  The GPU tier (-m gpu) repeats this on gfx950."""
 import numpy as np

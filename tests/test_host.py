@@ -75,7 +75,7 @@ def test_no_cpu_fallback_without_device():
 
 def test_product_never_imports_oracle():
     """Only tests/, smoke() and bench.py's cpu_baseline leg may touch oracle/."""
-    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gfx-ocean_amd")
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gfx_ocean_amd")
     for root, _, files in os.walk(pkg):
         for fn in files:
             if fn.endswith((".py", ".hpp", ".hip", ".h", ".cpp", ".rs")):

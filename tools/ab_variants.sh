@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT
 O=gpurun_out/${1:-abv}; mkdir -p $O; shift
 NS=${@:-4096}
 for rep in 1 2; do
-for so in gfx-ocean_amd/libocean_hip.so gfx-ocean_amd/variants/*.so; do
+for so in gfx_ocean_amd/libocean_hip.so gfx_ocean_amd/variants/*.so; do
   OCEAN_HIP_LIB=$PWD/$so timeout 600 python tools/sweep.py $NS 2>&1 | python -c "
 import sys, json
 for l in sys.stdin:

@@ -2,8 +2,8 @@
 // Builds the whole library as one translation unit with -DOCEAN_TIMELINE: lane 0 of every workgroup
 // stamps the 100 MHz wall clock at phase boundaries (ocean_device_intrinsics.hpp: OCEAN_TL).  Prints
 // per-phase statistics and the number of workgroups inside each phase over time.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -DOCEAN_TIMELINE -I gfx-ocean_amd/csrc tools/timeline.hip -o tools/timeline
-#include "../gfx-ocean_amd/csrc/ocean_api.hip"
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -DOCEAN_TIMELINE -I gfx_ocean_amd/csrc tools/timeline.hip -o tools/timeline
+#include "../gfx_ocean_amd/csrc/ocean_api.hip"
 #include <algorithm>
 #include <map>
 #include <random>
