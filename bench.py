@@ -405,6 +405,15 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
+    # per-kernel durations, live, HIP events bound to the dispatches on the stream the kernels run on.  Untimed, and
+    # run BEFORE the timed region on purpose: a cold GPU needs tens of milliseconds of work to reach its running
+    # clocks (measured on MI355X: the first ~25 frames of a run are ~10 % slower), and with the default W = 5 the
+    # timed K = 20 steps would otherwise be measured on the ramp.
+    acc = {}
+    for i in range(args.profile_frames):
+        for name, ms in dev.profile_frame(i / 60.0):
+            acc[name] = acc.get(name, 0.0) + ms
+
     for i in range(args.warmup):
         dev.frame(i / 60.0)
     barrier()
@@ -422,11 +431,6 @@ def main():
         all_ms = [wall_ms]
     agg = aggregate(all_ms, n_gpus, args.steps)
 
-    # per-kernel durations, live, HIP events bound to the dispatches on the stream the kernels run on
-    acc = {}
-    for i in range(args.profile_frames):
-        for name, ms in dev.profile_frame(i / 60.0):
-            acc[name] = acc.get(name, 0.0) + ms
     moved, contract = MOVED_BYTES_PER_TEXEL[args.spectrum], CONTRACT_BYTES_PER_TEXEL[args.spectrum]
     kernels = []
     for name, total in acc.items():
@@ -464,7 +468,8 @@ def main():
                                    f"three-complex-transform accounting of SURVEY 8d); seed N+rank",
                        "n": n, "spectrum": args.spectrum, "tiles": n_gpus,
                        "parallelism": f"tile-parallel x{n_gpus}, no data-path collective",
-                       "gpu_event_ms_per_step": frame_ms},
+                       "gpu_event_ms_per_step": frame_ms,
+                       "untimed_before_timed_region": f"{3 * args.profile_frames} frames of per-kernel profiling + {args.warmup} warmup"},
             "roofline": roofline,
         }
 

@@ -35,27 +35,43 @@ __device__ __forceinline__ c32 cconj(c32 a) { return a * mk(1.0f, -1.0f); }
 __device__ __forceinline__ c32 cmul_r(c32 a, c32 w, c32 wr) { return vfma(yy(a), wr, xx(a) * w); }
 __device__ __forceinline__ c32 cmul(c32 a, c32 w) { return vfma(yy(a) * yx(w), mk(-1.0f, 1.0f), xx(a) * w); }
 
-// e^{+2 pi i s / 32}, s in [0,32): exact trivial entries, others rounded from fp64.
-template <int S32> struct W32 {};
-#define OCEAN_W32(S, C, SN) \
-    template <> struct W32<S> { static constexpr float c = C; static constexpr float s = SN; };
-OCEAN_W32(0, 1.0f, 0.0f)
-OCEAN_W32(1, 0.9807852804032304f, 0.19509032201612825f)
-OCEAN_W32(2, 0.9238795325112867f, 0.3826834323650898f)
-OCEAN_W32(3, 0.8314696123025452f, 0.5555702330196022f)
-OCEAN_W32(4, 0.7071067811865476f, 0.7071067811865476f)
-OCEAN_W32(5, 0.5555702330196022f, 0.8314696123025452f)
-OCEAN_W32(6, 0.3826834323650898f, 0.9238795325112867f)
-OCEAN_W32(7, 0.19509032201612825f, 0.9807852804032304f)
-OCEAN_W32(8, 0.0f, 1.0f)
-OCEAN_W32(9, -0.19509032201612825f, 0.9807852804032304f)
-OCEAN_W32(10, -0.3826834323650898f, 0.9238795325112867f)
-OCEAN_W32(11, -0.5555702330196022f, 0.8314696123025452f)
-OCEAN_W32(12, -0.7071067811865476f, 0.7071067811865476f)
-OCEAN_W32(13, -0.8314696123025452f, 0.5555702330196022f)
-OCEAN_W32(14, -0.9238795325112867f, 0.3826834323650898f)
-OCEAN_W32(15, -0.9807852804032304f, 0.19509032201612825f)
-#undef OCEAN_W32
+// e^{+2 pi i s / 64}, s in [0,32): exact trivial entries, others rounded from fp64.
+template <int S64> struct W64 {};
+#define OCEAN_W64(S, C, SN) \
+    template <> struct W64<S> { static constexpr float c = C; static constexpr float s = SN; };
+OCEAN_W64(0, 1.0f, 0.0f)
+OCEAN_W64(1, 0.9951847266721969f, 0.0980171403295606f)
+OCEAN_W64(2, 0.9807852804032304f, 0.19509032201612825f)
+OCEAN_W64(3, 0.9569403357322088f, 0.29028467725446233f)
+OCEAN_W64(4, 0.9238795325112867f, 0.3826834323650898f)
+OCEAN_W64(5, 0.881921264348355f, 0.47139673682599764f)
+OCEAN_W64(6, 0.8314696123025452f, 0.5555702330196022f)
+OCEAN_W64(7, 0.773010453362737f, 0.6343932841636455f)
+OCEAN_W64(8, 0.7071067811865476f, 0.7071067811865475f)
+OCEAN_W64(9, 0.6343932841636455f, 0.773010453362737f)
+OCEAN_W64(10, 0.5555702330196023f, 0.8314696123025452f)
+OCEAN_W64(11, 0.4713967368259978f, 0.8819212643483549f)
+OCEAN_W64(12, 0.38268343236508984f, 0.9238795325112867f)
+OCEAN_W64(13, 0.29028467725446233f, 0.9569403357322089f)
+OCEAN_W64(14, 0.19509032201612833f, 0.9807852804032304f)
+OCEAN_W64(15, 0.09801714032956077f, 0.9951847266721968f)
+OCEAN_W64(16, 0.0f, 1.0f)
+OCEAN_W64(17, -0.09801714032956065f, 0.9951847266721969f)
+OCEAN_W64(18, -0.1950903220161282f, 0.9807852804032304f)
+OCEAN_W64(19, -0.29028467725446216f, 0.9569403357322089f)
+OCEAN_W64(20, -0.3826834323650897f, 0.9238795325112867f)
+OCEAN_W64(21, -0.4713967368259977f, 0.881921264348355f)
+OCEAN_W64(22, -0.555570233019602f, 0.8314696123025455f)
+OCEAN_W64(23, -0.6343932841636454f, 0.7730104533627371f)
+OCEAN_W64(24, -0.7071067811865475f, 0.7071067811865476f)
+OCEAN_W64(25, -0.773010453362737f, 0.6343932841636455f)
+OCEAN_W64(26, -0.8314696123025453f, 0.5555702330196022f)
+OCEAN_W64(27, -0.8819212643483549f, 0.47139673682599786f)
+OCEAN_W64(28, -0.9238795325112867f, 0.3826834323650899f)
+OCEAN_W64(29, -0.9569403357322088f, 0.2902846772544624f)
+OCEAN_W64(30, -0.9807852804032304f, 0.1950903220161286f)
+OCEAN_W64(31, -0.9951847266721968f, 0.09801714032956083f)
+#undef OCEAN_W64
 
 // In-register R-point unnormalised inverse DFT, natural order in and out (DIT recursion).
 template <int R> struct Dft;
@@ -81,15 +97,16 @@ template <> struct Dft<4> {
 template <int R, int S> struct Combine {
     static __device__ __forceinline__ void run(const c32 (&ev)[R / 2], const c32 (&od)[R / 2], c32 (&out)[R]) {
         // out[S] = ev + od * W, out[S + R/2] = ev - od * W,  W = e^{+2 pi i S / R}
-        constexpr int s32 = S * (32 / R);
-        if constexpr (s32 == 0) {
+        static_assert(R <= 64, "twiddle constants exist up to a 64-point butterfly");
+        constexpr int s64 = S * (64 / R);
+        if constexpr (s64 == 0) {
             out[S] = cadd(ev[S], od[S]);
             out[S + R / 2] = csub(ev[S], od[S]);
-        } else if constexpr (s32 == 8) {                                        // W = i
+        } else if constexpr (s64 == 16) {                                       // W = i
             out[S] = cadd_i(ev[S], od[S]);
             out[S + R / 2] = csub_i(ev[S], od[S]);
         } else {
-            const c32 t = cmul_r(od[S], mk(W32<s32>::c, W32<s32>::s), mk(-W32<s32>::s, W32<s32>::c));
+            const c32 t = cmul_r(od[S], mk(W64<s64>::c, W64<s64>::s), mk(-W64<s64>::s, W64<s64>::c));
             out[S] = cadd(ev[S], t);
             out[S + R / 2] = csub(ev[S], t);
         }
@@ -123,12 +140,14 @@ __device__ __forceinline__ int lds_pad(int i) { return i + (i >> 4); }
 template <int N> struct LdsLine { static constexpr int elems = N + (N >> 4); };
 
 // a[t] *= w^t, t in [0, R).  For R > 4 the rotation is split in two levels, t = 4*t1 + t2:
-// w^t = (w^4)^t1 * w^t2, so only {w, w^2, w^3, w^4, w^8, w^12} are ever live instead of a 15-entry power
-// table.  The three low powers are kept together with their rotated copies i w^t2 (each is used by four
+// w^t = (w^4)^t1 * w^t2, so only {w, w^2, w^3} and the powers of w^4 are ever live instead of an (R-1)-entry power
+// table.  The three low powers are kept together with their rotated copies i w^t2 (each is used by R/4
 // products, which then cost two packed instructions); the high powers use the three-instruction product.
-// Product depth <= 5 (w^12 * w^3), i.e. a few ulp on the twiddle.
+// R <= 16: the high powers w^4, w^8, w^12 are products (depth <= 5, a few ulp on the twiddle).
+// R >= 32: they are read from the twiddle table (tw[(4 t1 step) mod table]: exact entries, L1-resident) -- a
+// product chain would be 7 or 15 deep.
 template <int R>
-__device__ __forceinline__ void apply_twiddles(c32 (&a)[R], c32 w) {
+__device__ __forceinline__ void apply_twiddles(c32 (&a)[R], c32 w, const c32* __restrict__ tw, int step, int mask) {
     if constexpr (R == 2) {
         a[1] = cmul(a[1], w);
     } else if constexpr (R == 4) {
@@ -137,25 +156,44 @@ __device__ __forceinline__ void apply_twiddles(c32 (&a)[R], c32 w) {
         a[2] = cmul(a[2], w2);
         a[3] = cmul(a[3], cmul(w2, w));
     } else {
-        static_assert(R % 4 == 0 && R <= 16, "two-level twiddle split supports R = 8, 16");
+        static_assert(R % 4 == 0 && R <= 64, "two-level twiddle split supports R = 8 .. 64");
         constexpr int R1 = R / 4;
         const c32 wr = crot(w);
         const c32 w2 = cmul_r(w, w, wr), w2r = crot(w2);
         const c32 w3 = cmul_r(w2, w, wr), w3r = crot(w3);
-        const c32 w4 = cmul_r(w2, w2, w2r);
-        c32 hi[R1];
-        hi[0] = mk(1.0f, 0.0f);
-        hi[1] = w4;
-        if constexpr (R1 > 2) { hi[2] = cmul(w4, w4); hi[3] = cmul(hi[2], w4); }
+        if constexpr (R <= 16) {
+            const c32 w4 = cmul_r(w2, w2, w2r);
+            c32 hi[R1];
+            hi[0] = mk(1.0f, 0.0f);
+            hi[1] = w4;
+            if constexpr (R1 > 2) { hi[2] = cmul(w4, w4); hi[3] = cmul(hi[2], w4); }
 #pragma unroll
-        for (int t = 1; t < R; ++t) {
-            const int t1 = t / 4, t2 = t % 4;
-            c32 v = a[t];
-            if (t2 == 1) v = cmul_r(v, w, wr);
-            if (t2 == 2) v = cmul_r(v, w2, w2r);
-            if (t2 == 3) v = cmul_r(v, w3, w3r);
-            if (t1 > 0) v = cmul(v, hi[t1]);
-            a[t] = v;
+            for (int t = 1; t < R; ++t) {
+                const int t1 = t / 4, t2 = t % 4;
+                c32 v = a[t];
+                if (t2 == 1) v = cmul_r(v, w, wr);
+                if (t2 == 2) v = cmul_r(v, w2, w2r);
+                if (t2 == 3) v = cmul_r(v, w3, w3r);
+                if (t1 > 0) v = cmul(v, hi[t1]);
+                a[t] = v;
+            }
+        } else {
+#pragma unroll
+            for (int t1 = 0; t1 < R1; ++t1) {
+                c32 h = mk(1.0f, 0.0f);
+                if (t1 > 0) h = tw[(4 * t1 * step) & mask];
+#pragma unroll
+                for (int t2 = 0; t2 < 4; ++t2) {
+                    const int t = 4 * t1 + t2;
+                    if (t == 0) continue;
+                    c32 v = a[t];
+                    if (t2 == 1) v = cmul_r(v, w, wr);
+                    if (t2 == 2) v = cmul_r(v, w2, w2r);
+                    if (t2 == 3) v = cmul_r(v, w3, w3r);
+                    if (t1 > 0) v = cmul(v, h);
+                    a[t] = v;
+                }
+            }
         }
     }
 }
@@ -170,16 +208,18 @@ __device__ __forceinline__ void fft_pass(c32 (&reg)[E], int j, const c32* __rest
     constexpr int T = N / E;
     constexpr int U = E / R;
     c32 w = mk(1.0f, 0.0f);
-    if constexpr (NS > 1 && U == 1) w = tw[(j & (NS - 1)) * (TWS * (N / (NS * R)))];
+    constexpr int TW_MASK = N * TWS - 1;                               // the table holds e^{+2 pi i k / (N TWS)}, k < N TWS
+    int step = 0;
+    if constexpr (NS > 1 && U == 1) { step = (j & (NS - 1)) * (TWS * (N / (NS * R))); w = tw[step]; }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int jv = j + u * T;
         const int k = jv & (NS - 1);
-        if constexpr (NS > 1 && U > 1) w = tw[k * (TWS * (N / (NS * R)))];
+        if constexpr (NS > 1 && U > 1) { step = k * (TWS * (N / (NS * R))); w = tw[step]; }
         c32 a[R], b[R];
 #pragma unroll
         for (int t = 0; t < R; ++t) a[t] = reg[u + t * U];
-        if constexpr (NS > 1) apply_twiddles<R>(a, w);
+        if constexpr (NS > 1) apply_twiddles<R>(a, w, tw, step, TW_MASK);
         Dft<R>::run(a, b);
         const int base = (jv / NS) * (NS * R) + k;
         // lds_pad(base + s*NS) == lds_pad(base) + s*NS + ((s*NS) >> 4) for power-of-two NS, R

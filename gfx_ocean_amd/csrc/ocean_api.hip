@@ -55,6 +55,12 @@ struct OceanContext {
     c32* h0 = nullptr;          // initial_spec
     float* omega = nullptr;     // omega_buffer
     c32* field[3] = {nullptr, nullptr, nullptr};   // dx_spec, dy_spec, dz_spec
+    // Staged path, N <= 4096: ocean_fft_rows hands the field to ocean_fft_cols / ocean_correct in the 4 x 4-chunk
+    // layout (k_stage_rows / k_stage_cols, ocean_kernels.hpp).  Per field: which copy holds the current contents.
+    c32* cfield[3] = {nullptr, nullptr, nullptr};  // chunked copies (layout `lay`), allocated with the context
+    bool nat_valid[3] = {true, true, true};
+    bool chk_valid[3] = {false, false, false};
+    bool stage_chunked = false;
     // fused path: transposed static inputs + chunked intermediate
     c32* h0T = nullptr;         // fp32 complex, or (h0_f16) packed half2 in the first N*N*4 bytes
     bool h0_f16 = false;        // BASELINE config 5: fp16 spectrum storage for the fused path
@@ -130,6 +136,12 @@ template <int N> struct Launch {
         e = hipFuncSetAttribute((const void*)k_fft_lines<N, G::E, G::COL_LPW, true>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, G::col_lds);
         if (e != hipSuccess) return e;
+        if constexpr (G::stage_chunked) {
+            e = hipFuncSetAttribute((const void*)k_stage_rows<N, G::E>, hipFuncAttributeMaxDynamicSharedMemorySize, G::stage_lds);
+            if (e != hipSuccess) return e;
+            e = hipFuncSetAttribute((const void*)k_stage_cols<N, G::E>, hipFuncAttributeMaxDynamicSharedMemorySize, G::stage_lds);
+            if (e != hipSuccess) return e;
+        }
 #ifdef OCEAN_AB   // A/B builds only (tools/ab_variants.sh): the three-complex-transform frame and the other line counts
         e = hipFuncSetAttribute((const void*)k_frame_pass1<N, G::E, G::P>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, G::frame_lds);
@@ -152,7 +164,11 @@ template <int N> struct Launch {
     }
     // Lines per pass-1 workgroup of the shipped frame, per size (measured best): 2 where two
     // co-resident workgroups pay (512, 2048) and where 4 lines do not fit (8192), else 4.
-    static constexpr int default_psel() { return (N == 512 || N == 2048 || N > 4096) ? 2 : 4; }
+#ifdef OCEAN_FORCE_P                                                   // A/B knob (tools/ab_variants.sh)
+    static constexpr int default_psel() { return OCEAN_FORCE_P; }
+#else
+    static constexpr int default_psel() { return (N == 512 || N == 2048 || N > 4096 || CHUNK_W < 4) ? 2 : 4; }
+#endif
     static constexpr bool default_split() { return N > 4096; }
     // Which (plain, split) kernel pairs exist in this build: everything selectable in an A/B build, only the
     // size's default in the shipped one (no untested kernel ships).
@@ -167,10 +183,10 @@ template <int N> struct Launch {
         using H = Geo<N, PSEL>;
         hipError_t e = hipSuccess;
         if constexpr (plain_built<PSEL>()) {
-            e = hipFuncSetAttribute((const void*)k_half_pass1<N, H::E, H::P, false>,
+            e = hipFuncSetAttribute((const void*)k_half_pass1<N, H::E1, H::P, false>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, H::frame_lds);
             if (e != hipSuccess) return e;
-            e = hipFuncSetAttribute((const void*)k_half_pass1<N, H::E, H::P, true>,
+            e = hipFuncSetAttribute((const void*)k_half_pass1<N, H::E1, H::P, true>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, H::frame_lds);
             if (e != hipSuccess) return e;
             e = hipFuncSetAttribute((const void*)k_half_pass2<N, H::E, CHUNK_W, H::R2>,
@@ -178,10 +194,10 @@ template <int N> struct Launch {
             if (e != hipSuccess) return e;
         }
         if constexpr (split_built<PSEL>()) {
-            e = hipFuncSetAttribute((const void*)k_half_pass1_split<N, H::E, H::P, false>,
+            e = hipFuncSetAttribute((const void*)k_half_pass1_split<N, H::E1S, H::P, false>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, H::split_lds1);
             if (e != hipSuccess) return e;
-            e = hipFuncSetAttribute((const void*)k_half_pass1_split<N, H::E, H::P, true>,
+            e = hipFuncSetAttribute((const void*)k_half_pass1_split<N, H::E1S, H::P, true>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, H::split_lds1);
             if (e != hipSuccess) return e;
             e = hipFuncSetAttribute((const void*)k_half_pass2_split<N, H::E, CHUNK_W>,
@@ -195,11 +211,11 @@ template <int N> struct Launch {
         if constexpr (split_built<PSEL>()) {
             if (c->split) {
                 if (c->h0_f16)
-                    launch(k_half_pass1_split<N, H::E, H::P, true>, dim3(H::half_grid1), dim3(H::frame_threads),
+                    launch(k_half_pass1_split<N, H::E1S, H::P, true>, dim3(H::half_grid1), dim3(H::split_threads1),
                            H::split_lds1, s, t, (const void*)c->h0T, descale, (const float*)c->omegaT, c->inter, c->nyq,
                            (const c32*)c->tw, c->lay_h, time, domain);
                 else
-                    launch(k_half_pass1_split<N, H::E, H::P, false>, dim3(H::half_grid1), dim3(H::frame_threads),
+                    launch(k_half_pass1_split<N, H::E1S, H::P, false>, dim3(H::half_grid1), dim3(H::split_threads1),
                            H::split_lds1, s, t, (const void*)c->h0T, 1.0f, (const float*)c->omegaT, c->inter, c->nyq,
                            (const c32*)c->tw, c->lay_h, time, domain);
                 return;
@@ -207,11 +223,11 @@ template <int N> struct Launch {
         }
         if constexpr (plain_built<PSEL>()) {
             if (c->h0_f16)
-                launch(k_half_pass1<N, H::E, H::P, true>, dim3(H::half_grid1), dim3(H::frame_threads), H::frame_lds, s, t,
+                launch(k_half_pass1<N, H::E1, H::P, true>, dim3(H::half_grid1), dim3(H::half_threads1), H::frame_lds, s, t,
                        (const void*)c->h0T, descale, (const float*)c->omegaT, c->inter, c->nyq, (const c32*)c->tw,
                        c->lay_h, time, domain);
             else
-                launch(k_half_pass1<N, H::E, H::P, false>, dim3(H::half_grid1), dim3(H::frame_threads), H::frame_lds, s, t,
+                launch(k_half_pass1<N, H::E1, H::P, false>, dim3(H::half_grid1), dim3(H::half_threads1), H::frame_lds, s, t,
                        (const void*)c->h0T, 1.0f, (const float*)c->omegaT, c->inter, c->nyq, (const c32*)c->tw,
                        c->lay_h, time, domain);
         }
@@ -228,6 +244,16 @@ template <int N> struct Launch {
         if constexpr (plain_built<PSEL>())
             launch(k_half_pass2<N, H::E, CHUNK_W, H::R2>, dim3(H::thin_grid), dim3(H::thin_threads), H::thin_lds, s, t,
                    (const c32*)c->inter, c->out, (const c32*)c->tw, c->lay_h);
+    }
+    static void stage_rows(OceanContext* c, int f, hipStream_t s) {
+        if constexpr (G::stage_chunked)
+            hipLaunchKernelGGL((k_stage_rows<N, G::E>), dim3(G::stage_grid), dim3(G::stage_threads), G::stage_lds, s,
+                               (const c32*)c->field[f], c->cfield[f], (const c32*)c->tw, c->lay);
+    }
+    static void stage_cols(OceanContext* c, int f, hipStream_t s) {
+        if constexpr (G::stage_chunked)
+            hipLaunchKernelGGL((k_stage_cols<N, G::E>), dim3(G::stage_grid), dim3(G::stage_threads), G::stage_lds, s,
+                               c->cfield[f], (const c32*)c->tw, c->lay);
     }
     static void rows(OceanContext* c, c32* data, hipStream_t s) {
         hipLaunchKernelGGL((k_fft_lines<N, G::E, G::ROW_LPW, false>), dim3(G::row_grid), dim3(G::row_threads),
@@ -291,14 +317,48 @@ void launch_propagate(OceanContext* c, float time, float domain, hipStream_t s) 
     const unsigned grid = (unsigned)(((size_t)c->n * c->n / 2 + 255) / 256);
     hipLaunchKernelGGL(k_propagate, dim3(grid), dim3(256), 0, s, c->h0, c->omega, c->field[OCEAN_FIELD_DY],
                        c->field[OCEAN_FIELD_DX], c->field[OCEAN_FIELD_DZ], c->n, time, domain, c->quirks);
+    for (int f = 0; f < 3; ++f) { c->nat_valid[f] = true; c->chk_valid[f] = false; }
+}
+// Make the natural copy of field f current (no-op when it already is).
+void launch_unchunk(OceanContext* c, int f, hipStream_t s) {
+    if (c->nat_valid[f]) return;
+    hipLaunchKernelGGL(k_unchunk, dim3((unsigned)c->n / 4), dim3(256), 0, s, (const c32*)c->cfield[f], c->field[f], c->n, c->lay);
+    c->nat_valid[f] = true;
 }
 void launch_correct(OceanContext* c, hipStream_t s) {
+    const int dy = OCEAN_FIELD_DY, dx = OCEAN_FIELD_DX, dz = OCEAN_FIELD_DZ;
+    if (c->chk_valid[dy] && c->chk_valid[dx] && c->chk_valid[dz]) {         // straight from the chunked fields
+        hipLaunchKernelGGL(k_correct_chunked, dim3((unsigned)c->n / 4), dim3(256), 0, s, (const c32*)c->cfield[dy],
+                           (const c32*)c->cfield[dx], (const c32*)c->cfield[dz], c->out, c->n, c->lay);
+        return;
+    }
+    for (int f = 0; f < 3; ++f) launch_unchunk(c, f, s);
     const unsigned grid = (unsigned)(((size_t)c->n * c->n / 2 + 255) / 256);
-    hipLaunchKernelGGL(k_correct, dim3(grid), dim3(256), 0, s, c->field[OCEAN_FIELD_DY], c->field[OCEAN_FIELD_DX],
-                       c->field[OCEAN_FIELD_DZ], c->out, c->n);
+    hipLaunchKernelGGL(k_correct, dim3(grid), dim3(256), 0, s, c->field[dy], c->field[dx], c->field[dz], c->out, c->n);
 }
-void launch_rows(OceanContext* c, int f, hipStream_t s) { OCEAN_DISPATCH(c->n, L::rows(c, c->field[f], s)); }
-void launch_cols(OceanContext* c, int f, hipStream_t s) { OCEAN_DISPATCH(c->n, L::cols(c, c->field[f], s)); }
+// Row pass of field f (shader/fft_row.comp:44-63).  N <= 4096: natural rows in, chunked field out; else in place.
+void launch_rows(OceanContext* c, int f, hipStream_t s) {
+    launch_unchunk(c, f, s);                       // a second row pass on a chunked field starts from its natural copy
+    if (c->stage_chunked) {
+        OCEAN_DISPATCH(c->n, L::stage_rows(c, f, s));
+        c->nat_valid[f] = false;
+        c->chk_valid[f] = true;
+        return;
+    }
+    OCEAN_DISPATCH(c->n, L::rows(c, c->field[f], s));
+    c->chk_valid[f] = false;
+}
+// Column pass of field f (shader/fft_col.comp:44-63): in place on whichever copy is current (whole 128-byte chunks
+// when it follows the row pass; the natural-layout kernel otherwise, e.g. after ocean_write_field).
+void launch_cols(OceanContext* c, int f, hipStream_t s) {
+    if (c->stage_chunked && c->chk_valid[f]) {
+        OCEAN_DISPATCH(c->n, L::stage_cols(c, f, s));
+        c->nat_valid[f] = false;
+        return;
+    }
+    OCEAN_DISPATCH(c->n, L::cols(c, c->field[f], s));
+    c->chk_valid[f] = false;
+}
 void launch_frame(OceanContext* c, float time, float domain, hipStream_t s) {
     if (c->quirks != OCEAN_QUIRKS_REFERENCE) {      // the fused kernels implement the reference's arithmetic only
         launch_propagate(c, time, domain, s);
@@ -319,6 +379,7 @@ int32_t check_launch(OceanContext* c, const char* what) {
 void free_all(OceanContext* c) {
     auto f = [](void* p) { if (p) (void)hipFree(p); };
     f(c->h0); f(c->omega); f(c->field[0]); f(c->field[1]); f(c->field[2]);
+    f(c->cfield[0]); f(c->cfield[1]); f(c->cfield[2]);
     f(c->h0T); f(c->omegaT); f(c->inter); f(c->nyq); f(c->tw); f(c->out_own); f(c->normals); f(c->positions);
     if (c->ev_a) (void)hipEventDestroy(c->ev_a);
     if (c->ev_b) (void)hipEventDestroy(c->ev_b);
@@ -389,6 +450,9 @@ int32_t ocean_context_create(int32_t device, int32_t resolution, OceanContext** 
     CTX_TRY(hipMalloc((void**)&c->h0, n2 * sizeof(c32)));
     CTX_TRY(hipMalloc((void**)&c->omega, n2 * sizeof(float)));
     for (int f = 0; f < 3; ++f) CTX_TRY(hipMalloc((void**)&c->field[f], n2 * sizeof(c32)));
+    OCEAN_DISPATCH(resolution, c->stage_chunked = L::G::stage_chunked);
+    if (c->stage_chunked)
+        for (int f = 0; f < 3; ++f) CTX_TRY(hipMalloc((void**)&c->cfield[f], c->lay.fs * sizeof(c32)));
     CTX_TRY(hipMalloc((void**)&c->h0T, n2 * sizeof(c32)));
     CTX_TRY(hipMalloc((void**)&c->omegaT, n2 * sizeof(float)));
     #ifdef OCEAN_AB
@@ -685,6 +749,7 @@ int32_t ocean_read_field(OceanContext* ctx, int32_t field, float* host_re_im) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
     if (!host_re_im || field < 0 || field > 2) return fail(ctx, OCEAN_E_INVALID_ARG, "bad field or NULL output");
     DeviceGuard guard(ctx->device);
+    launch_unchunk(ctx, field, ctx->stream);       // the field may live in the chunked hand-off layout: natural copy first
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(host_re_im, ctx->field[field], (size_t)ctx->n * ctx->n * sizeof(c32), hipMemcpyDeviceToHost));
     return OCEAN_OK;
@@ -695,6 +760,8 @@ int32_t ocean_write_field(OceanContext* ctx, int32_t field, const float* host_re
     DeviceGuard guard(ctx->device);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(ctx->field[field], host_re_im, (size_t)ctx->n * ctx->n * sizeof(c32), hipMemcpyHostToDevice));
+    ctx->nat_valid[field] = true;
+    ctx->chk_valid[field] = false;
     return OCEAN_OK;
 }
 
@@ -728,8 +795,11 @@ static int32_t profile_common(OceanContext* ctx, float time, int32_t cap, const 
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
     if (!names || !ms || !out_n) return fail(ctx, OCEAN_E_INVALID_ARG, "NULL output");
     if (!ctx->uploaded) return fail(ctx, OCEAN_E_STATE, "ocean_upload_spectrum has not been called");
-    static const char* kStaged[8] = {"k_propagate", "k_fft_lines<ROW> dx", "k_fft_lines<ROW> dy", "k_fft_lines<ROW> dz",
-                                     "k_fft_lines<COL> dx", "k_fft_lines<COL> dy", "k_fft_lines<COL> dz", "k_correct"};
+    static const char* kNatural[8] = {"k_propagate", "k_fft_lines<ROW> dx", "k_fft_lines<ROW> dy", "k_fft_lines<ROW> dz",
+                                      "k_fft_lines<COL> dx", "k_fft_lines<COL> dy", "k_fft_lines<COL> dz", "k_correct"};
+    static const char* kChunked[8] = {"k_propagate", "k_stage_rows(fft) dx", "k_stage_rows(fft) dy", "k_stage_rows(fft) dz",
+                                      "k_stage_cols(fft) dx", "k_stage_cols(fft) dy", "k_stage_cols(fft) dz", "k_correct_chunked"};
+    const char* const* kStaged = ctx->stage_chunked ? kChunked : kNatural;
     const char* kFused[2] = {ctx->half ? "k_half_pass1" : "k_frame_pass1",
                              ctx->half ? "k_half_pass2" : (ctx->pass2_thin ? "k_frame_pass2_thin" : "k_frame_pass2")};
     const int count = staged ? 8 : 2;

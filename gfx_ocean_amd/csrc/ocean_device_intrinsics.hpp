@@ -112,6 +112,18 @@ __device__ __forceinline__ c32 unpack_half2(uint32_t bits, float descale) {
     return mk((float)h.x * descale, (float)h.y * descale);
 }
 
+// Static issue priority of this wave (s_setprio, 0..3; wave-uniform argument).  The waves of a workgroup that share
+// a SIMD otherwise move through every barrier-separated phase together (all in VALU, then all in their LDS stores);
+// distinct priorities serialise their VALU phases so that one wave's LDS traffic runs under the others' arithmetic.
+__device__ __forceinline__ void wave_priority(int p) {
+    switch (p & 3) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+
 // x is known to be identical in every lane of the wave: move it to an SGPR so that addresses
 // derived from it become scalar bases (one VGPR offset + SGPR base instead of E 64-bit VGPR pairs).
 __device__ __forceinline__ int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }

@@ -238,7 +238,16 @@ struct InterLayout { size_t sx, sy, fs; };
 // chunks, non-temporal stores) or P = 2 lines (the left or right 16 bytes of every chunk row; its
 // neighbour, dispatched in the adjacent slot of the same XCD, writes the other half and the XCD L2
 // merges them into full lines -- plain stores, so that the lines stay in L2 until complete).
-constexpr int CHUNK_W = 4, CHUNK_R = 4;
+// (Build-time knobs for A/B variants: -DOCEAN_CHUNK_W=2 -DOCEAN_CHUNK_R=8 makes a chunk 2 columns x 8 rows, so that a
+// 2-line pass-1 workgroup owns whole chunks; W * R stays 16 elements = 128 bytes.)
+#ifndef OCEAN_CHUNK_W
+#define OCEAN_CHUNK_W 4
+#endif
+#ifndef OCEAN_CHUNK_R
+#define OCEAN_CHUNK_R 4
+#endif
+constexpr int CHUNK_W = OCEAN_CHUNK_W, CHUNK_R = OCEAN_CHUNK_R;
+static_assert(CHUNK_W * CHUNK_R == 16, "a chunk is one 128-byte line");
 
 // Map block -> x-group so that a group and its mirror (which read the same two h0T line sets)
 // run on the same XCD, 8 blocks apart.
@@ -421,6 +430,118 @@ k_frame_pass2_thin(const c32* __restrict__ inter, float4* __restrict__ out, cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// Staged path, chunked hand-off (N <= 4096, 4 x 4 chunks)
+// ---------------------------------------------------------------------------------------------
+// The reference's column pass reads its lines with a 4 KiB lane stride (shader/fft_col.comp:45-47) and leaves it to
+// the L2 to merge neighbouring columns; k_fft_lines<COL> does the same with 32-byte pieces and reaches a quarter
+// of the HBM roofline.  The staged calls keep the reference's dispatch structure (ocean_fft_rows, then
+// ocean_fft_cols, per field) but hand the field over in the 4 x 4-chunk layout of the fused path, so that BOTH passes
+// move whole 128-byte lines:
+//   k_stage_rows:   4 natural rows in (contiguous) -> row FFT -> chunk row Y out: one contiguous 4 N-element span;
+//   k_stage_cols:   the 4 columns of chunk column X, in place on the chunked field (whole chunks in and out);
+//   k_correct_chunked / k_unchunk: the consumers (correction.comp:24-35, ocean_read_field) read the chunked field.
+// Results in the natural layout are available after every call through ocean_read_field (include/ocean_hip.h).
+template <int N, int E>
+__global__ void __launch_bounds__((N / E) * 4)
+k_stage_rows(const c32* __restrict__ nat, c32* __restrict__ chk, const c32* __restrict__ tw, InterLayout lay) {
+    constexpr int T = N / E, THREADS = 4 * T;
+    static_assert(CHUNK_W == 4 && CHUNK_R == 4, "the chunked staged path is written for 4 x 4 chunks");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    c32* lds = reinterpret_cast<c32*>(smem);
+    const int tid = threadIdx.x;
+    const int r = (T >= 64) ? wave_uniform(tid / T) : (tid / T);
+    const int j = tid % T;
+    const int Y = blockIdx.x;
+    c32* lds_line = lds + r * LinePitch<N>::elems;
+    c32 reg[E];
+    const c32* src = nat + (size_t)(Y * 4 + r) * N + j;
+#pragma unroll
+    for (int e = 0; e < E; ++e) reg[e] = src[e * T];
+    fft_line_to_lds<N, E>(reg, j, tw, lds_line);
+    // the chunk row is 2 N pieces of 16 bytes (chunk X, piece p: row p / 2, columns 2 (p % 2) and + 1), contiguous in
+    // this order: consecutive lanes store consecutive pieces
+    float4* dst = reinterpret_cast<float4*>(chk + (size_t)Y * lay.sy);
+#pragma unroll
+    for (int q = 0; q < (2 * N) / THREADS; ++q) {
+        const int idx = tid + q * THREADS;
+        const int p = idx & 7;
+        const int x = (idx >> 3) * 4 + 2 * (p & 1);
+        const c32* l = lds + (p >> 1) * LinePitch<N>::elems;
+        const c32 v0 = l[lds_pad(x)], v1 = l[lds_pad(x + 1)];
+        store_float4_nt(dst + idx, make_float4(v0.x, v0.y, v1.x, v1.y));
+    }
+}
+
+template <int N, int E>
+__global__ void __launch_bounds__((N / E) * 4)
+k_stage_cols(c32* __restrict__ chk, const c32* __restrict__ tw, InterLayout lay) {
+    constexpr int T = N / E, THREADS = 4 * T;
+    static_assert(CHUNK_W == 4 && CHUNK_R == 4, "the chunked staged path is written for 4 x 4 chunks");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    c32* lds = reinterpret_cast<c32*>(smem);
+    const int tid = threadIdx.x;
+    const int X = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+    c32* base = chk + (size_t)X * lay.sx;                          // chunk (X, Y) at + Y * lay.sy
+    // whole chunks in: piece idx -> chunk Y = idx / 8, piece p: row y = 4 Y + p / 2, columns 2 (p % 2) and + 1
+#pragma unroll
+    for (int q = 0; q < (2 * N) / THREADS; ++q) {
+        const int idx = tid + q * THREADS;
+        const int p = idx & 7;
+        const int y = (idx >> 3) * 4 + (p >> 1);
+        const float4 v = *reinterpret_cast<const float4*>(base + (size_t)(idx >> 3) * lay.sy + 2 * p);
+        c32* l = lds + (2 * (p & 1)) * LinePitch<N>::elems + lds_pad(y);
+        l[0] = mk(v.x, v.y);
+        l[LinePitch<N>::elems] = mk(v.z, v.w);
+    }
+    __syncthreads();
+    const int c = (T >= 64) ? wave_uniform(tid / T) : (tid / T);
+    const int j = tid % T;
+    c32* lds_line = lds + c * LinePitch<N>::elems;
+    c32 reg[E];
+    {
+        const c32* g = lds_line + lds_pad(j);
+#pragma unroll
+        for (int e = 0; e < E; ++e) reg[e] = g[e * (T + T / 16)];
+    }
+    __syncthreads();
+    fft_line_to_lds<N, E>(reg, j, tw, lds_line);
+    // whole chunks out, same addresses (every chunk of this column group was read above): thread -> (column pair h, row)
+    const int h = tid & 1;
+    const int i = tid >> 1;
+    const c32* l0 = lds + (2 * h) * LinePitch<N>::elems;
+    const c32* l1 = l0 + LinePitch<N>::elems;
+    c32* dst = base + (size_t)(i / 4) * lay.sy + (i % 4) * 4 + 2 * h;
+#pragma unroll
+    for (int q = 0; q < E / 2; ++q) {
+        const int y = i + q * (2 * T);
+        const c32 v0 = l0[lds_pad(y)], v1 = l1[lds_pad(y)];
+        store_float4_nt(reinterpret_cast<float4*>(dst + (size_t)q * ((2 * T) / 4) * lay.sy), make_float4(v0.x, v0.y, v1.x, v1.y));
+    }
+}
+
+// One workgroup per chunk row Y (4 rows of the field): wave w owns row 4 Y + w, lanes run along x, so the RGBA /
+// natural stores are whole rows; the four waves read the same 128-byte lines at the same time (one HBM fetch).
+__device__ __forceinline__ size_t chunked_index(InterLayout lay, int Y, int r, int x) {
+    return (size_t)Y * lay.sy + (size_t)(x >> 2) * lay.sx + r * 4 + (x & 3);
+}
+__global__ void __launch_bounds__(256)
+k_correct_chunked(const c32* __restrict__ height, const c32* __restrict__ disp_x, const c32* __restrict__ disp_z,
+                  float4* __restrict__ out, int n, InterLayout lay) {
+    const int Y = blockIdx.x, r = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int y = 4 * Y + r;
+    for (int x = lane; x < n; x += 64) {
+        const size_t i = chunked_index(lay, Y, r, x);
+        const float s = (((x + y) & 1) == 0) ? -1.0f : 1.0f;       // correction.comp:29
+        store_float4_nt(out + (size_t)y * n + x, make_float4(disp_x[i].x * s, height[i].x * s, disp_z[i].x * s, 0.0f));
+    }
+}
+__global__ void __launch_bounds__(256)
+k_unchunk(const c32* __restrict__ chk, c32* __restrict__ nat, int n, InterLayout lay) {
+    const int Y = blockIdx.x, r = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int x = lane; x < n; x += 64) nat[(size_t)(4 * Y + r) * n + x] = chk[chunked_index(lay, Y, r, x)];
+}
+
+// ---------------------------------------------------------------------------------------------
 // Fused frame, half-spectrum variant ("real-output" algorithm)
 // ---------------------------------------------------------------------------------------------
 // correction.comp:31 keeps only the real part of each inverse transform, and for any complex F
@@ -591,8 +712,14 @@ __device__ __forceinline__ void nyquist_spectra(const void* __restrict__ h0T, fl
 // kernel end at 133 us; a lone workgroup is latency-bound and takes 40 us for a third of the work).
 // __launch_bounds__(.., 4 waves/SIMD when the workgroup is >= 512 threads): 1024 threads per CU, i.e. one
 // 4-line or two 2-line workgroups co-resident (128 VGPRs each).
+// Waves per SIMD the register allocation must leave room for: with E = 16 a 512- or 1024-thread workgroup (or two of
+// 512) fills the CU's 1024 thread slots at 128 VGPRs; with more elements per thread (A/B knob OCEAN_E1) the workgroup
+// is smaller and each thread gets the registers of the threads that are not there.
+template <int E> constexpr int pass1_waves_per_simd(int threads) {
+    return (E == 16) ? ((threads >= 512) ? 4 : 1) : ((threads / 256) > 1 ? (threads / 256) : 1);
+}
 template <int N, int E, int P, bool H16>
-__global__ void __launch_bounds__((N / E) * P, ((N / E) * P >= 512) ? 4 : 1)
+__global__ void __launch_bounds__((N / E) * P, pass1_waves_per_simd<E>((N / E) * P))
 k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restrict__ omegaT, c32* __restrict__ inter,
              c32* nyq_spec, const c32* __restrict__ tw, InterLayout lay, float time, float domain_size) {
     constexpr int T = N / E;
@@ -609,6 +736,11 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
 
     const int X = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
     if (X == 0) nyquist_spectra<N, H16, T * P>(h0T, descale, omegaT, nyq_spec, tid, time, kscale);   // uniform branch
+#ifdef OCEAN_SETPRIO
+    // One wave of every line sits on each SIMD (T = 4 waves per line, waves dealt to the SIMDs cyclically):
+    // the line index is a priority that differs between the waves sharing a SIMD.
+    if constexpr (T >= 64) wave_priority((OCEAN_SETPRIO == 2) ? (3 - c) : c);
+#endif
     const bool packs_nyquist = (X == 0) && (c == 0);               // line 0 of that workgroup: column 0 + i * Nyquist
     const uint32_t x = (uint32_t)(X * P + c);                      // kx in [0, N/2)
     const uint32_t x2 = (N - x) & (N - 1);
@@ -729,7 +861,7 @@ __device__ __forceinline__ void half_load_AB_pairs(const void* __restrict__ h0T_
 // LDS exchange and barriers (run 16: FFT phases 14 / 10 / 13 us per field at 8192 against 6 / 6 / 7.5 for the
 // same amount of data at 4096).
 template <int N, int E, int P, bool H16>
-__global__ void __launch_bounds__((N / E) * P, ((N / E) * P >= 512) ? 4 : 1)
+__global__ void __launch_bounds__((N / E) * P, pass1_waves_per_simd<E>((N / E) * P))
 k_half_pass1_split(const void* __restrict__ h0T, float descale, const float* __restrict__ omegaT, c32* __restrict__ inter,
                    c32* nyq_spec, const c32* __restrict__ tw, InterLayout lay, float time, float domain_size) {
     constexpr int M = N / 2;                                       // sub-transform length
@@ -748,6 +880,9 @@ k_half_pass1_split(const void* __restrict__ h0T, float descale, const float* __r
 
     const int X = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
     if (X == 0) nyquist_spectra<N, H16, THREADS>(h0T, descale, omegaT, nyq_spec, tid, time, kscale);   // uniform branch
+#ifdef OCEAN_SETPRIO
+    if constexpr (TS >= 64) wave_priority((OCEAN_SETPRIO == 2) ? (3 - l) : l);   // one wave of every sub-line per SIMD
+#endif
     const bool packs_nyquist = (X == 0) && (c == 0);               // both parities of column 0 carry the Nyquist column
     const uint32_t x = (uint32_t)(X * P + c);
     const uint32_t x2 = (N - x) & (N - 1);
@@ -789,15 +924,31 @@ k_half_pass1_split(const void* __restrict__ h0T, float descale, const float* __r
             const c32 lo0 = u0 + t0, hi0 = u0 - t0, lo1 = u1 + t1, hi1 = u1 - t1;
             float4* olo = reinterpret_cast<float4*>(dst + (size_t)q * (THREADS / CR) * lay.sy);
             float4* ohi = reinterpret_cast<float4*>(dst + (size_t)(q * (THREADS / CR) + M / CR) * lay.sy);
-            *olo = make_float4(lo0.x, lo0.y, lo1.x, lo1.y);        // half a chunk row: meets its other half in L2
-            *ohi = make_float4(hi0.x, hi0.y, hi1.x, hi1.y);
+            if constexpr (P == CW) {                               // whole chunk rows (2-column chunks): streamed
+                store_float4_nt(olo, make_float4(lo0.x, lo0.y, lo1.x, lo1.y));
+                store_float4_nt(ohi, make_float4(hi0.x, hi0.y, hi1.x, hi1.y));
+            } else {
+                *olo = make_float4(lo0.x, lo0.y, lo1.x, lo1.y);    // half a chunk row: meets its other half in L2
+                *ohi = make_float4(hi0.x, hi0.y, hi1.x, hi1.y);
+            }
         }
         OCEAN_TL(3 + 2 * f);
     }
 }
 
-// Pass 2 of the half-spectrum path: one row per R2-slot; two complex FFTs per row.
-// __launch_bounds__(256, 4): four workgroups per CU (LDS: 4 x 35 KiB), i.e. at most 128 VGPRs.
+// LDS pitch of pass 2's line buffers: with two rows per workgroup the loader's 16-lane store groups alternate
+// between the two lines (see below), and a pitch of 16 dwords mod 32 banks keeps them on disjoint banks.
+template <int N, int R2> struct Pitch2 { static constexpr int elems = LdsLine<N>::elems + ((R2 == 2) ? 8 : 4); };
+
+// Pass 2 of the half-spectrum path: R2 rows per workgroup (T threads each); two complex FFTs per row.
+// Two thread mappings:
+//   loader  (lr, lk): the rows of a workgroup lie in one chunk row (R2 divides CHUNK_R), so consecutive lanes read
+//           a chunk's CHUNK_W columns of row 0, then of row 1, ...: R2 * CHUNK_W * 8 contiguous bytes per 128-byte
+//           line and per load instruction (32 B at R2 = 1 with 4 x 4 chunks, 64 B at R2 = 2) -- fewer distinct
+//           lines per wave instruction and fewer sharers of a line in L2.  R2 = 1: lk = tid, the FFT mapping.
+//   FFT     (ll, j):  a wave stays inside one row; thread j holds x[j + e T].
+// The two meet in LDS, where the full row is rebuilt from the half spectrum anyway.
+// __launch_bounds__(.., 4 waves/SIMD): 1024 threads per CU (LDS: 4 x 35 KiB or 2 x 70 KiB), i.e. at most 128 VGPRs.
 template <int N, int E, int P1, int R2>
 __global__ void __launch_bounds__((N / E) * R2, 4)
 k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32* __restrict__ tw, InterLayout lay) {
@@ -810,22 +961,34 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
     const int ll = (T >= 64) ? wave_uniform(tid / T) : (tid / T);
     const int j = tid % T;
     constexpr int CR = CHUNK_R;
-    static_assert(P1 == CHUNK_W, "pass 2 reads 4-column chunks");
+    constexpr int LP = Pitch2<N, R2>::elems;
+    static_assert(P1 == CHUNK_W, "pass 2 reads whole chunk rows");
+    static_assert(CR % R2 == 0 || R2 % CR == 0, "the rows of a workgroup tile chunk rows");
     constexpr int S = (CR > R2) ? (CR / R2) : 1;
     int rb = blockIdx.x;
     if (S > 1 && (gridDim.x % (8 * S)) == 0) {
         const int xcd = rb & 7, slot = rb >> 3;
         rb = ((slot / S) * 8 + xcd) * S + (slot % S);
     }
-    const int y = rb * R2 + ll;
-    c32* lds_line = lds + ll * LinePitch<N>::elems;
+    const int y = rb * R2 + ll;                                    // the row this thread transforms and stores
+#ifdef OCEAN_SETPRIO2
+    wave_priority(wave_uniform((int)(blockIdx.x >> 3) & 3));        // co-resident workgroups: one wave each per SIMD
+#endif
+    c32* lds_line = lds + ll * LP;
+    // loader coordinates
+    constexpr int RL = (R2 < CR) ? R2 : CR;                        // rows of one chunk this workgroup owns
+    const int lr = (R2 == 1) ? 0 : ((tid / P1) % RL + (tid / (T * RL)) * RL);   // row within the workgroup
+    const int lk0 = (R2 == 1) ? tid : (((tid % (T * RL)) / (P1 * RL)) * P1 + tid % P1);   // kx of element e = 0
+    const int ly = rb * R2 + lr;
+    c32* load_line = lds + lr * LP;
 
     float keep_h[E];
     OCEAN_TL(0);
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {                         // 0: height, 1: (disp_x, disp_z)
         const int jf = opaque_lane(j);
-        const size_t off = (size_t)(y / CR) * lay.sy + (size_t)(jf / P1) * lay.sx + (y % CR) * P1 + (jf % P1);
+        const int lk = (R2 == 1) ? jf : opaque_lane(lk0);
+        const size_t off = (size_t)(ly / CR) * lay.sy + (size_t)(lk / P1) * lay.sx + (ly % CR) * P1 + (lk % P1);
         c32 a[EH], b[EH];
         if (pass == 0) {
             const c32* src = inter + (size_t)1 * lay.fs + off;
@@ -840,8 +1003,8 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
         if (pass > 0) __syncthreads();                             // previous FFT's LDS reads done
         // rebuild the full row: C[k] = A + iB, C[N-k] = conj(A) + i conj(B).  Column 0 of the intermediate
         // holds two real columns, (kx = 0, kx = N/2) as (re, im): C[0] = re(A) + i re(B), C[N/2] = im(A) + i im(B)
-        c32* lo = lds_line + lds_pad(jf);                          // lds_pad(jf + e*T) = lds_pad(jf) + e*(T + T/16)
-        c32* hi = lds_line + lds_pad(N - jf);                      // lds_pad(N - jf - e*T) = lds_pad(N - jf) - e*(T + T/16)
+        c32* lo = load_line + lds_pad(lk);                         // lds_pad(lk + e*T) = lds_pad(lk) + e*(T + T/16)
+        c32* hi = load_line + lds_pad(N - lk);                     // lds_pad(N - lk - e*T) = lds_pad(N - lk) - e*(T + T/16)
 #pragma unroll
         for (int e = 0; e < EH; ++e) {
             c32 ck, cm;
@@ -853,14 +1016,14 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
                 cm = vfma(yx(b[e]), mk(1.0f, 1.0f), cconj(a[e]));   // conj(A) + i conj(B)
             }
             if (e == 0) {
-                const bool dc = (jf == 0);                         // kx = 0; its mirror slot is the Nyquist bin
+                const bool dc = (lk == 0);                         // kx = 0; its mirror slot is the Nyquist bin
                 if (dc) {
                     const c32 bb = (pass == 0) ? mk(0.0f, 0.0f) : b[e];
                     ck = mk(a[e].x, bb.x);
                     cm = mk(a[e].y, bb.y);
                 }
                 lo[0] = ck;
-                (dc ? (lds_line + lds_pad(N / 2)) : hi)[0] = cm;
+                (dc ? (load_line + lds_pad(N / 2)) : hi)[0] = cm;
             } else {
                 lo[e * (T + T / 16)] = ck;
                 hi[-e * (T + T / 16)] = cm;
@@ -1008,16 +1171,28 @@ k_half_pass2_split(const c32* __restrict__ inter, float4* __restrict__ out, cons
 // ---------------------------------------------------------------------------------------------
 template <int N, int PSEL = 0> struct Geo {
     static constexpr int E = 16;                                   // elements per thread
+#ifdef OCEAN_E1                                                        // A/B knob: elements per thread in fused pass 1 (N >= 4096)
+#ifndef OCEAN_E1_MIN_N
+#define OCEAN_E1_MIN_N 4096
+#endif
+    static constexpr int E1 = (N >= OCEAN_E1_MIN_N) ? OCEAN_E1 : 16;
+    static constexpr int E1S = (N / 2 >= OCEAN_E1_MIN_N) ? OCEAN_E1 : 16;    // split kernels: lines of N / 2 points
+#else
+    static constexpr int E1 = 16;
+    static constexpr int E1S = 16;
+#endif
     static constexpr int T = N / E;                                // threads per line
     static constexpr int ROW_LPW = (256 / T) > 1 ? (256 / T) : 1;  // rows per workgroup (staged)
     static constexpr int COL_LPW = (N > 4096) ? 2 : ((256 / T) > 4 ? (256 / T) : 4);  // columns per workgroup (staged)
     // lines per workgroup of fused pass 1.  4 lines = 1024 threads at N = 4096 (one workgroup per CU,
     // whole 4 x 4 chunks); 2 lines = 512 threads and 70 KiB LDS, i.e. two co-resident workgroups whose
     // load / compute / store phases overlap (each writes half of every chunk row).  PSEL = 0 = default.
-    static constexpr int P = PSEL ? PSEL : ((N > 4096) ? 2 : 4);
+    static constexpr int P = PSEL ? PSEL : ((N > 4096 || CHUNK_W < 4) ? 2 : 4);
     static constexpr int row_threads = T * ROW_LPW;
     static constexpr int col_threads = T * COL_LPW;
     static constexpr int frame_threads = T * P;
+    static constexpr int half_threads1 = (N / E1) * P;             // fused pass 1 (half-spectrum path)
+    static constexpr int split_threads1 = (N / E1S) * P;
     static constexpr int line_bytes = LinePitch<N>::elems * (int)sizeof(c32);
     static constexpr int row_lds = ROW_LPW * line_bytes;
     static constexpr int col_lds = COL_LPW * line_bytes;
@@ -1025,11 +1200,20 @@ template <int N, int PSEL = 0> struct Geo {
     static constexpr int row_grid = N / ROW_LPW;
     static constexpr int col_grid = N / COL_LPW;
     static constexpr int frame_grid = N / P;
+#ifdef OCEAN_R2                                                        // A/B knob: rows per pass-2 workgroup (>= 256 threads)
+    static constexpr int R2 = (OCEAN_R2 > ROW_LPW && T * OCEAN_R2 <= 1024) ? OCEAN_R2 : ROW_LPW;
+#else
     static constexpr int R2 = ROW_LPW;                             // rows per workgroup, thin pass 2
+#endif
     static constexpr int thin_threads = T * R2;
-    static constexpr int thin_lds = R2 * line_bytes;
+    static constexpr int thin_lds = R2 * Pitch2<N, R2>::elems * (int)sizeof(c32);
     static constexpr int thin_grid = N / R2;
     static constexpr int half_grid1 = (N / 2) / P;                 // column groups
+    // staged path with the chunked hand-off (k_stage_rows / k_stage_cols): 4 lines per workgroup
+    static constexpr bool stage_chunked = (N <= 4096) && CHUNK_W == 4 && CHUNK_R == 4;
+    static constexpr int stage_threads = 4 * T;
+    static constexpr int stage_lds = 4 * line_bytes;
+    static constexpr int stage_grid = N / 4;
     // split geometry (lines as two interleaved N/2 transforms; k_half_pass1_split / k_half_pass2_split)
     static constexpr bool can_split = (P == 2) && (N >= 512);
     static constexpr int split_lds1 = 2 * P * LinePitch<N / 2>::elems * (int)sizeof(c32);

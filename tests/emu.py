@@ -6,7 +6,10 @@ import subprocess
 import numpy as np
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_SO = os.path.join(_ROOT, "tests", "hipemu", "libocean_emu.so")
+# OCEAN_EMU_FLAGS="-DOCEAN_CHUNK_W=2 -DOCEAN_CHUNK_R=8 ..." builds (and loads) an A/B variant of the kernels
+_FLAGS = os.environ.get("OCEAN_EMU_FLAGS", "").split()
+_TAG = ("_" + "_".join(f.replace("-D", "").replace("=", "") for f in _FLAGS)) if _FLAGS else ""
+_SO = os.path.join(_ROOT, "tests", "hipemu", f"libocean_emu{_TAG}.so")
 _SRC = [os.path.join(_ROOT, "tests", "hipemu", "emu_kernels.cpp"),
         os.path.join(_ROOT, "tests", "hipemu", "hip", "hip_runtime.h"),
         os.path.join(_ROOT, "gfx_ocean_amd", "csrc", "ocean_kernels.hpp"),
@@ -20,7 +23,7 @@ def build(force=False):
     if force or stale:
         subprocess.check_call([
             "g++", "-std=c++20", "-O1", "-pthread", "-shared", "-fPIC",
-            "-I", os.path.join(_ROOT, "tests", "hipemu"), "-I", os.path.join(_ROOT, "gfx_ocean_amd", "csrc"),
+            "-I", os.path.join(_ROOT, "tests", "hipemu"), "-I", os.path.join(_ROOT, "gfx_ocean_amd", "csrc"), *_FLAGS,
             _SRC[0], "-o", _SO])
 
 
@@ -74,10 +77,16 @@ def correct(h, dx, dz):
     return out
 
 
+def chunk():
+    """(columns, rows) of a chunk in the loaded build (4 x 4 unless an A/B variant was requested)."""
+    return lib().emu_chunk_w(), lib().emu_chunk_r()
+
+
 def _layout(columns, n, P, layout, pad):
-    """(sx, sy, fs) in elements -- mirrors ocean_context_create: chunks are 4 columns x 4 rows whatever
-    the number of lines P a pass-1 workgroup owns."""
-    gx, gy = columns // 4, n // 4
+    """(sx, sy, fs) in elements -- mirrors ocean_context_create: chunks are CHUNK_W columns x CHUNK_R rows
+    (16 elements) whatever the number of lines P a pass-1 workgroup owns."""
+    cw, cr = chunk()
+    gx, gy = columns // cw, n // cr
     if layout == "p1":
         sy, sx = 16, gy * 16 + pad
         return sx, sy, sx * gx
@@ -93,10 +102,11 @@ def unpack_inter(inter, n, P, lay, f, columns=None):
     """Intermediate field f -> natural [y, x] array (columns < n for the half-spectrum path)."""
     sx, sy, fs = lay
     columns = columns or n
-    X, Y, r, c = np.meshgrid(np.arange(columns // 4), np.arange(n // 4), np.arange(4), np.arange(4), indexing="ij")
-    idx = f * fs + X * sx + Y * sy + r * 4 + c
+    cw, cr = chunk()
+    X, Y, r, c = np.meshgrid(np.arange(columns // cw), np.arange(n // cr), np.arange(cr), np.arange(cw), indexing="ij")
+    idx = f * fs + X * sx + Y * sy + r * cw + c
     out = np.empty((n, columns), np.complex64)
-    out[(Y * 4 + r).ravel(), (X * 4 + c).ravel()] = inter[idx.ravel()]
+    out[(Y * cr + r).ravel(), (X * cw + c).ravel()] = inter[idx.ravel()]
     return out
 
 
@@ -174,3 +184,30 @@ def positions(rgba, verts=128, offset=(0.0, 0.0)):
     lib().emu_positions.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_float]
     assert lib().emu_positions(n, _p(rgba), _p(out), int(verts), float(offset[0]), float(offset[1])) == 0
     return out
+
+
+def staged_chunked(fields, do_cols=True):
+    """The staged row pass (natural -> chunked), column pass (in place on the chunks) and both consumers
+    (k_unchunk, k_correct_chunked) for the three natural fields (height, disp_x, disp_z).
+    -> (natural fields after the passes, RGBA from the chunked correction)."""
+    n = fields[0].shape[0]
+    sx, sy, fs = inter_layout(n, 4)
+    tw = twiddles(n)
+    L = lib()
+    L.emu_stage.argtypes = [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_size_t] * 3
+    L.emu_unchunk.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 2 + [ctypes.c_size_t] * 3
+    L.emu_correct_chunked.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_size_t] * 3
+    chunked, natural = [], []
+    for f in fields:
+        nat = np.ascontiguousarray(f, np.complex64).copy()
+        chk = np.full(fs, np.nan + 1j * np.nan, np.complex64)
+        assert L.emu_stage(n, 0, _p(nat), _p(chk), _p(tw), sx, sy, fs) == 0
+        if do_cols:
+            assert L.emu_stage(n, 1, None, _p(chk), _p(tw), sx, sy, fs) == 0
+        back = np.full((n, n), np.nan + 1j * np.nan, np.complex64)
+        assert L.emu_unchunk(n, _p(chk), _p(back), sx, sy, fs) == 0
+        chunked.append(chk)
+        natural.append(back)
+    out = np.full((n, n, 4), np.nan, np.float32)
+    assert L.emu_correct_chunked(n, *map(_p, chunked), _p(out), sx, sy, fs) == 0
+    return natural, out

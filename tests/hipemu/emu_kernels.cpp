@@ -53,13 +53,15 @@ template <int N> static int run_fft_lines(int col, c32* data, const c32* tw) {
 template <int N> static int run_pass1(const c32* h0T, const float* omT, c32* inter, const c32* tw, InterLayout lay,
                                       float time, float L) {
     using G = Geo<N>;
-    emu_launch(G::frame_grid, G::frame_threads,
+    if constexpr (CHUNK_W % G::P != 0) return -4;
+    else emu_launch(G::frame_grid, G::frame_threads,
                [&] { k_frame_pass1<N, G::E, G::P>(h0T, omT, inter, tw, lay, time, L); });
     return 0;
 }
 template <int N> static int run_pass2(const c32* inter, float4* out, const c32* tw, InterLayout lay) {
     using G = Geo<N>;
-    emu_launch(G::frame_grid, G::frame_threads, [&] { k_frame_pass2<N, G::E, G::P>(inter, out, tw, lay); });
+    if constexpr (G::P != CHUNK_W || G::P != CHUNK_R) return -4;
+    else emu_launch(G::frame_grid, G::frame_threads, [&] { k_frame_pass2<N, G::E, G::P>(inter, out, tw, lay); });
     return 0;
 }
 
@@ -73,10 +75,10 @@ template <int N> static int run_pass2_thin(const c32* inter, float4* out, const 
 template <int N, int PSEL> static int run_half_p(const void* h0T, int f16, float descale, const float* omT, c32* inter, c32* nyq,
                                                  float4* out, const c32* tw, InterLayout lay, float time, float L) {
     using G = Geo<N, PSEL>;
-    if (f16) emu_launch(G::half_grid1, G::frame_threads,
-                        [&] { k_half_pass1<N, G::E, G::P, true>(h0T, descale, omT, inter, nyq, tw, lay, time, L); });
-    else emu_launch(G::half_grid1, G::frame_threads,
-                    [&] { k_half_pass1<N, G::E, G::P, false>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L); });
+    if (f16) emu_launch(G::half_grid1, G::half_threads1,
+                        [&] { k_half_pass1<N, G::E1, G::P, true>(h0T, descale, omT, inter, nyq, tw, lay, time, L); });
+    else emu_launch(G::half_grid1, G::half_threads1,
+                    [&] { k_half_pass1<N, G::E1, G::P, false>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L); });
     emu_launch(G::thin_grid, G::thin_threads,
                [&] { k_half_pass2<N, G::E, CHUNK_W, G::R2>(inter, out, tw, lay); });
     return 0;
@@ -85,10 +87,10 @@ template <int N> static int run_half_split(const void* h0T, int f16, float desca
                                            float4* out, const c32* tw, InterLayout lay, float time, float L) {
     using G = Geo<N, 2>;
     static_assert(G::can_split, "split geometry");
-    if (f16) emu_launch(G::half_grid1, G::frame_threads,
-                        [&] { k_half_pass1_split<N, G::E, G::P, true>(h0T, descale, omT, inter, nyq, tw, lay, time, L); });
-    else emu_launch(G::half_grid1, G::frame_threads,
-                    [&] { k_half_pass1_split<N, G::E, G::P, false>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L); });
+    if (f16) emu_launch(G::half_grid1, G::split_threads1,
+                        [&] { k_half_pass1_split<N, G::E1S, G::P, true>(h0T, descale, omT, inter, nyq, tw, lay, time, L); });
+    else emu_launch(G::half_grid1, G::split_threads1,
+                    [&] { k_half_pass1_split<N, G::E1S, G::P, false>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L); });
     emu_launch(N, G::split_threads2, [&] { k_half_pass2_split<N, G::E, CHUNK_W>(inter, out, tw, lay); });
     return 0;
 }
@@ -99,7 +101,19 @@ template <int N> static int run_half(int psel, const void* h0T, int f16, float d
         else return -3;
     }
     if (psel == 2) return run_half_p<N, 2>(h0T, f16, descale, omT, inter, nyq, out, tw, lay, time, L);
-    return run_half_p<N, 0>(h0T, f16, descale, omT, inter, nyq, out, tw, lay, time, L);
+    if constexpr (CHUNK_W % Geo<N, 0>::P != 0) return -4;
+    else return run_half_p<N, 0>(h0T, f16, descale, omT, inter, nyq, out, tw, lay, time, L);
+}
+
+// staged path with the chunked hand-off: rows (natural -> chunked), cols (in place, chunked), correction / un-chunk
+template <int N> static int run_stage(int what, c32* nat, c32* chk, const c32* tw, InterLayout lay) {
+    using G = Geo<N>;
+    if constexpr (!G::stage_chunked) return -4;
+    else {
+        if (what == 0) emu_launch(G::stage_grid, G::stage_threads, [&] { k_stage_rows<N, G::E>(nat, chk, tw, lay); });
+        else emu_launch(G::stage_grid, G::stage_threads, [&] { k_stage_cols<N, G::E>(chk, tw, lay); });
+        return 0;
+    }
 }
 
 #define DISPATCH(n, CALL)                 \
@@ -113,6 +127,8 @@ template <int N> static int run_half(int psel, const void* h0T, int f16, float d
     }
 
 extern "C" {
+int emu_chunk_w() { return CHUNK_W; }
+int emu_chunk_r() { return CHUNK_R; }
 int emu_frame_p(int n) {
 #define C_(N) Geo<N>::P
     DISPATCH(n, C_)
@@ -144,6 +160,19 @@ int emu_frame_half(int n, int psel, const void* h0T, int f16, float descale, con
 #define C_(N) run_half<N>(psel, h0T, f16, descale, omT, (c32*)inter, (c32*)nyq, (float4*)out, (const c32*)tw, InterLayout{sx, sy, fs}, time, L)
     DISPATCH(n, C_)
 #undef C_
+}
+int emu_stage(int n, int what, float* nat, float* chk, const float* tw, size_t sx, size_t sy, size_t fs) {
+#define C_(N) run_stage<N>(what, (c32*)nat, (c32*)chk, (const c32*)tw, InterLayout{sx, sy, fs})
+    DISPATCH(n, C_)
+#undef C_
+}
+int emu_unchunk(int n, const float* chk, float* nat, size_t sx, size_t sy, size_t fs) {
+    emu_launch(n / 4, 256, [&] { k_unchunk((const c32*)chk, (c32*)nat, n, InterLayout{sx, sy, fs}); });
+    return 0;
+}
+int emu_correct_chunked(int n, const float* h, const float* dx, const float* dz, float* out, size_t sx, size_t sy, size_t fs) {
+    emu_launch(n / 4, 256, [&] { k_correct_chunked((const c32*)h, (const c32*)dx, (const c32*)dz, (float4*)out, n, InterLayout{sx, sy, fs}); });
+    return 0;
 }
 int emu_positions(int n, const float* rgba, float* positions, int verts, float ox, float oz) {
     const int grid = (verts * verts + 255) / 256;

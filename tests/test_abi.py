@@ -43,7 +43,7 @@ def test_library_loads_and_reports_version(so_path):
 def test_library_contains_gfx950_code(so_path):
     with open(so_path, "rb") as f:
         blob = f.read()
-    assert b"gfx950" in blob and b"k_frame_pass1" in blob and b"k_frame_pass2" in blob
+    assert b"gfx950" in blob and b"k_half_pass1" in blob and b"k_half_pass2" in blob and b"k_fft_lines" in blob
 
 
 def test_null_handles_are_rejected_not_crashed(so_path):
@@ -72,7 +72,7 @@ def test_header_is_plain_c_and_links_from_c(so_path, tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "c_abi_check.c"), "-o", exe,
                            "-L", libdir, "-locean_hip", "-Wl,-rpath," + libdir,
-                           "-L", "/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+                           "-L", "/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lm"])
     assert subprocess.call([exe]) == 0
 
 

@@ -205,3 +205,21 @@ def test_emu_half_intermediate_layout(ref_inputs_256, P):
         spec = nyq.view(np.complex64)[f * n:(f + 1) * n]
         assert_parity(spec[:, None], (F + Fm)[:, n // 2][:, None], 5e-6, f"nyquist spectrum field {f}")
     assert np.isnan(inter.real).sum() >= 3 * (lay[2] - n * n // 2)
+
+
+@pytest.mark.parametrize("n", [256, 512])
+def test_emu_staged_chunked_handoff(n, ref_inputs, ref_inputs_256):
+    """The staged path's chunked hand-off (k_stage_rows -> k_stage_cols -> k_correct_chunked / k_unchunk, N <= 4096):
+    row pass and column pass against the fp64 line transforms, the correction against the literal shader."""
+    h0, om = ref_inputs if n == 512 else ref_inputs_256
+    fields = oc.propagate_literal(h0, om, 2.5)                       # height, disp_x, disp_z
+    rows_only, _ = emu.staged_chunked(fields, do_cols=False)
+    for got, f in zip(rows_only, fields):
+        assert_parity(got, oc.ifft_lines_f64(f), 5e-6, f"chunked row pass n={n}")
+    both, rgba = emu.staged_chunked(fields)
+    refs = [oc.ifft_lines_f64(oc.ifft_lines_f64(f).T).T for f in fields]
+    for got, ref in zip(both, refs):
+        assert not np.isnan(got.view(np.float32)).any()
+        assert_parity(got, ref, 5e-6, f"chunked row + column pass n={n}")
+    want = oc.correction_literal(*[b for b in both])                 # same inputs, the literal correction
+    assert np.array_equal(rgba, want)

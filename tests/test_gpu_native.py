@@ -1,0 +1,52 @@
+"""GPU tier: NATIVE callers drive the C ABI.  A C++ program through the host mirror
+(csrc/host/ocean.hpp: Device / Propagation / Fft / Correction / render, what src/render.rs:223-225 and
+:1101-1310 would bind) and a plain C99 program through include/ocean_hip.h decode the reference's own bincode
+inputs, run the frame at N = 512, t = 1 on the GPU and compare with the golden crop produced by executing the
+reference's shipped SPIR-V (tests/golden/spirv_frame512_t1.npz).  No Python between the caller and the library."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import gfx_ocean_amd as g
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def _build(tmp_path, compiler, std, src, name):
+    so = g.build_library()
+    libdir = os.path.dirname(so)
+    exe = str(tmp_path / name)
+    subprocess.check_call([compiler, std, "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", src),
+                           "-o", exe, "-L", libdir, "-locean_hip", "-Wl,-rpath," + libdir,
+                           "-L", "/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lm"])
+    return exe
+
+
+def _crop_file(tmp_path):
+    crop = np.load(os.path.join(GOLDEN, "spirv_frame512_t1.npz"))["crop"]      # float32 [64, 64, 4]
+    path = str(tmp_path / "crop.f32")
+    np.ascontiguousarray(crop, dtype="<f4").tofile(path)
+    return path
+
+
+@pytest.mark.gpu
+def test_cpp_host_mirror_renders_the_reference_frame(tmp_path):
+    exe = _build(tmp_path, "g++", "-std=c++17", "host_mirror_check.cpp", "host_mirror_check")
+    p = subprocess.run([exe, os.path.join(GOLDEN, "spectrum.bin"), os.path.join(GOLDEN, "omega.bin"), _crop_file(tmp_path), "1.0"],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "native c++: staged" in p.stdout
+    print(p.stdout.strip())
+
+
+@pytest.mark.gpu
+def test_plain_c_caller_renders_the_reference_frame(tmp_path):
+    exe = _build(tmp_path, "gcc", "-std=c99", "c_abi_check.c", "c_abi_check")
+    p = subprocess.run([exe, os.path.join(GOLDEN, "spectrum.bin"), os.path.join(GOLDEN, "omega.bin"), _crop_file(tmp_path)],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "native c: fused" in p.stdout
+    print(p.stdout.strip())

@@ -84,6 +84,41 @@ def test_stage_by_stage_512(r512, ref_inputs):
     assert_parity(r512.displacement()[..., :3], oc.frame_f64(h0, om, t)[..., :3], TOL, "after correction")
 
 
+def test_staged_field_layout_state_machine(r512):
+    """The staged calls hand a field from the row pass to the column pass in the chunked layout (N <= 4096,
+    k_stage_rows / k_stage_cols); ocean_read_field / ocean_write_field and every order of calls must still behave
+    as the reference's in-place passes on a natural buffer: read after any stage, inject then transform columns
+    first, transform rows twice."""
+    n = 512
+    dev = r512.device
+    rng = np.random.default_rng(5)
+    a = (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))).astype(np.complex64)
+    rows_of = lambda v: oc.ifft_lines_f64(v)                        # noqa: E731
+    cols_of = lambda v: oc.ifft_lines_f64(np.ascontiguousarray(v.T)).T   # noqa: E731
+    # rows -> read (natural copy made, chunked copy still current) -> cols on the chunks -> read
+    dev.write_field(g.FIELD_DX, a)
+    r512.fft.row_pass(g.FIELD_DX)
+    assert_parity(dev.read_field(g.FIELD_DX), rows_of(a), 5e-6, "rows")
+    r512.fft.col_pass(g.FIELD_DX)
+    assert_parity(dev.read_field(g.FIELD_DX), cols_of(rows_of(a)), 5e-6, "rows, read, cols")
+    # inject, then the column pass first (natural-layout kernel), then the row pass
+    dev.write_field(g.FIELD_DY, a)
+    r512.fft.col_pass(g.FIELD_DY)
+    assert_parity(dev.read_field(g.FIELD_DY), cols_of(a), 5e-6, "cols on an injected field")
+    r512.fft.row_pass(g.FIELD_DY)
+    assert_parity(dev.read_field(g.FIELD_DY), rows_of(cols_of(a)), 5e-6, "cols then rows")
+    # two row passes in a row (the second starts from the chunked result of the first), without a read between
+    dev.write_field(g.FIELD_DZ, a)
+    r512.fft.row_pass(g.FIELD_DZ)
+    r512.fft.row_pass(g.FIELD_DZ)
+    assert_parity(dev.read_field(g.FIELD_DZ), rows_of(rows_of(a)), 5e-6, "rows twice")
+    # correction with the three fields in three different states (chunked, natural, chunked)
+    r512.fft.col_pass(g.FIELD_DZ)
+    r512.correction.dispatch(g.CorrectionLocals(n))
+    want = oc.correction_literal(dev.read_field(g.FIELD_DY), dev.read_field(g.FIELD_DX), dev.read_field(g.FIELD_DZ))
+    assert np.array_equal(r512.displacement(), want)
+
+
 def test_config1_n256_centre_crop(r256, ref_inputs_256):
     for t in (0.0, 1.0):
         r256.render_fused(t)
@@ -283,7 +318,14 @@ def test_config5_fp16_spectrum(n, ref_inputs):
             nmax, rl2 = oc.parity_errors(out[..., :3], oc.frame_f64(h0, om, t)[..., :3])
             assert rl2.max() > 1e-5              # the quantisation is real: not the fp32 result
         else:
-            # full size: sampled texels by direct fp64 summation of the quantised spectrum
+            # full size, EVERY texel: the C restatement of the four shaders on the host cores, fed the same
+            # dequantised spectrum the kernels use (config 5 parity is judged on the quantised inputs)
+            cc.set_threads(min(32, cc.max_threads()))
+            refc = cc.FrameRunner(deq, om).frame(t)
+            nmax, rl2 = assert_parity(out[..., :3], refc[..., :3], TOL, f"N={n} fp16 spectrum vs C oracle(quantised)")
+            assert nmax.max() < 2e-5                      # two fp32 paths on identical inputs: a few 1e-6
+            assert np.all(out[..., 3] == 0.0)
+            # and sampled texels by direct fp64 summation of the quantised spectrum (independent of any FFT)
             H, DX, DZ = oc.propagate_f64(deq, om, t)
             k = np.arange(n)
             scale = np.abs(out[..., :3]).max((0, 1))
