@@ -26,6 +26,8 @@ SYMBOLS = [
     "ocean_normals", "ocean_read_normals", "ocean_positions", "ocean_read_positions",
     "ocean_read_displacement", "ocean_read_field", "ocean_write_field", "ocean_displacement_device_ptr",
     "ocean_bind_displacement", "ocean_stream", "ocean_time_frames", "ocean_profile_frame", "ocean_profile_staged",
+    "ocean_shard_create", "ocean_shard_destroy", "ocean_shard_last_error", "ocean_shard_upload", "ocean_shard_rows",
+    "ocean_shard_cols", "ocean_shard_sync", "ocean_shard_stream",
 ]
 
 
@@ -117,6 +119,14 @@ def load_library():
                                       ctypes.POINTER(i32)]),
         "ocean_profile_staged": (i32, [vp, f32, i32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(f32),
                                        ctypes.POINTER(i32)]),
+        "ocean_shard_create": (i32, [i32, i32, i32, i32, pp]),
+        "ocean_shard_destroy": (None, [vp]),
+        "ocean_shard_last_error": (ctypes.c_char_p, [vp]),
+        "ocean_shard_upload": (i32, [vp, vp, vp, vp]),
+        "ocean_shard_rows": (i32, [vp, ctypes.POINTER(PropagateLocalsC), vp, vp]),
+        "ocean_shard_cols": (i32, [vp, vp, vp, vp]),
+        "ocean_shard_sync": (i32, [vp]),
+        "ocean_shard_stream": (vp, [vp]),
     }
     assert sorted(sig) == sorted(SYMBOLS)
     for name, (res, args) in sig.items():

@@ -21,6 +21,19 @@
 
 #include <ocean_device_intrinsics.hpp>
 
+// Timing experiments only (results are wrong, never shipped): OCEAN_X_NOBAR=1 drops the write-after-read barriers of the
+// line FFT, =2 drops every barrier inside it -- an upper bound on what a barrier-free (one wave per line) exchange buys.
+#if defined(OCEAN_X_NOBAR) && OCEAN_X_NOBAR >= 1
+#define OCEAN_FFT_WAR_BARRIER() ((void)0)
+#else
+#define OCEAN_FFT_WAR_BARRIER() __syncthreads()
+#endif
+#if defined(OCEAN_X_NOBAR) && OCEAN_X_NOBAR >= 2
+#define OCEAN_FFT_RAW_BARRIER() ((void)0)
+#else
+#define OCEAN_FFT_RAW_BARRIER() __syncthreads()
+#endif
+
 namespace ocean {
 
 // c32 (ocean_device_intrinsics.hpp) is a packed (re, im) 2-vector; everything here is written in whole-vector
@@ -236,7 +249,7 @@ template <int N, int E, int R, int NS, int TWS = 1>
 __device__ __forceinline__ void fft_pass_exchange(c32 (&reg)[E], int j, const c32* __restrict__ tw, c32* lds_line) {
     constexpr int T = N / E;
     fft_pass<N, E, R, NS, TWS>(reg, j, tw, [&](int, int ppos, c32 v, int) { lds_line[ppos] = v; });
-    __syncthreads();
+    OCEAN_FFT_RAW_BARRIER();
     // lds_pad(j + e*T) == lds_pad(j) + e*(T + T/16)   (T is a multiple of 16)
     const c32* g = lds_line + lds_pad(j);
 #pragma unroll
@@ -255,7 +268,7 @@ __device__ __forceinline__ void fft_line(c32 (&reg)[E], int j, const c32* __rest
     (void)ns;
     if constexpr (R0 > 1) {
         fft_pass_exchange<N, E, R0, 1, TWS>(reg, j, tw, lds_line);
-        __syncthreads();   // WAR: next scatter reuses the buffer
+        OCEAN_FFT_WAR_BARRIER();   // WAR: next scatter reuses the buffer
     }
     constexpr int NS1 = R0;                  // after the optional small pass
     if constexpr (Q == 1) {
@@ -272,7 +285,7 @@ __device__ __forceinline__ void fft_line(c32 (&reg)[E], int j, const c32* __rest
 #pragma unroll
             for (int e = 0; e < E; ++e) reg[e] = out[e];
         } else {
-            __syncthreads();
+            OCEAN_FFT_WAR_BARRIER();
             fft_pass_exchange<N, E, E, NS2, TWS>(reg, j, tw, lds_line);
             constexpr int NS3 = NS2 * E;
             c32 out[E];
@@ -293,17 +306,17 @@ __device__ __forceinline__ void fft_line_to_lds(c32 (&reg)[E], int j, const c32*
     static_assert(Q >= 2 && Q <= 3, "unsupported N/E combination");
     if constexpr (R0 > 1) {
         fft_pass_exchange<N, E, R0, 1, TWS>(reg, j, tw, lds_line);
-        __syncthreads();
+        OCEAN_FFT_WAR_BARRIER();
     }
     constexpr int NS1 = R0;
     fft_pass_exchange<N, E, E, NS1, TWS>(reg, j, tw, lds_line);
-    __syncthreads();
+    OCEAN_FFT_WAR_BARRIER();
     constexpr int NS2 = NS1 * E;
     if constexpr (Q == 2) {
         fft_pass<N, E, E, NS2, TWS>(reg, j, tw, [&](int, int ppos, c32 v, int) { lds_line[ppos] = v; });
     } else {
         fft_pass_exchange<N, E, E, NS2, TWS>(reg, j, tw, lds_line);
-        __syncthreads();
+        OCEAN_FFT_WAR_BARRIER();
         constexpr int NS3 = NS2 * E;
         fft_pass<N, E, E, NS3, TWS>(reg, j, tw, [&](int, int ppos, c32 v, int) { lds_line[ppos] = v; });
     }

@@ -137,6 +137,10 @@ template <int N> struct Launch {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, G::col_lds);
         if (e != hipSuccess) return e;
         if constexpr (G::stage_chunked) {
+#ifdef OCEAN_STAGE_ROWS_THIN
+            e = hipFuncSetAttribute((const void*)k_stage_rows_thin<N, G::E, G::ROW_LPW>, hipFuncAttributeMaxDynamicSharedMemorySize, G::row_lds);
+            if (e != hipSuccess) return e;
+#endif
             e = hipFuncSetAttribute((const void*)k_stage_rows<N, G::E>, hipFuncAttributeMaxDynamicSharedMemorySize, G::stage_lds);
             if (e != hipSuccess) return e;
             e = hipFuncSetAttribute((const void*)k_stage_cols<N, G::E>, hipFuncAttributeMaxDynamicSharedMemorySize, G::stage_lds);
@@ -246,9 +250,15 @@ template <int N> struct Launch {
                    (const c32*)c->inter, c->out, (const c32*)c->tw, c->lay_h);
     }
     static void stage_rows(OceanContext* c, int f, hipStream_t s) {
+#ifdef OCEAN_STAGE_ROWS_THIN   // A/B: one row per 256-thread workgroup, 32-byte chunk pieces merged in L2
+        if constexpr (G::stage_chunked && G::T >= 4)
+            hipLaunchKernelGGL((k_stage_rows_thin<N, G::E, G::ROW_LPW>), dim3(G::row_grid), dim3(G::row_threads), G::row_lds, s,
+                               (const c32*)c->field[f], c->cfield[f], (const c32*)c->tw, c->lay);
+#else
         if constexpr (G::stage_chunked)
             hipLaunchKernelGGL((k_stage_rows<N, G::E>), dim3(G::stage_grid), dim3(G::stage_threads), G::stage_lds, s,
                                (const c32*)c->field[f], c->cfield[f], (const c32*)c->tw, c->lay);
+#endif
     }
     static void stage_cols(OceanContext* c, int f, hipStream_t s) {
         if constexpr (G::stage_chunked)
@@ -315,8 +325,9 @@ hipStream_t pick(OceanContext* c, void* stream) { return stream ? (hipStream_t)s
 
 void launch_propagate(OceanContext* c, float time, float domain, hipStream_t s) {
     const unsigned grid = (unsigned)(((size_t)c->n * c->n / 2 + 255) / 256);
-    hipLaunchKernelGGL(k_propagate, dim3(grid), dim3(256), 0, s, c->h0, c->omega, c->field[OCEAN_FIELD_DY],
-                       c->field[OCEAN_FIELD_DX], c->field[OCEAN_FIELD_DZ], c->n, time, domain, c->quirks);
+    hipLaunchKernelGGL(k_propagate, dim3(grid), dim3(256), 0, s, (const c32*)c->h0, (const c32*)c->h0, (const float*)c->omega,
+                       c->field[OCEAN_FIELD_DY], c->field[OCEAN_FIELD_DX], c->field[OCEAN_FIELD_DZ], c->n, 0, c->n, time,
+                       domain, c->quirks);
     for (int f = 0; f < 3; ++f) { c->nat_valid[f] = true; c->chk_valid[f] = false; }
 }
 // Make the natural copy of field f current (no-op when it already is).
@@ -334,7 +345,8 @@ void launch_correct(OceanContext* c, hipStream_t s) {
     }
     for (int f = 0; f < 3; ++f) launch_unchunk(c, f, s);
     const unsigned grid = (unsigned)(((size_t)c->n * c->n / 2 + 255) / 256);
-    hipLaunchKernelGGL(k_correct, dim3(grid), dim3(256), 0, s, c->field[dy], c->field[dx], c->field[dz], c->out, c->n);
+    hipLaunchKernelGGL(k_correct, dim3(grid), dim3(256), 0, s, (const c32*)c->field[dy], (const c32*)c->field[dx],
+                       (const c32*)c->field[dz], c->out, c->n, 0, c->n);
 }
 // Row pass of field f (shader/fft_row.comp:44-63).  N <= 4096: natural rows in, chunked field out; else in place.
 void launch_rows(OceanContext* c, int f, hipStream_t s) {
@@ -853,3 +865,5 @@ int32_t ocean_profile_staged(OceanContext* ctx, float time, int32_t cap, const c
 }
 
 }  // extern "C"
+
+#include "ocean_shard.hip"   // the sharded-tile entry points (same translation unit, same kernels)

@@ -82,22 +82,27 @@ __device__ __forceinline__ c32 mul_minus_i_kn(float kn, c32 h) { return yx(h) * 
 // ---------------------------------------------------------------------------------------------
 // Staged kernels
 // ---------------------------------------------------------------------------------------------
-// One thread per 2 texels.  grid = N*N/2/256.
+// One thread per 2 texels of a block of `rows` rows starting at row `row0` (the whole tile: row0 = 0, rows = N;
+// grid = rows*N/2/256).  h0 / omega / outputs point at the block's first texel; h0_partner points at the first texel
+// of the rows the "-k" partners live in: the block itself for the whole tile, the opposite row block
+// [N - row0 - rows, N - row0) when the tile is sharded by row blocks (Q2 on only).
 __global__ void __launch_bounds__(256)
-k_propagate(const c32* __restrict__ h0, const float* __restrict__ omega, c32* __restrict__ height,
-            c32* __restrict__ disp_x, c32* __restrict__ disp_z, int n, float time, float domain_size, uint32_t quirks) {
+k_propagate(const c32* __restrict__ h0, const c32* __restrict__ h0_partner, const float* __restrict__ omega,
+            c32* __restrict__ height, c32* __restrict__ disp_x, c32* __restrict__ disp_z, int n, int row0, int rows,
+            float time, float domain_size, uint32_t quirks) {
     const uint32_t un = (uint32_t)n;
     const uint32_t pair = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t total = un * un;
+    const uint32_t total = un * (uint32_t)rows;
     const uint32_t index = pair * 2u;
     if (index >= total) return;
-    const uint32_t gx = index % un, gy = index / un;               // gx even, gx+1 same row
+    const uint32_t gx = index % un, gy = index / un + (uint32_t)row0;   // gx even, gx+1 same row
     const float4 own = *reinterpret_cast<const float4*>(h0 + index);
-    // index_neg = N*N-1-index (:48); the pair (index, index+1) mirrors to (ineg, ineg-1).  With Q2 off the
-    // partners are columns ((N+1-gx)%N, (N-gx)%N) of row (N+1-gy)%N: the same reversed pair, other base.
+    // index_neg = N*N-1-index (:48): row N-1-gy reversed, i.e. the partner block read backwards; the pair
+    // (index, index+1) mirrors to (ineg, ineg-1).  With Q2 off the partners are columns ((N+1-gx)%N, (N-gx)%N) of
+    // row (N+1-gy)%N: the same reversed pair, other base (whole-tile calls only).
     const bool q2 = (quirks & OCEAN_QUIRK_Q2) != 0u;
     const uint32_t pbase = q2 ? (total - 2u - index) : (((un + 1u - gy) & (un - 1u)) * un + ((un - gx) & (un - 1u)));
-    float4 neg = *reinterpret_cast<const float4*>(h0 + pbase);
+    float4 neg = *reinterpret_cast<const float4*>(h0_partner + pbase);
     if (!q2) { neg.y = -neg.y; neg.w = -neg.w; }                   // conjugated partner
     const c32 om = *reinterpret_cast<const c32*>(omega + index);
     const float ky = OCEAN_PI_F * wave_index(gy, un, quirks) / domain_size;
@@ -115,14 +120,16 @@ k_propagate(const c32* __restrict__ h0, const float* __restrict__ omega, c32* __
     *reinterpret_cast<float4*>(disp_z + index) = make_float4(dz0.x, dz0.y, dz1.x, dz1.y);
 }
 
-// One thread per 2 texels.
+// One thread per 2 texels of a block of `lines` lines of N texels starting at line `line0` (whole tile: 0, N).
+// The sign depends on the parity of x + y only, so the same kernel serves a block of rows (line = y) and, in the
+// sharded transform, a block of columns stored as lines (line = x, position = y).
 __global__ void __launch_bounds__(256)
 k_correct(const c32* __restrict__ height, const c32* __restrict__ disp_x, const c32* __restrict__ disp_z,
-          float4* __restrict__ out, int n) {
+          float4* __restrict__ out, int n, int line0, int lines) {
     const uint32_t un = (uint32_t)n;
     const uint32_t index = (blockIdx.x * 256u + threadIdx.x) * 2u;
-    if (index >= un * un) return;
-    const uint32_t x = index % un, y = index / un;
+    if (index >= un * (uint32_t)lines) return;
+    const uint32_t x = index % un, y = index / un + (uint32_t)line0;
     const float4 h = *reinterpret_cast<const float4*>(height + index);
     const float4 dx = *reinterpret_cast<const float4*>(disp_x + index);
     const float4 dz = *reinterpret_cast<const float4*>(disp_z + index);
@@ -472,6 +479,36 @@ k_stage_rows(const c32* __restrict__ nat, c32* __restrict__ chk, const c32* __re
     }
 }
 
+// A/B variant of the row pass: ROW_LPW rows per workgroup as k_fft_lines<ROW> (256 threads, 4 workgroups per CU), each row
+// stored as 32-byte pieces of the chunks; the four workgroups that fill a chunk row run in adjacent slots of one XCD
+// and their pieces meet in its L2 (plain stores).
+template <int N, int E, int LPW>
+__global__ void __launch_bounds__((N / E) * LPW)
+k_stage_rows_thin(const c32* __restrict__ nat, c32* __restrict__ chk, const c32* __restrict__ tw, InterLayout lay) {
+    constexpr int T = N / E;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    c32* lds = reinterpret_cast<c32*>(smem);
+    const int tid = threadIdx.x;
+    const int ll = (T >= 64) ? wave_uniform(tid / T) : (tid / T);
+    const int j = tid % T;
+    constexpr int S = (4 > LPW) ? (4 / LPW) : 1;                   // workgroups per chunk row
+    int rb = blockIdx.x;
+    if (S > 1 && (gridDim.x % (8 * S)) == 0) {
+        const int xcd = rb & 7, slot = rb >> 3;
+        rb = ((slot / S) * 8 + xcd) * S + (slot % S);
+    }
+    const int y = rb * LPW + ll;
+    c32* lds_line = lds + ll * LinePitch<N>::elems;
+    c32 reg[E];
+    const c32* src = nat + (size_t)y * N + j;
+#pragma unroll
+    for (int e = 0; e < E; ++e) reg[e] = src[e * T];
+    fft_line<N, E>(reg, j, tw, lds_line);
+    c32* dst = chk + (size_t)(y >> 2) * lay.sy + (size_t)(j >> 2) * lay.sx + (y & 3) * 4 + (j & 3);
+#pragma unroll
+    for (int e = 0; e < E; ++e) dst[(size_t)e * (T / 4) * lay.sx] = reg[e];
+}
+
 template <int N, int E>
 __global__ void __launch_bounds__((N / E) * 4)
 k_stage_cols(c32* __restrict__ chk, const c32* __restrict__ tw, InterLayout lay) {
@@ -754,6 +791,9 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
     const int i = tid / H2;
     const c32* l0 = lds + (2 * h) * LinePitch<N>::elems;
     const c32* l1 = lds + (2 * h + 1) * LinePitch<N>::elems;
+#ifdef OCEAN_ROTQ
+    const int rotq = (OCEAN_ROTQ == 2) ? (int)((blockIdx.x * 5u + (blockIdx.x >> 3)) & (E / 2 - 1)) : (X & (E / 2 - 1));
+#endif
 #pragma unroll
     for (int f = 0; f < 3; ++f) {
         c32 reg[E];
@@ -767,12 +807,30 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
             }
         }
         if (f > 0) __syncthreads();
+#ifdef OCEAN_X_NOFFT   // timing experiment only (wrong results): the transform replaced by its final LDS scatter
+        {
+            c32* g = lds_line + lds_pad(jf);
+#pragma unroll
+            for (int e = 0; e < E; ++e) g[e * (T + T / 16)] = reg[e];
+            __syncthreads();
+        }
+#else
         fft_line_to_lds<N, E>(reg, jf, tw, lds_line);
+#endif
         OCEAN_TL(2 + 2 * f);
         c32* dst = inter + (size_t)f * lay.fs + (size_t)((X * P) / CW) * lay.sx + (size_t)(i / CR) * lay.sy + (i % CR) * CW +
                    ((X * P) % CW) + 2 * h;
 #pragma unroll
-        for (int q = 0; q < E / 2; ++q) {
+        for (int q0 = 0; q0 < E / 2; ++q0) {
+#ifdef OCEAN_ROTQ
+            // Every workgroup walks the rows of its columns from a different starting block: without this all 256
+            // resident workgroups store to the same few chunk rows at the same time (a moving 8 MB window of the
+            // intermediate), which the memory system serves at the rate of a grid-stride store (4.1-4.8 TB/s in
+            // tools/membench2) instead of the 5.4-6.2 TB/s of stores spread over the whole buffer.
+            const int q = (q0 + rotq) & (E / 2 - 1);
+#else
+            const int q = q0;
+#endif
             const int y = i + q * (2 * T);
             const c32 v0 = l0[lds_pad(y)];
             const c32 v1 = l1[lds_pad(y)];
@@ -914,7 +972,12 @@ k_half_pass1_split(const void* __restrict__ h0T, float descale, const float* __r
         c32* dst = inter + (size_t)f * lay.fs + (size_t)((X * P) / CW) * lay.sx + (size_t)(tf / CR) * lay.sy + (tf % CR) * CW +
                    ((X * P) % CW);
 #pragma unroll
-        for (int q = 0; q < M / THREADS; ++q) {
+        for (int q0 = 0; q0 < M / THREADS; ++q0) {
+#ifdef OCEAN_ROTQ
+            const int q = (q0 + (X & (M / THREADS - 1))) & (M / THREADS - 1);   // see k_half_pass1
+#else
+            const int q = q0;
+#endif
             const int k = tf + q * THREADS;                        // rows k and k + M
             const c32 w = tw[k];
             const c32 wr = crot(w);
@@ -1163,6 +1226,61 @@ k_half_pass2_split(const c32* __restrict__ inter, float4* __restrict__ out, cons
         }
         if (pass == 1) OCEAN_TL(6);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// One N x N transform sharded by row blocks over `world` GPUs (N up to 16384)
+// ---------------------------------------------------------------------------------------------
+// Rank r owns rows [r N/world, (r+1) N/world) of the three spectra: k_propagate on its block, the row pass below,
+// ONE all-to-all, then the column pass on the N/world columns it receives (k_shard_transpose + k_fft_lines<ROW> +
+// k_correct).  The row pass stores straight into the all-to-all send buffer
+//     send[dest][field][row][column of dest]      (dest = x / cols; pieces of `cols` contiguous elements),
+// and the receive buffer recv[src][field][row of src][my column] is the column block in row-major order.
+template <int N, int E, int LPW>
+__global__ void __launch_bounds__((N / E) * LPW)
+k_shard_rows(const c32* __restrict__ block, c32* __restrict__ send, const c32* __restrict__ tw, int field, int rows,
+             int cols_log2) {
+    constexpr int T = N / E;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    c32* lds = reinterpret_cast<c32*>(smem);
+    const int tid = threadIdx.x;
+    const int ll = (T >= 64) ? wave_uniform(tid / T) : (tid / T);
+    const int j = tid % T;
+    const int line = (int)blockIdx.x * LPW + ll;                   // local row
+    c32* lds_line = lds + ll * LinePitch<N>::elems;
+    c32 reg[E];
+    const c32* src = block + (size_t)line * N + j;
+#pragma unroll
+    for (int e = 0; e < E; ++e) reg[e] = src[e * T];
+    fft_line<N, E>(reg, j, tw, lds_line);
+    const int cols = 1 << cols_log2;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int x = j + e * T;
+        const int dest = x >> cols_log2;
+        send[(((size_t)dest * 3 + field) * rows + line) * cols + (x & (cols - 1))] = reg[e];
+    }
+}
+
+// recv[src][field][rows][cols] (field f of the column block, row-major: y = src * rows + row) -> out[column][y],
+// 32 x 32 tiles through LDS (32 * 33 * 8 bytes, dynamic), both sides in 256-byte pieces.
+// grid = (N / 32) * (cols / 32), 256 threads.
+__global__ void __launch_bounds__(256)
+k_shard_transpose(const c32* __restrict__ recv, c32* __restrict__ out, int n, int field, int rows, int cols) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    c32 (*tile)[33] = reinterpret_cast<c32 (*)[33]>(smem);
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int tiles_y = n / 32;
+    const int y0 = ((int)blockIdx.x % tiles_y) * 32, c0 = ((int)blockIdx.x / tiles_y) * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int y = y0 + ty + 8 * k;
+        const int src = y / rows, ry = y - src * rows;
+        tile[ty + 8 * k][tx] = recv[(((size_t)src * 3 + field) * rows + ry) * cols + c0 + tx];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[(size_t)(c0 + ty + 8 * k) * n + y0 + tx] = tile[tx][ty + 8 * k];
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -10,6 +10,8 @@ pub struct OceanFft { _p: [u8; 0] }
 pub struct OceanPropagation { _p: [u8; 0] }
 #[repr(C)]
 pub struct OceanCorrection { _p: [u8; 0] }
+#[repr(C)]
+pub struct OceanShard { _p: [u8; 0] }
 
 /// src/ocean.rs:8-13 -- here with the explicit layout the reference relies on by accident (Q6).
 #[repr(C)]
@@ -60,4 +62,17 @@ extern "C" {
                                ms: *mut f32, out_n: *mut i32) -> i32;
     pub fn ocean_profile_staged(ctx: *mut OceanContext, time: f32, cap: i32, names: *mut *const c_char,
                                 ms: *mut f32, out_n: *mut i32) -> i32;
+
+    // ---- one N x N tile sharded by row blocks over the GPUs of a node (include/ocean_hip.h "sharded tile") ----
+    pub fn ocean_shard_create(device_ordinal: i32, resolution: i32, rank: i32, world: i32, out: *mut *mut OceanShard) -> i32;
+    pub fn ocean_shard_destroy(shard: *mut OceanShard);
+    pub fn ocean_shard_last_error(shard: *const OceanShard) -> *const c_char;
+    pub fn ocean_shard_upload(shard: *mut OceanShard, h0_own_rows: *const f32, h0_partner_rows: *const f32,
+                              omega_own_rows: *const f32) -> i32;
+    pub fn ocean_shard_rows(shard: *mut OceanShard, locals: *const OceanPropagateLocals, send_device: *mut c_void,
+                            stream: *mut c_void) -> i32;
+    pub fn ocean_shard_cols(shard: *mut OceanShard, recv_device: *const c_void, out_rgba_t_device: *mut c_void,
+                            stream: *mut c_void) -> i32;
+    pub fn ocean_shard_sync(shard: *mut OceanShard) -> i32;
+    pub fn ocean_shard_stream(shard: *mut OceanShard) -> *mut c_void;
 }

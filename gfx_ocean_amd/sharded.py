@@ -1,0 +1,140 @@
+"""ONE N x N tile whose 2-D transform is sharded over the GPUs of a node (include/ocean_hip.h
+"sharded tile").  Independent tiles need no exchange (bench.py); this module is for a single tile that is
+too large or too slow for one GPU (N up to 16384).
+
+Decomposition = the reference's own dispatch order (src/render.rs:1122-1310): propagate and all row passes, a
+barrier, all column passes, correction -- with the barrier replaced by ONE all-to-all over xGMI:
+
+    rank r owns rows [r N/R, (r+1) N/R)           propagate + row pass on them        (ocean_shard_rows)
+    all_to_all_single(recv, send)                 3 N^2 8 / R bytes per rank and frame, (R-1)/R of it over xGMI
+    rank r owns columns [r N/R, (r+1) N/R)        column pass + correction on them    (ocean_shard_cols)
+
+The result is distributed by COLUMN blocks and stored transposed: ``out[x - r N/R, y] = (disp_x, height, disp_z, 0)``.
+
+`ShardedTile` drives a backend with three calls (upload / rows / cols).  The product backend is `HipShardBackend`
+(the C ABI on device memory, RCCL through torch.distributed); the tests plug in a backend that executes the same
+kernels on the CPU (tests/emu.py) under gloo.  There is no CPU fallback in the product: `HipShardBackend` raises
+OceanError without the HIP library or a GPU.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from ._lib import OCEAN_OK, OceanError, PropagateLocalsC, load_library
+from .ocean import DOMAIN_SIZE
+
+
+def split_inputs(h0: np.ndarray, omega: np.ndarray, rank: int, world: int):
+    """The static inputs rank `rank` of `world` needs: its own rows of h0 and omega, and the rows of h0 in which the
+    "-k" partners of its texels live -- texel (gx, gy) pairs with (N-1-gx, N-1-gy) (shader/propagate.comp:48), i.e.
+    with the opposite row block read backwards."""
+    n = h0.shape[0]
+    rows = n // world
+    own = slice(rank * rows, (rank + 1) * rows)
+    partner = slice(n - (rank + 1) * rows, n - rank * rows)
+    return (np.ascontiguousarray(h0[own], np.complex64), np.ascontiguousarray(h0[partner], np.complex64),
+            np.ascontiguousarray(omega[own], np.float32))
+
+
+def exchange_bytes_per_rank(n: int, world: int) -> int:
+    """All-to-all payload per rank and frame: three complex fp32 fields of N/world rows (its own part stays local)."""
+    return 3 * (n // world) * n * 8
+
+
+class HipShardBackend:
+    """The C ABI (ocean_shard_*) on torch CUDA tensors; torch supplies device memory and the collective only."""
+
+    def __init__(self, n: int, rank: int, world: int, device_ordinal: int = 0):
+        import torch
+        self.torch = torch
+        self.lib = load_library()
+        h = ctypes.c_void_p()
+        st = self.lib.ocean_shard_create(int(device_ordinal), int(n), int(rank), int(world), ctypes.byref(h))
+        if st != OCEAN_OK:
+            raise OceanError(st, (self.lib.ocean_shard_last_error(None) or b"").decode())
+        self._h = h
+        self.n, self.rank, self.world, self.rows = n, rank, world, n // world
+        self.device = torch.device("cuda", device_ordinal)
+        # Kernels and the collective are ordered on ONE explicit stream.  (torch's default stream has the handle 0,
+        # which the C ABI reads as "the shard's own stream": work launched there would not be ordered with torch's.)
+        self.stream = torch.cuda.Stream(self.device)
+
+    def _check(self, st):
+        if st != OCEAN_OK:
+            raise OceanError(st, (self.lib.ocean_shard_last_error(self._h) or b"").decode())
+
+    def upload(self, h0_own, h0_partner, omega_own):
+        self._check(self.lib.ocean_shard_upload(self._h, h0_own.ctypes.data, h0_partner.ctypes.data, omega_own.ctypes.data))
+
+    def alloc_exchange(self):
+        """[dest or src][field][row][column] complex fp32, as float32 pairs (RCCL moves plain floats)."""
+        return self.torch.empty((self.world, 3, self.rows, self.rows, 2), dtype=self.torch.float32, device=self.device)
+
+    def alloc_out(self):
+        return self.torch.empty((self.rows, self.n, 4), dtype=self.torch.float32, device=self.device)
+
+    def on_stream(self):
+        """Context manager: torch work issued inside (the all-to-all) is ordered with the shard's kernels."""
+        return self.torch.cuda.stream(self.stream)
+
+    def rows_pass(self, time, domain_size, send):
+        loc = PropagateLocalsC(float(time), int(self.n), float(domain_size))
+        self._check(self.lib.ocean_shard_rows(self._h, ctypes.byref(loc), send.data_ptr(), self.stream.cuda_stream))
+
+    def cols_pass(self, recv, out):
+        self._check(self.lib.ocean_shard_cols(self._h, recv.data_ptr(), out.data_ptr(), self.stream.cuda_stream))
+
+    def synchronize(self):
+        self.stream.synchronize()
+
+    def to_numpy(self, out):
+        self.stream.synchronize()
+        return out.cpu().numpy()
+
+    def destroy(self):
+        if self._h:
+            self.lib.ocean_shard_destroy(self._h)
+            self._h = None
+
+
+class ShardedTile:
+    """frame(t) = rows pass -> one all-to-all -> column pass.  `dist` is an initialised torch.distributed (RCCL on the
+    GPUs, gloo in the CPU tests); None (world == 1 only) skips the collective."""
+
+    def __init__(self, backend, dist=None, domain_size: float = DOMAIN_SIZE):
+        self.b, self.dist, self.domain_size = backend, dist, float(domain_size)
+        self.send = backend.alloc_exchange()
+        self.recv = backend.alloc_exchange()
+        self.out = backend.alloc_out()
+
+    def upload(self, h0: np.ndarray, omega: np.ndarray):
+        """Every rank passes the same full arrays (or at least its own slices of them) and keeps only what it needs."""
+        self.b.upload(*split_inputs(h0, omega, self.b.rank, self.b.world))
+
+    def frame(self, time: float):
+        self.b.rows_pass(time, self.domain_size, self.send)
+        if self.dist is not None:
+            with self.b.on_stream():
+                self.dist.all_to_all_single(self.recv, self.send)  # the only collective of the frame
+            recv = self.recv
+        else:
+            recv = self.send                                       # one rank, no group: the send buffer IS the column block
+        self.b.cols_pass(recv, self.out)
+        return self.out
+
+    def result(self) -> np.ndarray:
+        """The rank's column block, transposed: [N/world, N, 4] with [x - x0, y] = (disp_x, height, disp_z, 0)."""
+        return self.b.to_numpy(self.out)
+
+    def gather_tile(self) -> np.ndarray | None:
+        """Whole tile in the natural orientation [y, x, 4] on rank 0 (tests / small N only)."""
+        mine = self.result()
+        if self.b.world == 1:
+            return np.ascontiguousarray(mine.transpose(1, 0, 2))
+        parts = [None] * self.b.world if self.b.rank == 0 else None
+        self.dist.gather_object(mine, parts, dst=0)
+        if self.b.rank != 0:
+            return None
+        return np.ascontiguousarray(np.concatenate(parts, axis=0).transpose(1, 0, 2))

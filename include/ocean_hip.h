@@ -166,6 +166,32 @@ int32_t ocean_profile_frame(OceanContext* ctx, float time, int32_t cap, const ch
 int32_t ocean_profile_staged(OceanContext* ctx, float time, int32_t cap, const char** names, float* ms,
                              int32_t* out_n);
 
+/* ---- one N x N tile sharded over the GPUs of a node ------------------------------------------------
+ * The reference runs one 512 x 512 transform on one GPU; the only ordering it imposes is "all row passes, barrier,
+ * all column passes" (src/render.rs:1158-1231).  For tiles too large or too slow for one GPU (N up to 16384) the same
+ * chain is sharded by ROW BLOCKS: rank r of `world` owns rows [r N/world, (r+1) N/world) of the three spectra,
+ *     ocean_shard_rows:  propagate (shader/propagate.comp:42-72) + row pass (shader/fft_row.comp:44-63) on its rows,
+ *                        written as the send buffer of ONE all-to-all:  send[dest][field][row][column of dest];
+ *     (caller)           all-to-all over xGMI (RCCL: torch.distributed.all_to_all_single, gfx_ocean_amd/sharded.py),
+ *                        3 N^2 8 / world bytes per rank and frame;
+ *     ocean_shard_cols:  recv[src][field][row of src][own column] -> column pass (shader/fft_col.comp:44-63) and
+ *                        correction (shader/correction.comp:24-35) on its N/world columns.
+ * The result is the rank's COLUMN block, transposed: out[(x - rank N/world) * N + y] = (disp_x, height, disp_z, 0).
+ * Fields are ordered dx, dy, dz (OCEAN_FIELD_*), complex fp32.  Reference quirks only.  One OceanShard per GPU. */
+typedef struct OceanShard OceanShard;
+int32_t ocean_shard_create(int32_t device_ordinal, int32_t resolution /* 512 .. 16384 */, int32_t rank, int32_t world,
+                           OceanShard** out);
+void ocean_shard_destroy(OceanShard* shard);
+const char* ocean_shard_last_error(const OceanShard* shard);      /* shard may be NULL: last error of a failed create */
+/* The rank's static inputs (host pointers, rows of N texels): its own rows of h0 and omega, and the rows
+ * [N - (rank+1) N/world, N - rank N/world) of h0 in which the "-k" partners of its texels live (propagate.comp:48). */
+int32_t ocean_shard_upload(OceanShard* shard, const float* h0_own_rows, const float* h0_partner_rows,
+                           const float* omega_own_rows);
+int32_t ocean_shard_rows(OceanShard* shard, const OceanPropagateLocals* locals, void* send_device, void* stream);
+int32_t ocean_shard_cols(OceanShard* shard, const void* recv_device, void* out_rgba_T_device, void* stream);
+int32_t ocean_shard_sync(OceanShard* shard);
+void* ocean_shard_stream(OceanShard* shard);
+
 #ifdef __cplusplus
 }
 #endif

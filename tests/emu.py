@@ -211,3 +211,48 @@ def staged_chunked(fields, do_cols=True):
     out = np.full((n, n, 4), np.nan, np.float32)
     assert L.emu_correct_chunked(n, *map(_p, chunked), _p(out), sx, sy, fs) == 0
     return natural, out
+
+
+class EmuShardBackend:
+    """Backend of gfx_ocean_amd.sharded.ShardedTile that runs the shard kernels on the CPU (numpy buffers wrapped as
+    torch CPU tensors for gloo).  Test infrastructure: the product backend is HipShardBackend."""
+
+    def __init__(self, n, rank, world):
+        import torch
+        self.torch = torch
+        self.n, self.rank, self.world, self.rows = n, rank, world, n // world
+        self.tw = twiddles(n)
+        self.fld = np.zeros((3, self.rows, n), np.complex64)
+        L = lib()
+        L.emu_shard_rows.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 6 + [ctypes.c_float] * 2
+        L.emu_shard_cols.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 4
+
+    def upload(self, h0_own, h0_partner, omega_own):
+        self.h0_own, self.h0_partner, self.omega = h0_own, h0_partner, omega_own
+
+    def alloc_exchange(self):
+        return self.torch.zeros((self.world, 3, self.rows, self.rows, 2), dtype=self.torch.float32)
+
+    def alloc_out(self):
+        return self.torch.zeros((self.rows, self.n, 4), dtype=self.torch.float32)
+
+    def rows_pass(self, time, domain_size, send):
+        buf = send.numpy()
+        assert lib().emu_shard_rows(self.n, self.rank, self.world, _p(self.h0_own), _p(self.h0_partner), _p(self.omega),
+                                    _p(self.fld), _p(buf), _p(self.tw), float(time), float(domain_size)) == 0
+
+    def cols_pass(self, recv, out):
+        assert lib().emu_shard_cols(self.n, self.rank, self.world, _p(recv.numpy()), _p(self.fld), _p(out.numpy()), _p(self.tw)) == 0
+
+    def on_stream(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def synchronize(self):
+        pass
+
+    def to_numpy(self, out):
+        return out.numpy().copy()
+
+    def destroy(self):
+        pass

@@ -116,6 +116,35 @@ template <int N> static int run_stage(int what, c32* nat, c32* chk, const c32* t
     }
 }
 
+// one tile sharded by row blocks (ocean_shard_rows / ocean_shard_cols of csrc/ocean_shard.hip, same kernels, same order)
+template <int N> static int run_shard_rows(int rank, int world, const c32* h0_own, const c32* h0_partner, const float* om,
+                                           c32* fld, c32* send, const c32* tw, float time, float L) {
+    constexpr int E = 16, T = N / E, LPW = (256 / T) > 1 ? (256 / T) : 1;
+    const int rows = N / world;
+    const size_t block = (size_t)rows * N;
+    int cols_log2 = 0;
+    while ((1 << cols_log2) < rows) ++cols_log2;
+    emu_launch((int)((block / 2 + 255) / 256), 256, [&] {
+        k_propagate(h0_own, h0_partner, om, fld + 1 * block, fld + 0 * block, fld + 2 * block, N, rank * rows, rows, time, L, 3u);
+    });
+    for (int f = 0; f < 3; ++f)
+        emu_launch(rows / LPW, T * LPW, [&] { k_shard_rows<N, E, LPW>(fld + f * block, send, tw, f, rows, cols_log2); });
+    return 0;
+}
+template <int N> static int run_shard_cols(int rank, int world, const c32* recv, c32* fld, float4* out, const c32* tw) {
+    constexpr int E = 16, T = N / E, LPW = (256 / T) > 1 ? (256 / T) : 1;
+    const int cols = N / world;
+    const size_t block = (size_t)cols * N;
+    for (int f = 0; f < 3; ++f) {
+        emu_launch((N / 32) * (cols / 32), 256, [&] { k_shard_transpose(recv, fld + f * block, N, f, cols, cols); });
+        emu_launch(cols / LPW, T * LPW, [&] { k_fft_lines<N, E, LPW, false>(fld + f * block, tw); });
+    }
+    emu_launch((int)((block / 2 + 255) / 256), 256, [&] {
+        k_correct(fld + 1 * block, fld + 0 * block, fld + 2 * block, out, N, rank * cols, cols);
+    });
+    return 0;
+}
+
 #define DISPATCH(n, CALL)                 \
     switch (n) {                          \
         case 256: return CALL(256);       \
@@ -174,6 +203,17 @@ int emu_correct_chunked(int n, const float* h, const float* dx, const float* dz,
     emu_launch(n / 4, 256, [&] { k_correct_chunked((const c32*)h, (const c32*)dx, (const c32*)dz, (float4*)out, n, InterLayout{sx, sy, fs}); });
     return 0;
 }
+int emu_shard_rows(int n, int rank, int world, const float* h0_own, const float* h0_partner, const float* om, float* fld,
+                   float* send, const float* tw, float time, float L) {
+#define C_(N) run_shard_rows<N>(rank, world, (const c32*)h0_own, (const c32*)h0_partner, om, (c32*)fld, (c32*)send, (const c32*)tw, time, L)
+    DISPATCH(n, C_)
+#undef C_
+}
+int emu_shard_cols(int n, int rank, int world, const float* recv, float* fld, float* out, const float* tw) {
+#define C_(N) run_shard_cols<N>(rank, world, (const c32*)recv, (c32*)fld, (float4*)out, (const c32*)tw)
+    DISPATCH(n, C_)
+#undef C_
+}
 int emu_positions(int n, const float* rgba, float* positions, int verts, float ox, float oz) {
     const int grid = (verts * verts + 255) / 256;
     emu_launch(grid, 256, [&] { k_positions((const float4*)rgba, (float4*)positions, n, verts, ox, oz); });
@@ -186,12 +226,12 @@ int emu_normals(int n, const float* rgba, float* normals, int channel) {
 }
 int emu_propagate(int n, const float* h0, const float* omega, float* h, float* dx, float* dz, float time, float L, unsigned quirks) {
     const int grid = (n * n / 2 + 255) / 256;
-    emu_launch(grid, 256, [&] { k_propagate((const c32*)h0, omega, (c32*)h, (c32*)dx, (c32*)dz, n, time, L, quirks); });
+    emu_launch(grid, 256, [&] { k_propagate((const c32*)h0, (const c32*)h0, omega, (c32*)h, (c32*)dx, (c32*)dz, n, 0, n, time, L, quirks); });
     return 0;
 }
 int emu_correct(int n, const float* h, const float* dx, const float* dz, float* out) {
     const int grid = (n * n / 2 + 255) / 256;
-    emu_launch(grid, 256, [&] { k_correct((const c32*)h, (const c32*)dx, (const c32*)dz, (float4*)out, n); });
+    emu_launch(grid, 256, [&] { k_correct((const c32*)h, (const c32*)dx, (const c32*)dz, (float4*)out, n, 0, n); });
     return 0;
 }
 }

@@ -1,0 +1,128 @@
+"""One N x N tile sharded by row blocks over several ranks (gfx_ocean_amd/sharded.py, csrc/ocean_shard.hip):
+propagate + row pass on the rank's rows, ONE all-to-all, column pass + correction on the rank's columns.
+
+CPU tier: the shard kernels run in the host emulation, the all-to-all is gloo with world size 2 (and 4), and the
+assembled tile must match the fp64 oracle of the whole frame -- i.e. the decomposition, the send/receive layouts and
+the partner-block indexing of propagate are right.  GPU tier: the same through the C ABI on one GPU (world = 1 and,
+with OCEAN_BENCH_FORCE_DIST-style single-rank RCCL, the collective call itself)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import gfx_ocean_amd as g
+from gfx_ocean_amd import sharded
+from oracle import ocean_oracle as oc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_WORKER = r"""
+import json, os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, torch, torch.distributed as dist
+import emu, gfx_ocean_amd as g
+from gfx_ocean_amd import sharded
+from oracle import ocean_oracle as oc
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group(backend="gloo")
+n, t = int(sys.argv[2]), 1.5
+h0, om = g.synth.make_inputs(n, seed=77)            # every rank builds the same tile and keeps its slices
+tile = sharded.ShardedTile(emu.EmuShardBackend(n, rank, world), dist)
+tile.upload(h0, om)
+tile.frame(t)
+full = tile.gather_tile()
+if rank == 0:
+    ref = oc.frame_f64(h0, om, t)
+    nmax, rl2 = oc.parity_errors(full[..., :3], ref[..., :3])
+    print("RESULT " + json.dumps({"nmax": float(nmax.max()), "rl2": float(rl2.max()), "alpha0": bool(np.all(full[..., 3] == 0)),
+                                  "bytes": sharded.exchange_bytes_per_rank(n, world)}))
+dist.destroy_process_group()
+"""
+
+
+def test_split_inputs_partner_block_is_the_mirror():
+    n, world = 64, 4
+    h0 = (np.arange(n * n).reshape(n, n) * (1 + 0.5j)).astype(np.complex64)
+    om = np.arange(n * n, dtype=np.float32).reshape(n, n)
+    for r in range(world):
+        own, partner, o = sharded.split_inputs(h0, om, r, world)
+        rows = n // world
+        assert np.array_equal(own, h0[r * rows:(r + 1) * rows]) and np.array_equal(o, om[r * rows:(r + 1) * rows])
+        # texel (ly, x) of the block pairs with (N-1-gy, N-1-x) = the partner block read backwards (propagate.comp:48)
+        gy = r * rows + 3
+        assert partner[::-1, ::-1][3, 5] == h0[n - 1 - gy, n - 1 - 5]
+    assert sharded.exchange_bytes_per_rank(16384, 8) == 3 * 2048 * 16384 * 8
+
+
+@pytest.mark.parametrize("world,n", [(2, 512), (4, 512)])
+def test_sharded_tile_matches_the_whole_frame_oracle(tmp_path, world, n):
+    worker = tmp_path / "worker.py"
+    worker.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(29540 + world), str(worker), ROOT, str(n)],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
+    assert r["nmax"] <= 1e-4 and r["rl2"] <= 1e-4 and r["alpha0"], r       # north_star tolerance; expect ~1e-6
+    assert r["nmax"] < 1e-5
+    assert r["bytes"] == 3 * (n // world) * n * 8
+
+
+def test_single_rank_shard_is_the_whole_tile():
+    """world = 1 degenerates to rows pass + column pass on one rank, no collective."""
+    import emu
+    n, t = 512, 0.75
+    h0, om = g.synth.make_inputs(n, seed=5)
+    tile = sharded.ShardedTile(emu.EmuShardBackend(n, 0, 1))
+    tile.upload(h0, om)
+    tile.frame(t)
+    nmax, rl2 = oc.parity_errors(tile.gather_tile()[..., :3], oc.frame_f64(h0, om, t)[..., :3])
+    assert nmax.max() < 1e-5 and rl2.max() < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [512, 4096])
+def test_gpu_shard_abi_world1_matches_the_fused_frame(n):
+    """The C ABI of the sharded tile on one GPU: same tile as ocean_frame, transposed."""
+    h0, om = g.synth.make_inputs(n, seed=9)
+    tile = sharded.ShardedTile(sharded.HipShardBackend(n, 0, 1))
+    dev = g.OceanDevice(n)
+    try:
+        tile.upload(h0, om)
+        tile.frame(2.25)
+        got = tile.gather_tile()
+        dev.upload_spectrum(h0, om)
+        dev.frame(2.25)
+        want = dev.read_displacement()
+        nmax, rl2 = oc.parity_errors(got[..., :3], want[..., :3])
+        assert nmax.max() < 2e-5 and rl2.max() < 2e-5 and np.all(got[..., 3] == 0.0)
+    finally:
+        dev.destroy()
+        tile.b.destroy()
+
+
+@pytest.mark.gpu
+def test_gpu_shard_16384_sampled_texels():
+    """N = 16384 (a size only the sharded path supports: one 16384-point line is a whole workgroup): sampled texels
+    against a direct fp64 evaluation of the 2-D sum, on one GPU with world = 1."""
+    n, t = 16384, 1.0
+    h0, om = g.synth.make_inputs(n, seed=3)
+    tile = sharded.ShardedTile(sharded.HipShardBackend(n, 0, 1))
+    try:
+        tile.upload(h0, om)
+        tile.frame(t)
+        out = tile.result()                                     # [x, y, 4]
+        H, DX, DZ = oc.propagate_f64(h0, om, t)
+        k = np.arange(n)
+        scale = np.abs(out[..., :3]).max((0, 1))
+        for (x, y) in [(0, 0), (n // 2 + 3, n // 3), (n - 1, n - 1)]:
+            ey, ex = np.exp(2j * np.pi * k * y / n), np.exp(2j * np.pi * k * x / n)
+            sgn = -1.0 if (x + y) % 2 == 0 else 1.0
+            ref = np.array([(ey @ (F @ ex)).real for F in (DX, H, DZ)]) * sgn
+            assert np.all(np.abs(out[x, y, :3] - ref) <= 1e-4 * scale), (x, y, out[x, y, :3], ref)
+    finally:
+        tile.b.destroy()
