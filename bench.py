@@ -332,6 +332,7 @@ def main():
     ap.add_argument("--gather-steps", type=int, default=30)
     ap.add_argument("--gather-timeout", type=float, default=120.0, help="seconds before a stuck gather leg is abandoned")
     ap.add_argument("--profile-frames", type=int, default=20, help="frames averaged for the per-kernel durations")
+    ap.add_argument("--ramp-frames", type=int, default=100, help="untimed frames before anything is measured (GPU clock ramp)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launch: seconds before the ranks are killed")
     ap.add_argument("--plumbing", action="store_true",
                     help="tests only: launcher + rendezvous + reductions + gather bookkeeping on gloo/CPU, no device work")
@@ -405,10 +406,11 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
-    # per-kernel durations, live, HIP events bound to the dispatches on the stream the kernels run on.  Untimed, and
-    # run BEFORE the timed region on purpose: a cold GPU needs tens of milliseconds of work to reach its running
-    # clocks (measured on MI355X: the first ~25 frames of a run are ~10 % slower), and with the default W = 5 the
-    # timed K = 20 steps would otherwise be measured on the ramp.
+    # A cold GPU needs tens of milliseconds of work to reach its running clocks (measured on MI355X: the first ~25
+    # frames of a run are ~10 % slower, and with W = 5 the timed K = 20 steps would be measured on the ramp).  So,
+    # untimed and BEFORE the timed region: `--ramp-frames` frames, then the per-kernel durations (live, HIP events
+    # bound to the dispatches on the stream the kernels run on), then the W warmup steps.
+    dev.time_frames(args.ramp_frames, t0=0.0, dt=1.0 / 60.0)        # clock ramp, untimed (see above)
     acc = {}
     for i in range(args.profile_frames):
         for name, ms in dev.profile_frame(i / 60.0):
@@ -469,7 +471,8 @@ def main():
                        "n": n, "spectrum": args.spectrum, "tiles": n_gpus,
                        "parallelism": f"tile-parallel x{n_gpus}, no data-path collective",
                        "gpu_event_ms_per_step": frame_ms,
-                       "untimed_before_timed_region": f"{3 * args.profile_frames} frames of per-kernel profiling + {args.warmup} warmup"},
+                       "untimed_before_timed_region": f"{args.ramp_frames} clock-ramp frames + {3 * args.profile_frames} frames of "
+                                                      f"per-kernel profiling + {args.warmup} warmup"},
             "roofline": roofline,
         }
 

@@ -1,6 +1,9 @@
 #!/bin/bash
-# Evidence run for profiles/: GPU tests, smoke, bench (with cpu baseline), rocprof kernel stats, HBM counters.
+# Evidence run for profiles/: GPU tests, smoke, sweep, bench lines (fp32 N = 4096; config 5: fp16 spectrum N = 8192),
+# rocprofv3 kernel stats of the same bench commands, HBM counters (FETCH_SIZE / WRITE_SIZE in separate passes) for the
+# fused frame and for the staged 8-dispatch path.   tools/gpu_evidence.sh <tag>
 set -u
+exec < /dev/null
 TAG=${1:-ev}; O=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $O
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
@@ -11,14 +14,23 @@ import json
 for l in open("$O/sweep.jsonl"):
     try: r=json.loads(l)
     except Exception: print(l.strip()); continue
-    print(r["n"], "fused %.4f ms  %.0f fps  %.0f GB/s alg |"%(r["fused_ms"], r["fused_fps"], r["frame_GBps_alg"]), {k: round(v,4) for k,v in r["fused"].items()}, "| staged %.4f ms"%r["staged_ms_total"])
+    print(r["n"], "fused %.4f ms  %.0f fps |"%(r["fused_ms"], r["fused_fps"]), {k: round(v*1000,1) for k,v in r["fused"].items()}, "| staged %.4f ms"%r["staged_ms_total"])
 PY
-echo "== bench"; timeout 900 python bench.py 2>&1 | tee $O/bench.json | cut -c1-400
+echo "== bench (driver flags)"; timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 2>$O/bench.err | tee $O/bench.json | cut -c1-300
+echo "== bench config 5"; timeout 900 python bench.py --n 8192 --spectrum f16 --steps 20 --warmup 5 2>$O/bench_f16.err | tee $O/bench_n8192_f16.json | cut -c1-300
 cd /tmp
-echo "== rocprof kernel stats (same command as bench, no cpu baseline)"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $O/rocprof_stats_stdout.txt 2>&1
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o run -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 10 --warmup 2 --profile-frames 2 > $O/pmc_${c}_stdout.txt 2>&1
-done
+run_prof() {   # name, then the command
+  local name=$1; shift
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$name/stats -o run -- "$@" > $O/$name.stats_stdout.txt 2>&1
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/$name/pmc_$c -o run -- "$@" > $O/$name.pmc_${c}_stdout.txt 2>&1
+  done
+  python $GRAFT_REPO_ROOT/tools/rocprof_summary.py $O/$name > $O/$name.summary.txt 2>&1
+  echo "== $name"; grep -v "^$" $O/$name.summary.txt | cut -c1-160 | head -24
+}
+run_prof fused_n4096 python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 20 --warmup 5 --profile-frames 5
+run_prof fused_n8192_f16 python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --n 8192 --spectrum f16 --steps 10 --warmup 2 --profile-frames 2
+run_prof staged_n4096 python $GRAFT_REPO_ROOT/tools/staged_frames.py 4096 10
 cd $GRAFT_REPO_ROOT
-python tools/rocprof_summary.py $O > $O/summary.txt 2>&1; cat $O/summary.txt | head -40
+# keep the pulled directory small: the csv traces are summarised above
+find $O -name "*.csv" -size +2M -delete
