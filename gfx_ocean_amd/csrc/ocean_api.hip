@@ -424,7 +424,11 @@ int32_t ocean_context_create(int32_t device, int32_t resolution, OceanContext** 
         // Chunks are 4 x 4 complex (128 B); chunk (X, Y) at X*sx + Y*sy, +32 elements
         // (256 B) of padding per slab so that the strided side of the hand-off does not revisit one channel.
         // Pass-2-contiguous: the chunks of one chunk row are adjacent.
+#ifdef OCEAN_LAYOUT_P1   // A/B knob: pass-1-contiguous (a pass-1 workgroup writes one contiguous span per field)
+        bool p1 = true;
+#else
         bool p1 = false;
+#endif
         // lines per pass-1 workgroup of the half-spectrum path: measured best per size (run 14): two
         // co-resident 2-line workgroups win where the intermediate is cache-resident (512, 2048) and
         // are the only option at 8192; one 4-line workgroup wins at 4096 (whole-chunk non-temporal stores).

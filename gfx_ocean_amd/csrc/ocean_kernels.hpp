@@ -693,12 +693,21 @@ __device__ __forceinline__ void half_load_AB(const void* __restrict__ h0T_, floa
             const int y0 = S * jj + par;
             const int y2 = (N - y0) & (N - 1);
             const int ym = (y0 - 1) & (N - 1);
+#ifdef OCEAN_X_NODUP   // timing experiment only (wrong results): the two streams that re-read lines another wave of the
+                       // workgroup loads (own2 of column c+1 = mirror of c, mirror2 of c+1 = own of c) are not loaded
+            (void)ym; a2 = m; m2 = a;
+#else
             a2 = Spec<H16>::load(h0T + (size_t)x2 * N + y2, descale);
             m2 = Spec<H16>::load(h0T + (size_t)xm * N + ym, descale);
+#endif
             w2 = OCEAN_OMEGA_LOAD((omegaT + (size_t)x2 * N) + y2);
         } else {
+#ifdef OCEAN_X_NODUP
+            a2 = m; m2 = a;
+#else
             a2 = Spec<H16>::load((own2 + (N - S * (e + 1) * T)) + S * (T - jj), descale);   // own2[N - y]
             m2 = Spec<H16>::load((mir2 + (S * e * T - 1)) + S * jj, descale);               // mir2[y - 1]
+#endif
             w2 = OCEAN_OMEGA_LOAD((om2 + (N - S * (e + 1) * T)) + S * (T - jj));
         }
         A[e] = propagate_height(a, m, w, time);
