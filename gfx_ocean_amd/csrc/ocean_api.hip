@@ -170,6 +170,8 @@ template <int N> struct Launch {
     // co-resident workgroups pay (512, 2048) and where 4 lines do not fit (8192), else 4.
 #ifdef OCEAN_FORCE_P                                                   // A/B knob (tools/ab_variants.sh)
     static constexpr int default_psel() { return OCEAN_FORCE_P; }
+#elif defined(OCEAN_P_SMALL)                                           // A/B knob: lines per pass-1 workgroup at N <= 1024
+    static constexpr int default_psel() { return (N <= 1024) ? OCEAN_P_SMALL : ((N == 2048 || N > 4096 || CHUNK_W < 4) ? 2 : 4); }
 #else
     static constexpr int default_psel() { return (N == 512 || N == 2048 || N > 4096 || CHUNK_W < 4) ? 2 : 4; }
 #endif

@@ -1298,14 +1298,21 @@ k_shard_transpose(const c32* __restrict__ recv, c32* __restrict__ out, int n, in
 // ---------------------------------------------------------------------------------------------
 template <int N, int PSEL = 0> struct Geo {
     static constexpr int E = 16;                                   // elements per thread
-#ifdef OCEAN_E1                                                        // A/B knob: elements per thread in fused pass 1 (N >= 4096)
+    // Elements per thread of fused pass 1.  At N <= 1024 a frame is launch- and latency-bound (a 512-point line with 16
+    // elements per thread is half a wave): 8 elements per thread double the waves that share a workgroup's serial chain
+    // of load batches and transforms (run r02_run12: N = 512 51.0k -> 67.1k frames/s, 256 63k -> 77k, 1024 38.9k -> 41.3k;
+    // 2048 unchanged).  A/B knobs: OCEAN_E1 (large N: 32 and 64 measured slower), OCEAN_E1_SMALL.
+#ifdef OCEAN_E1
 #ifndef OCEAN_E1_MIN_N
 #define OCEAN_E1_MIN_N 4096
 #endif
     static constexpr int E1 = (N >= OCEAN_E1_MIN_N) ? OCEAN_E1 : 16;
     static constexpr int E1S = (N / 2 >= OCEAN_E1_MIN_N) ? OCEAN_E1 : 16;    // split kernels: lines of N / 2 points
+#elif defined(OCEAN_E1_SMALL)
+    static constexpr int E1 = (N <= OCEAN_E1_SMALL_MAX_N) ? OCEAN_E1_SMALL : 16;
+    static constexpr int E1S = 16;
 #else
-    static constexpr int E1 = 16;
+    static constexpr int E1 = (N <= 1024) ? 8 : 16;
     static constexpr int E1S = 16;
 #endif
     static constexpr int T = N / E;                                // threads per line
@@ -1327,10 +1334,15 @@ template <int N, int PSEL = 0> struct Geo {
     static constexpr int row_grid = N / ROW_LPW;
     static constexpr int col_grid = N / COL_LPW;
     static constexpr int frame_grid = N / P;
-#ifdef OCEAN_R2                                                        // A/B knob: rows per pass-2 workgroup (>= 256 threads)
+    // Rows per workgroup of fused pass 2: 256 threads' worth at N >= 2048; at most two at the launch-bound sizes, where
+    // 8 or 16 rows per workgroup leave most CUs without one (N = 512: 64 workgroups; run r02_run13: 67.0k -> 72-73k
+    // frames/s at 512, 76.8k -> 80-85k at 256).  A/B knobs: OCEAN_R2 (more rows at N >= 4096: slower), OCEAN_R2_SMALL.
+#ifdef OCEAN_R2
     static constexpr int R2 = (OCEAN_R2 > ROW_LPW && T * OCEAN_R2 <= 1024) ? OCEAN_R2 : ROW_LPW;
+#elif defined(OCEAN_R2_SMALL)
+    static constexpr int R2 = (ROW_LPW > OCEAN_R2_SMALL) ? OCEAN_R2_SMALL : ROW_LPW;
 #else
-    static constexpr int R2 = ROW_LPW;                             // rows per workgroup, thin pass 2
+    static constexpr int R2 = (N <= 1024 && ROW_LPW > 2) ? 2 : ROW_LPW;
 #endif
     static constexpr int thin_threads = T * R2;
     static constexpr int thin_lds = R2 * Pitch2<N, R2>::elems * (int)sizeof(c32);
