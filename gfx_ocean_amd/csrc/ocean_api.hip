@@ -67,8 +67,8 @@ struct OceanContext {
     int scale_log2 = 0;
     float* omegaT = nullptr;
     c32* inter = nullptr;
-    InterLayout lay{0, 0, 0};     // three complex fields, all N columns        (OCEAN_ALGO=c2c)
-    InterLayout lay_h{0, 0, 0};   // three complex fields, columns 0..N/2-1     (half-spectrum path)
+    InterLayout lay{0, 0, 0, 0};     // three complex fields, all N columns, B = 1   (staged hand-off; OCEAN_ALGO=c2c)
+    InterLayout lay_h{0, 0, 0, 0};   // three complex fields, columns 0..N/2-1       (half-spectrum path)
     c32* nyq = nullptr;           // scratch of the half-spectrum path: the Nyquist column's 3 spectra, 3 x N complex
     bool half = true;             // OCEAN_ALGO=c2c selects the three-complex-transform frame (A/B)
     bool split = false;           // lines as two interleaved N/2 transforms (N = 8192; OCEAN_SPLIT=0/1 for A/B)
@@ -195,7 +195,7 @@ template <int N> struct Launch {
             e = hipFuncSetAttribute((const void*)k_half_pass1<N, H::E1, H::P, true>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, H::frame_lds);
             if (e != hipSuccess) return e;
-            e = hipFuncSetAttribute((const void*)k_half_pass2<N, H::E, CHUNK_W, H::R2>,
+            e = hipFuncSetAttribute((const void*)k_half_pass2<N, H::E, CHUNK_W, H::R2, H::p2_group>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, H::thin_lds);
             if (e != hipSuccess) return e;
         }
@@ -206,7 +206,7 @@ template <int N> struct Launch {
             e = hipFuncSetAttribute((const void*)k_half_pass1_split<N, H::E1S, H::P, true>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, H::split_lds1);
             if (e != hipSuccess) return e;
-            e = hipFuncSetAttribute((const void*)k_half_pass2_split<N, H::E, CHUNK_W>,
+            e = hipFuncSetAttribute((const void*)k_half_pass2_split<N, H::E, CHUNK_W, H::p2_group>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, H::split_lds2);
         }
         return e;
@@ -242,13 +242,13 @@ template <int N> struct Launch {
         using H = Geo<N, PSEL>;
         if constexpr (split_built<PSEL>()) {
             if (c->split) {
-                launch(k_half_pass2_split<N, H::E, CHUNK_W>, dim3(N), dim3(H::split_threads2), H::split_lds2, s, t,
+                launch(k_half_pass2_split<N, H::E, CHUNK_W, H::p2_group>, dim3(N), dim3(H::split_threads2), H::split_lds2, s, t,
                        (const c32*)c->inter, c->out, (const c32*)c->tw, c->lay_h);
                 return;
             }
         }
         if constexpr (plain_built<PSEL>())
-            launch(k_half_pass2<N, H::E, CHUNK_W, H::R2>, dim3(H::thin_grid), dim3(H::thin_threads), H::thin_lds, s, t,
+            launch(k_half_pass2<N, H::E, CHUNK_W, H::R2, H::p2_group>, dim3(H::thin_grid), dim3(H::thin_threads), H::thin_lds, s, t,
                    (const c32*)c->inter, c->out, (const c32*)c->tw, c->lay_h);
     }
     static void stage_rows(OceanContext* c, int f, hipStream_t s) {
@@ -426,11 +426,8 @@ int32_t ocean_context_create(int32_t device, int32_t resolution, OceanContext** 
         // Chunks are 4 x 4 complex (128 B); chunk (X, Y) at X*sx + Y*sy, +32 elements
         // (256 B) of padding per slab so that the strided side of the hand-off does not revisit one channel.
         // Pass-2-contiguous: the chunks of one chunk row are adjacent.
-#ifdef OCEAN_LAYOUT_P1   // A/B knob: pass-1-contiguous (a pass-1 workgroup writes one contiguous span per field)
-        bool p1 = true;
-#else
-        bool p1 = false;
-#endif
+        int bshift = 0, padx = 0;                  // blocks of 2^bshift chunk rows (Geo::inter_bshift: 0 = pass-2-contiguous)
+        OCEAN_DISPATCH(resolution, { bshift = L::G::inter_bshift; padx = L::G::inter_padx; });
         // lines per pass-1 workgroup of the half-spectrum path: measured best per size (run 14): two
         // co-resident 2-line workgroups win where the intermediate is cache-resident (512, 2048) and
         // are the only option at 8192; one 4-line workgroup wins at 4096 (whole-chunk non-temporal stores).
@@ -439,21 +436,27 @@ int32_t ocean_context_create(int32_t device, int32_t resolution, OceanContext** 
         // A/B builds (tools/ab_variants.sh) read their variant from the environment; the shipped library has no
         // environment-dependent behaviour.
         if (const char* v = std::getenv("OCEAN_PASS2")) c->pass2_thin = (std::strcmp(v, "fat") != 0);
-        if (const char* v = std::getenv("OCEAN_INTER_LAYOUT")) p1 = std::strcmp(v, "p1") == 0;   // pass-1-contiguous
+        if (const char* v = std::getenv("OCEAN_INTER_LAYOUT")) { if (std::strcmp(v, "p1") == 0) { bshift = 30; padx = 32; } }   // pass-1-contiguous
         if (const char* pe = std::getenv("OCEAN_P")) { const int pv = std::atoi(pe); if (pv == 2 || (pv == 4 && resolution <= 4096)) c->Ph = pv; }
         if (const char* a = std::getenv("OCEAN_ALGO")) c->half = (std::strcmp(a, "c2c") != 0);
         // N = 8192 = 2 * 16^3 has no three-pass plan: its lines run as two interleaved 4096-point transforms
         if (const char* sp = std::getenv("OCEAN_SPLIT")) c->split = (std::atoi(sp) != 0) && c->Ph == 2 && resolution >= 512;
 #endif
-        auto make = [&](size_t columns) {
-            InterLayout l{0, 0, 0};
+        // chunk (X, Y) at (Y / B) * sy + X * sx + (Y % B) * 16, B = 2^bshift (ocean_kernels.hpp InterLayout); +32
+        // elements (256 B) per block slab and `padx` per chunk column so that the strided side of the hand-off does not
+        // revisit one channel
+        auto make = [&](size_t columns, int bs, int px) {
             const size_t gx = columns / CHUNK_W, gy = (size_t)resolution / CHUNK_R;
-            if (p1) { l.sy = 16; l.sx = gy * 16 + 32; l.fs = l.sx * gx; }
-            else { l.sx = 16; l.sy = gx * 16 + 32; l.fs = l.sy * gy; }
+            while (((size_t)1 << bs) > gy) --bs;
+            const size_t B = (size_t)1 << bs;
+            InterLayout l{0, 0, 0, bs};
+            l.sx = B * 16 + (size_t)px;
+            l.sy = gx * l.sx + 32;
+            l.fs = l.sy * (gy / B);
             return l;
         };
-        c->lay = make((size_t)resolution);
-        c->lay_h = make((size_t)resolution / 2);
+        c->lay = make((size_t)resolution, 0, 0);                // staged hand-off and (A/B builds) the three-complex-transform frame
+        c->lay_h = make((size_t)resolution / 2, bshift, padx);  // the fused frame's half-spectrum intermediate
     }
     auto bail = [&](hipError_t err, const char* what) {
         const int32_t code = hip_fail(nullptr, err, what);

@@ -240,7 +240,15 @@ k_fft_lines(c32* __restrict__ data, const c32* __restrict__ tw) {
 // 128-byte chunks with a 128 KiB stride (measured 25 us/frame faster at N = 4096 than the
 // opposite choice; both are selectable at context creation for A/B runs).
 // Field order in the intermediate: 0 = disp_x, 1 = height, 2 = disp_z (OCEAN_FIELD_*).
-struct InterLayout { size_t sx, sy, fs; };
+struct InterLayout { size_t sx, sy, fs; int bshift; };
+// Rows of chunks are grouped in blocks of B = 2^bshift: chunk (X, Y) sits at
+//     field * fs + (Y / B) * sy + X * sx + (Y % B) * 16        (elements; 16 = one 128-byte chunk).
+// B = 1 is pass-2-contiguous (the chunks of one chunk row adjacent, sx = 16); B = N / 4 is pass-1-contiguous (all the
+// chunks of one chunk column adjacent); in between a pass-1 workgroup writes B * 128 contiguous bytes and a pass-2
+// workgroup finds its row's lines B * 128 bytes apart.  The staged hand-off and the A/B c2c kernels always use B = 1.
+__device__ __forceinline__ size_t chunk_row_offset(const InterLayout& lay, int Y) {
+    return (size_t)(Y >> lay.bshift) * lay.sy + (size_t)(Y & ((1 << lay.bshift) - 1)) * (size_t)16;   // one chunk = 16 elements
+}
 // A chunk is 4 columns x 4 rows of complex = 128 bytes.  A pass-1 workgroup owns P = 4 lines (whole
 // chunks, non-temporal stores) or P = 2 lines (the left or right 16 bytes of every chunk row; its
 // neighbour, dispatched in the adjacent slot of the same XCD, writes the other half and the XCD L2
@@ -827,7 +835,9 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
         fft_line_to_lds<N, E>(reg, jf, tw, lds_line);
 #endif
         OCEAN_TL(2 + 2 * f);
-        c32* dst = inter + (size_t)f * lay.fs + (size_t)((X * P) / CW) * lay.sx + (size_t)(i / CR) * lay.sy + (i % CR) * CW +
+        // chunk row Y = i / CR + q * (2T / CR): the thread's part and the (wave-uniform, scalar) part of the address add
+        // up because 2T / CR is a power of two > i / CR (no carry between them in chunk_row_offset)
+        c32* dst = inter + (size_t)f * lay.fs + (size_t)((X * P) / CW) * lay.sx + chunk_row_offset(lay, i / CR) + (i % CR) * CW +
                    ((X * P) % CW) + 2 * h;
 #pragma unroll
         for (int q0 = 0; q0 < E / 2; ++q0) {
@@ -843,7 +853,7 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
             const int y = i + q * (2 * T);
             const c32 v0 = l0[lds_pad(y)];
             const c32 v1 = l1[lds_pad(y)];
-            float4* o = reinterpret_cast<float4*>(dst + (size_t)q * ((2 * T) / CR) * lay.sy);
+            float4* o = reinterpret_cast<float4*>(dst + chunk_row_offset(lay, q * ((2 * T) / CR)));
             if constexpr (P == CW) store_float4_nt(o, make_float4(v0.x, v0.y, v1.x, v1.y));
             else *o = make_float4(v0.x, v0.y, v1.x, v1.y);        // half a chunk row: must meet its other half in L2
         }
@@ -978,8 +988,8 @@ k_half_pass1_split(const void* __restrict__ h0T, float descale, const float* __r
         fft_line_to_lds<M, E, 2>(reg, jf, tw, lds_line);           // tw holds e^{2 pi i k / N}: stride 2 for length N/2
         OCEAN_TL(2 + 2 * f);
         const int tf = opaque_lane(tid);
-        c32* dst = inter + (size_t)f * lay.fs + (size_t)((X * P) / CW) * lay.sx + (size_t)(tf / CR) * lay.sy + (tf % CR) * CW +
-                   ((X * P) % CW);
+        c32* dst = inter + (size_t)f * lay.fs + (size_t)((X * P) / CW) * lay.sx + chunk_row_offset(lay, tf / CR) + (tf % CR) * CW +
+                   ((X * P) % CW);                                  // + the wave-uniform part of the chunk row below (see k_half_pass1)
 #pragma unroll
         for (int q0 = 0; q0 < M / THREADS; ++q0) {
 #ifdef OCEAN_ROTQ
@@ -994,8 +1004,8 @@ k_half_pass1_split(const void* __restrict__ h0T, float descale, const float* __r
             const c32 t0 = cmul_r(o0[pk], w, wr), t1 = cmul_r(o1[pk], w, wr);
             const c32 u0 = e0[pk], u1 = e1[pk];
             const c32 lo0 = u0 + t0, hi0 = u0 - t0, lo1 = u1 + t1, hi1 = u1 - t1;
-            float4* olo = reinterpret_cast<float4*>(dst + (size_t)q * (THREADS / CR) * lay.sy);
-            float4* ohi = reinterpret_cast<float4*>(dst + (size_t)(q * (THREADS / CR) + M / CR) * lay.sy);
+            float4* olo = reinterpret_cast<float4*>(dst + chunk_row_offset(lay, q * (THREADS / CR)));
+            float4* ohi = reinterpret_cast<float4*>(dst + chunk_row_offset(lay, q * (THREADS / CR) + M / CR));
             if constexpr (P == CW) {                               // whole chunk rows (2-column chunks): streamed
                 store_float4_nt(olo, make_float4(lo0.x, lo0.y, lo1.x, lo1.y));
                 store_float4_nt(ohi, make_float4(hi0.x, hi0.y, hi1.x, hi1.y));
@@ -1021,7 +1031,9 @@ template <int N, int R2> struct Pitch2 { static constexpr int elems = LdsLine<N>
 //   FFT     (ll, j):  a wave stays inside one row; thread j holds x[j + e T].
 // The two meet in LDS, where the full row is rebuilt from the half spectrum anyway.
 // __launch_bounds__(.., 4 waves/SIMD): 1024 threads per CU (LDS: 4 x 35 KiB or 2 x 70 KiB), i.e. at most 128 VGPRs.
-template <int N, int E, int P1, int R2>
+// GRP: this many consecutive chunk rows run in adjacent dispatch slots of one XCD (with the pass-1-contiguous layout the
+// chunks (X, Y), (X, Y + 1), ... are adjacent in memory: the workgroups that read one DRAM page run together).
+template <int N, int E, int P1, int R2, int GRP = 1>
 __global__ void __launch_bounds__((N / E) * R2, 4)
 k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32* __restrict__ tw, InterLayout lay) {
     constexpr int T = N / E;
@@ -1036,7 +1048,7 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
     constexpr int LP = Pitch2<N, R2>::elems;
     static_assert(P1 == CHUNK_W, "pass 2 reads whole chunk rows");
     static_assert(CR % R2 == 0 || R2 % CR == 0, "the rows of a workgroup tile chunk rows");
-    constexpr int S = (CR > R2) ? (CR / R2) : 1;
+    constexpr int S = ((CR > R2) ? (CR / R2) : 1) * GRP;           // workgroups per XCD group: sharers of a chunk row x GRP
     int rb = blockIdx.x;
     if (S > 1 && (gridDim.x % (8 * S)) == 0) {
         const int xcd = rb & 7, slot = rb >> 3;
@@ -1060,7 +1072,7 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
     for (int pass = 0; pass < 2; ++pass) {                         // 0: height, 1: (disp_x, disp_z)
         const int jf = opaque_lane(j);
         const int lk = (R2 == 1) ? jf : opaque_lane(lk0);
-        const size_t off = (size_t)(ly / CR) * lay.sy + (size_t)(lk / P1) * lay.sx + (ly % CR) * P1 + (lk % P1);
+        const size_t off = chunk_row_offset(lay, ly / CR) + (size_t)(lk / P1) * lay.sx + (ly % CR) * P1 + (lk % P1);
         c32 a[EH], b[EH];
         if (pass == 0) {
             const c32* src = inter + (size_t)1 * lay.fs + off;
@@ -1130,7 +1142,7 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
 // Pass 2 for the split geometry (N = 8192): the row is rebuilt in LDS as two interleaved half-length lines
 // (C[2m] and C[2m+1]), each transformed by N/(2E) threads in three passes, and the final radix-2 step is done by
 // the thread that owns outputs n and n + N/2 in the epilogue (see k_half_pass1_split).  One row per workgroup.
-template <int N, int E, int P1>
+template <int N, int E, int P1, int GRP = 1>
 __global__ void __launch_bounds__(N / E, ((N / E) >= 512) ? 2 : 1)
 k_half_pass2_split(const c32* __restrict__ inter, float4* __restrict__ out, const c32* __restrict__ tw, InterLayout lay) {
     constexpr int M = N / 2;
@@ -1144,7 +1156,7 @@ k_half_pass2_split(const c32* __restrict__ inter, float4* __restrict__ out, cons
     const int tid = threadIdx.x;
     const int par = (TS >= 64) ? wave_uniform(tid / TS) : (tid / TS);   // the sub-line this thread transforms
     const int j = tid % TS;
-    constexpr int S = CR;                                          // workgroups sharing a chunk line: same XCD
+    constexpr int S = CR * GRP;                                    // workgroups sharing a chunk line (x GRP chunk rows): same XCD
     int rb = blockIdx.x;
     if ((gridDim.x % (8 * S)) == 0) {
         const int xcd = rb & 7, slot = rb >> 3;
@@ -1160,7 +1172,7 @@ k_half_pass2_split(const c32* __restrict__ inter, float4* __restrict__ out, cons
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {                         // 0: height, 1: (disp_x, disp_z)
         const int tf = opaque_lane(tid);                           // loads: kx = tf + e*T, e < E/2
-        const size_t off = (size_t)(y / CR) * lay.sy + (size_t)(tf / P1) * lay.sx + (y % CR) * P1 + (tf % P1);
+        const size_t off = chunk_row_offset(lay, y / CR) + (size_t)(tf / P1) * lay.sx + (y % CR) * P1 + (tf % P1);
         c32 a[EH], b[EH];
         if (pass == 0) {
             const c32* src = inter + (size_t)1 * lay.fs + off;
@@ -1343,6 +1355,30 @@ template <int N, int PSEL = 0> struct Geo {
     static constexpr int R2 = (ROW_LPW > OCEAN_R2_SMALL) ? OCEAN_R2_SMALL : ROW_LPW;
 #else
     static constexpr int R2 = (N <= 1024 && ROW_LPW > 2) ? 2 : ROW_LPW;
+#endif
+    // Intermediate layout of the fused frame (InterLayout): blocks of B = 2^inter_bshift chunk rows.
+    // B = 1 is pass-2-contiguous (pass 2 streams, pass 1 scatters single 128-byte chunks), B = N / 4 pass-1-contiguous.
+    // At N >= 4096, where pass 1 is bound by its scattered stores, B = 4: a pass-1 wave stores 512-byte pieces, and the
+    // workgroups of pass 2 that read one block (4 chunk rows = 16 rows) plus the next one run in adjacent slots of
+    // one XCD (p2_group = 8 chunk rows).  Measured (runs r02_run20-22, four repetitions per box): N = 4096 5440-5500
+    // frames/s against 4905-5270 with B = 1 and 5170-5220 with B = N / 4 (pass 1 93-95 us against 101-115 and 92-98,
+    // pass 2 88-91 us against 88-92 and 99-100); N = 8192 1047-1065 against 1034-1054; N = 2048 indifferent (B = 1 kept).
+    // A/B knobs: OCEAN_INTER_BSHIFT, OCEAN_INTER_PADX, OCEAN_P2_GROUP.
+    static constexpr int chunk_rows_log2() { int l = 0; while ((CHUNK_R << l) < N) ++l; return l; }
+#ifdef OCEAN_INTER_BSHIFT
+    static constexpr int inter_bshift = (OCEAN_INTER_BSHIFT < chunk_rows_log2()) ? OCEAN_INTER_BSHIFT : chunk_rows_log2();
+#else
+    static constexpr int inter_bshift = (N >= 4096) ? 2 : 0;
+#endif
+#ifdef OCEAN_INTER_PADX                                                // elements added to the pitch between chunk columns (B > 1)
+    static constexpr int inter_padx = (inter_bshift > 0) ? OCEAN_INTER_PADX : 0;
+#else
+    static constexpr int inter_padx = 0;
+#endif
+#ifdef OCEAN_P2_GROUP
+    static constexpr int p2_group = OCEAN_P2_GROUP;
+#else
+    static constexpr int p2_group = (inter_bshift > 0) ? 8 : 1;
 #endif
     static constexpr int thin_threads = T * R2;
     static constexpr int thin_lds = R2 * Pitch2<N, R2>::elems * (int)sizeof(c32);

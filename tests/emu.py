@@ -36,7 +36,7 @@ def lib():
         _LIB.emu_frame_pass2.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_size_t] * 3
         _LIB.emu_frame_pass2_thin.argtypes = _LIB.emu_frame_pass2.argtypes
         _LIB.emu_frame_half.argtypes = ([ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_float] + [ctypes.c_void_p] * 5 +
-                                        [ctypes.c_size_t] * 3 + [ctypes.c_float] * 2)
+                                        [ctypes.c_size_t] * 3 + [ctypes.c_int] + [ctypes.c_float] * 2)
         _LIB.emu_fft_lines.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         _LIB.emu_propagate.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_float] * 2 + [ctypes.c_uint32]
         _LIB.emu_correct.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4
@@ -100,11 +100,15 @@ def inter_layout(n, P, layout="p2", pad=32):
 
 def unpack_inter(inter, n, P, lay, f, columns=None):
     """Intermediate field f -> natural [y, x] array (columns < n for the half-spectrum path)."""
-    sx, sy, fs = lay
+    sx, sy, fs = lay[:3]
     columns = columns or n
     cw, cr = chunk()
     X, Y, r, c = np.meshgrid(np.arange(columns // cw), np.arange(n // cr), np.arange(cr), np.arange(cw), indexing="ij")
-    idx = f * fs + X * sx + Y * sy + r * cw + c
+    if len(lay) == 4:                                   # block layout of the half-spectrum path
+        b = lay[3]
+        idx = f * fs + (Y >> b) * sy + X * sx + (Y & ((1 << b) - 1)) * (cw * cr) + r * cw + c
+    else:
+        idx = f * fs + X * sx + Y * sy + r * cw + c
     out = np.empty((n, columns), np.complex64)
     out[(Y * cr + r).ravel(), (X * cw + c).ravel()] = inter[idx.ravel()]
     return out
@@ -127,9 +131,25 @@ def frame(h0, omega, time, L=1000.0, return_inter=False, thin=True, layout="p2")
     return out
 
 
-def half_layout(n, P, layout="p2", pad=32):
-    """(sx, sy, fs) of the half-spectrum intermediate (N/2 columns) -- mirrors ocean_context_create."""
-    return _layout(n // 2, n, P, layout, pad)
+def half_layout(n, P, layout="p2", pad=32, bshift=None, padx=None):
+    """(sx, sy, fs, bshift) of the half-spectrum intermediate (N/2 columns) -- mirrors ocean_context_create:
+    chunk (X, Y) at (Y / B) * sy + X * sx + (Y % B) * 16, B = 2^bshift.  layout "p2" = B 1, "p1" = B N/4 (all chunk
+    rows), "default" = what the build ships for this N (Geo::inter_bshift); an explicit bshift overrides."""
+    cw, cr = chunk()
+    gx, gy = (n // 2) // cw, n // cr
+    if bshift is None:
+        if layout == "default":
+            bshift = lib().emu_inter_bshift(n)
+            padx = lib().emu_inter_padx(n) if padx is None else padx
+        else:
+            bshift = 0 if layout == "p2" else gy.bit_length() - 1
+    bshift = min(bshift, gy.bit_length() - 1)
+    if padx is None:
+        padx = 32 if bshift > 0 else 0
+    B = 1 << bshift
+    sx = B * 16 + padx
+    sy = gx * sx + pad
+    return sx, sy, sy * (gy // B), bshift
 
 
 def quantize_f16(h0):
@@ -144,7 +164,7 @@ def quantize_f16(h0):
     return (bits[..., 0] | (bits[..., 1] << 16)).astype(np.uint32), deq, s
 
 
-def frame_half(h0, omega, time, L=1000.0, layout="p2", return_inter=False, spectrum_fp16=False, P=None, split=False):
+def frame_half(h0, omega, time, L=1000.0, layout="p2", return_inter=False, spectrum_fp16=False, P=None, split=False, bshift=None):
     """split=True: every line as two interleaved N/2 transforms (the N = 8192 geometry, P = 2)."""
     n = h0.shape[0]
     P = 2 if split else (P or lib().emu_frame_p(n))
@@ -156,15 +176,15 @@ def frame_half(h0, omega, time, L=1000.0, layout="p2", return_inter=False, spect
     else:
         h0T = np.ascontiguousarray(h0.T, np.complex64)
     omT = np.ascontiguousarray(omega.T, np.float32)
-    sx, sy, fs = half_layout(n, P, layout)
+    sx, sy, fs, bshift = half_layout(n, P, layout, bshift=bshift)
     inter = np.full(3 * fs, np.nan + 1j * np.nan, np.complex64)
     nyq = np.full(6 * n, np.nan, np.float32)           # scratch: the Nyquist column's three spectra
     out = np.full((n, n, 4), np.nan, np.float32)
     tw = twiddles(n)
     assert lib().emu_frame_half(n, 22 if split else int(P), _p(h0T), int(spectrum_fp16), descale, _p(omT), _p(inter), _p(nyq), _p(out), _p(tw),
-                                sx, sy, fs, time, L) == 0
+                                sx, sy, fs, bshift, time, L) == 0
     if return_inter:
-        return out, inter, nyq, (P, (sx, sy, fs))
+        return out, inter, nyq, (P, (sx, sy, fs, bshift))
     return out
 
 

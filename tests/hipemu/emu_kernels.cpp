@@ -80,7 +80,7 @@ template <int N, int PSEL> static int run_half_p(const void* h0T, int f16, float
     else emu_launch(G::half_grid1, G::half_threads1,
                     [&] { k_half_pass1<N, G::E1, G::P, false>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L); });
     emu_launch(G::thin_grid, G::thin_threads,
-               [&] { k_half_pass2<N, G::E, CHUNK_W, G::R2>(inter, out, tw, lay); });
+               [&] { k_half_pass2<N, G::E, CHUNK_W, G::R2, G::p2_group>(inter, out, tw, lay); });
     return 0;
 }
 template <int N> static int run_half_split(const void* h0T, int f16, float descale, const float* omT, c32* inter, c32* nyq,
@@ -91,7 +91,7 @@ template <int N> static int run_half_split(const void* h0T, int f16, float desca
                         [&] { k_half_pass1_split<N, G::E1S, G::P, true>(h0T, descale, omT, inter, nyq, tw, lay, time, L); });
     else emu_launch(G::half_grid1, G::split_threads1,
                     [&] { k_half_pass1_split<N, G::E1S, G::P, false>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L); });
-    emu_launch(N, G::split_threads2, [&] { k_half_pass2_split<N, G::E, CHUNK_W>(inter, out, tw, lay); });
+    emu_launch(N, G::split_threads2, [&] { k_half_pass2_split<N, G::E, CHUNK_W, G::p2_group>(inter, out, tw, lay); });
     return 0;
 }
 template <int N> static int run_half(int psel, const void* h0T, int f16, float descale, const float* omT, c32* inter, c32* nyq,
@@ -158,6 +158,16 @@ template <int N> static int run_shard_cols(int rank, int world, const c32* recv,
 extern "C" {
 int emu_chunk_w() { return CHUNK_W; }
 int emu_chunk_r() { return CHUNK_R; }
+int emu_inter_bshift(int n) {
+#define C_(N) Geo<N>::inter_bshift
+    DISPATCH(n, C_)
+#undef C_
+}
+int emu_inter_padx(int n) {
+#define C_(N) Geo<N>::inter_padx
+    DISPATCH(n, C_)
+#undef C_
+}
 int emu_frame_p(int n) {
 #define C_(N) Geo<N>::P
     DISPATCH(n, C_)
@@ -185,8 +195,8 @@ int emu_frame_pass2_thin(int n, const float* inter, float* out, const float* tw,
 #undef C_
 }
 int emu_frame_half(int n, int psel, const void* h0T, int f16, float descale, const float* omT, float* inter, c32* nyq, float* out,
-                   const float* tw, size_t sx, size_t sy, size_t fs, float time, float L) {
-#define C_(N) run_half<N>(psel, h0T, f16, descale, omT, (c32*)inter, (c32*)nyq, (float4*)out, (const c32*)tw, InterLayout{sx, sy, fs}, time, L)
+                   const float* tw, size_t sx, size_t sy, size_t fs, int bshift, float time, float L) {
+#define C_(N) run_half<N>(psel, h0T, f16, descale, omT, (c32*)inter, (c32*)nyq, (float4*)out, (const c32*)tw, InterLayout{sx, sy, fs, bshift}, time, L)
     DISPATCH(n, C_)
 #undef C_
 }

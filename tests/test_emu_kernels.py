@@ -116,6 +116,13 @@ def test_emu_normals(ref_inputs_256, channel):
     assert np.allclose(np.linalg.norm(got[..., :3], axis=-1), 1.0, atol=1e-6) and np.all(got[..., 3] == 0)
 
 
+def test_emu_split_line_geometry_block_layout(ref_inputs):
+    """The split kernels (N = 8192 geometry) with the intermediate in blocks of 8 chunk rows."""
+    h0, om = ref_inputs
+    out = emu.frame_half(h0, om, 2.5, split=True, bshift=3)
+    assert_parity(out[..., :3], oc.frame_f64(h0, om, 2.5)[..., :3], 5e-6, "split frame, blocks of 8 chunk rows")
+
+
 @pytest.mark.parametrize("n", [512, 1024])
 def test_emu_split_line_geometry(n, ref_inputs):
     """The N = 8192 kernels (every line as two interleaved N/2 transforms, last radix-2 step at read-out) at sizes
@@ -185,14 +192,17 @@ def test_emu_fp16_spectrum_config5(ref_inputs_256):
     assert 1e-5 < rl2.max() < 2e-3          # fp16 rounding of the inputs is visible, as SURVEY 7 predicts
 
 
+@pytest.mark.parametrize("bshift", [0, 2, 30])
 @pytest.mark.parametrize("P", [4, 2])
-def test_emu_half_intermediate_layout(ref_inputs_256, P):
+def test_emu_half_intermediate_layout(ref_inputs_256, P, bshift):
     """k_half_pass1 writes columns kx < N/2 of FFT_y(2 S(F)) as 4 x 4 chunks (128 bytes), whole or in
     halves; column 0 carries two real columns, (kx = 0, kx = N/2) as (re, im), and the scratch holds the
-    Nyquist column's three symmetrised spectra."""
+    Nyquist column's three symmetrised spectra.  bshift: the chunk rows in blocks of 1 (pass-2-contiguous), 4, or
+    all of them (pass-1-contiguous, what N = 4096 ships) -- the frame must not care."""
     h0, om = ref_inputs_256
     n = 256
-    out, inter, nyq, (P_, lay) = emu.frame_half(h0, om, 2.0, return_inter=True, P=P)
+    out, inter, nyq, (P_, lay) = emu.frame_half(h0, om, 2.0, return_inter=True, P=P, bshift=bshift)
+    assert_parity(out[..., :3], oc.frame_f64(h0, om, 2.0)[..., :3], 5e-6, f"frame, blocks of 2^{bshift} chunk rows")
     H, DX, DZ = oc.propagate_f64(h0, om, 2.0)
     for f, F in ((0, DX), (1, H), (2, DZ)):
         Fm = np.conj(np.roll(np.roll(F[::-1, ::-1], 1, axis=0), 1, axis=1))
