@@ -240,6 +240,20 @@ template <int N> struct Launch {
     }
     template <int PSEL> static void half_pass2(OceanContext* c, hipStream_t s, Timing t) {
         using H = Geo<N, PSEL>;
+#ifdef OCEAN_E2_8192   // A/B knob: at N = 8192 the plain pass 2 with 32 elements per thread (256 threads per row) instead of the split one
+        if constexpr (N == 8192) {
+            constexpr int lds = Pitch2<N, 1>::elems * (int)sizeof(c32);
+            static bool prepared = false;
+            if (!prepared) {
+                (void)hipFuncSetAttribute((const void*)k_half_pass2<N, OCEAN_E2_8192, CHUNK_W, 1, H::p2_group>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                prepared = true;
+            }
+            launch(k_half_pass2<N, OCEAN_E2_8192, CHUNK_W, 1, H::p2_group>, dim3(N), dim3(N / OCEAN_E2_8192), lds, s, t,
+                   (const c32*)c->inter, c->out, (const c32*)c->tw, c->lay_h);
+            return;
+        }
+#endif
         if constexpr (split_built<PSEL>()) {
             if (c->split) {
                 launch(k_half_pass2_split<N, H::E, CHUNK_W, H::p2_group>, dim3(N), dim3(H::split_threads2), H::split_lds2, s, t,

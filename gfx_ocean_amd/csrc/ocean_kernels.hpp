@@ -1034,7 +1034,7 @@ template <int N, int R2> struct Pitch2 { static constexpr int elems = LdsLine<N>
 // GRP: this many consecutive chunk rows run in adjacent dispatch slots of one XCD (with the pass-1-contiguous layout the
 // chunks (X, Y), (X, Y + 1), ... are adjacent in memory: the workgroups that read one DRAM page run together).
 template <int N, int E, int P1, int R2, int GRP = 1>
-__global__ void __launch_bounds__((N / E) * R2, 4)
+__global__ void __launch_bounds__((N / E) * R2, (E == 16) ? 4 : 2)
 k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32* __restrict__ tw, InterLayout lay) {
     constexpr int T = N / E;
     constexpr int EH = E / 2;                                      // elements of the half spectrum per thread
