@@ -812,7 +812,12 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
     const int rotq = (OCEAN_ROTQ == 2) ? (int)((blockIdx.x * 5u + (blockIdx.x >> 3)) & (E / 2 - 1)) : (X & (E / 2 - 1));
 #endif
 #pragma unroll
-    for (int f = 0; f < 3; ++f) {
+    for (int ff = 0; ff < 3; ++ff) {
+#ifdef OCEAN_FIELD_ORDER   // A/B knob: height first (its spectrum is the cheapest and the first transform of a round is exposed)
+        const int f = (ff == 0) ? 1 : ((ff == 1) ? 0 : 2);
+#else
+        const int f = ff;
+#endif
         c32 reg[E];
         const int jf = opaque_lane(j);
         half_spectrum<N, E>(f, A, B, kxv, kscale, jf, reg);
@@ -823,7 +828,7 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
                 reg[e] = cadd_i(reg[e], z[e * T]);                 // + i * Sn
             }
         }
-        if (f > 0) __syncthreads();
+        if (ff > 0) __syncthreads();
 #ifdef OCEAN_X_NOFFT   // timing experiment only (wrong results): the transform replaced by its final LDS scatter
         {
             c32* g = lds_line + lds_pad(jf);
@@ -834,7 +839,7 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
 #else
         fft_line_to_lds<N, E>(reg, jf, tw, lds_line);
 #endif
-        OCEAN_TL(2 + 2 * f);
+        OCEAN_TL(2 + 2 * ff);
         // chunk row Y = i / CR + q * (2T / CR): the thread's part and the (wave-uniform, scalar) part of the address add
         // up because 2T / CR is a power of two > i / CR (no carry between them in chunk_row_offset)
         c32* dst = inter + (size_t)f * lay.fs + (size_t)((X * P) / CW) * lay.sx + chunk_row_offset(lay, i / CR) + (i % CR) * CW +
@@ -857,7 +862,7 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
             if constexpr (P == CW) store_float4_nt(o, make_float4(v0.x, v0.y, v1.x, v1.y));
             else *o = make_float4(v0.x, v0.y, v1.x, v1.y);        // half a chunk row: must meet its other half in L2
         }
-        OCEAN_TL(3 + 2 * f);
+        OCEAN_TL(3 + 2 * ff);
     }
 }
 
