@@ -232,20 +232,16 @@ k_fft_lines(c32* __restrict__ data, const c32* __restrict__ tw) {
 // ---------------------------------------------------------------------------------------------
 // Fused frame
 // ---------------------------------------------------------------------------------------------
-// Intermediate (between the two passes): P x P chunks of c32 (128 bytes for P = 4).  Chunk (X, Y)
-// holds columns x = X*P + c and rows y = Y*P + r at offset r*P + c.  Its address is
-//     field * fs + X * sx + Y * sy          (elements)
-// The shipped layout is "pass-2-contiguous": sx = P*P, sy = (N/P)*P*P + pad, i.e. the chunks of one
-// row group are adjacent, so pass 2 streams 128 KiB contiguous per row group while pass 1 scatters
-// 128-byte chunks with a 128 KiB stride (measured 25 us/frame faster at N = 4096 than the
-// opposite choice; both are selectable at context creation for A/B runs).
-// Field order in the intermediate: 0 = disp_x, 1 = height, 2 = disp_z (OCEAN_FIELD_*).
+// Intermediate (between the two passes): 4 x 4 chunks of c32 (128 bytes).  Chunk (X, Y) holds columns
+// x = 4 X + c and rows y = 4 Y + r at offset 4 r + c.  Field order: 0 = disp_x, 1 = height, 2 = disp_z (OCEAN_FIELD_*).
 struct InterLayout { size_t sx, sy, fs; int bshift; };
 // Rows of chunks are grouped in blocks of B = 2^bshift: chunk (X, Y) sits at
 //     field * fs + (Y / B) * sy + X * sx + (Y % B) * 16        (elements; 16 = one 128-byte chunk).
-// B = 1 is pass-2-contiguous (the chunks of one chunk row adjacent, sx = 16); B = N / 4 is pass-1-contiguous (all the
-// chunks of one chunk column adjacent); in between a pass-1 workgroup writes B * 128 contiguous bytes and a pass-2
-// workgroup finds its row's lines B * 128 bytes apart.  The staged hand-off and the A/B c2c kernels always use B = 1.
+// B = 1 is pass-2-contiguous (the chunks of one chunk row adjacent, sx = 16: pass 2 streams 64 KiB runs while pass 1
+// scatters single chunks 64 KiB apart); B = N / 4 is pass-1-contiguous (all the chunks of one chunk column adjacent);
+// in between a pass-1 workgroup writes B * 128 contiguous bytes and a pass-2 workgroup finds its row's lines B * 128
+// bytes apart.  Shipped: B = 4 at N >= 4096, B = 1 below (Geo::inter_bshift, measurements there and in DESIGN 4.4).
+// The staged hand-off and the A/B c2c kernels always use B = 1.
 __device__ __forceinline__ size_t chunk_row_offset(const InterLayout& lay, int Y) {
     return (size_t)(Y >> lay.bshift) * lay.sy + (size_t)(Y & ((1 << lay.bshift) - 1)) * (size_t)16;   // one chunk = 16 elements
 }
