@@ -720,6 +720,74 @@ __device__ __forceinline__ void half_load_AB(const void* __restrict__ h0T_, floa
     }
 }
 
+// A/B variant of half_load_AB (whole lines, S = 1): every line of the spectrum is asked for twice within a microsecond --
+// own[x + c] by wave group c and mirror2 of column x + c + 1 by wave group c + 1 (the next workgroup for c = 3), likewise
+// mirror / own2 -- and most of those pairs miss the L2 together.  Here the second-use streams (own2,
+// mirror2 and their dispersion stream) trail the first-use streams (own, mirror) by one load batch, so that the line is
+// in the L2 when it is asked for again.  One more stage in the batch chain (LOAD_BATCHES + 1).
+template <int N, int E, bool H16>
+__device__ __forceinline__ void half_load_AB_skewed(const void* __restrict__ h0T_, float descale, const float* __restrict__ omegaT,
+                                                    uint32_t x, int j, float time, c32 (&A)[E], c32 (&B)[E]) {
+    typedef typename Spec<H16>::elem Sp;
+    constexpr int T = N / E;
+    const Sp* h0T = reinterpret_cast<const Sp*>(h0T_);
+    const uint32_t x2 = (N - x) & (N - 1);
+    const uint32_t xm = (x - 1u) & (N - 1);
+    const Sp* own = h0T + (size_t)x * N;
+    const Sp* mir = h0T + (size_t)(N - 1 - x) * N;
+    const Sp* own2 = h0T + (size_t)x2 * N;
+    const Sp* mir2 = h0T + (size_t)xm * N;
+    const float* om = omegaT + (size_t)x * N;
+    const float* om2 = omegaT + (size_t)x2 * N;
+    constexpr int LOAD_BATCHES = 4;
+    constexpr int PER = E / LOAD_BATCHES;
+    int jj = j;
+    float dep = 0.0f;
+#pragma unroll
+    for (int b = 0; b <= LOAD_BATCHES; ++b) {
+        if (b > 0) jj = opaque_after(j, dep);
+        c32 a[PER], m[PER], a2[PER], m2[PER];
+        float w[PER], w2[PER];
+        if (b < LOAD_BATCHES) {
+#pragma unroll
+            for (int t = 0; t < PER; ++t) {
+                const int e = b * PER + t;
+                a[t] = Spec<H16>::load((own + e * T) + jj, descale);
+                m[t] = Spec<H16>::load((mir + (N - 1 - (e + 1) * T + 1)) + (T - 1 - jj), descale);   // mir[N - 1 - y]
+                w[t] = OCEAN_OMEGA_LOAD((om + e * T) + jj);
+            }
+        }
+        if (b >= 1) {
+#pragma unroll
+            for (int t = 0; t < PER; ++t) {
+                const int e = (b - 1) * PER + t;
+                if (e == 0) {                                      // y may be 0: (N - y) % N and (y - 1) % N wrap
+                    const int y2 = (N - jj) & (N - 1);
+                    const int ym = (jj - 1) & (N - 1);
+                    a2[t] = Spec<H16>::load(h0T + (size_t)x2 * N + y2, descale);
+                    m2[t] = Spec<H16>::load(h0T + (size_t)xm * N + ym, descale);
+                    w2[t] = OCEAN_OMEGA_LOAD((omegaT + (size_t)x2 * N) + y2);
+                } else {
+                    a2[t] = Spec<H16>::load((own2 + (N - (e + 1) * T)) + (T - jj), descale);   // own2[N - y]
+                    m2[t] = Spec<H16>::load((mir2 + (e * T - 1)) + jj, descale);               // mir2[y - 1]
+                    w2[t] = OCEAN_OMEGA_LOAD((om2 + (N - (e + 1) * T)) + (T - jj));
+                }
+            }
+        }
+        dep = 0.0f;
+        if (b < LOAD_BATCHES) {
+#pragma unroll
+            for (int t = 0; t < PER; ++t) A[b * PER + t] = propagate_height(a[t], m[t], w[t], time);
+            dep += A[b * PER + PER - 1].x;
+        }
+        if (b >= 1) {
+#pragma unroll
+            for (int t = 0; t < PER; ++t) B[(b - 1) * PER + t] = cconj(propagate_height(a2[t], m2[t], w2[t], time));
+            dep += B[(b - 1) * PER + PER - 1].y;
+        }
+    }
+}
+
 // The same for ONE position (the Nyquist column is done element-wise by a whole workgroup).
 template <int N, bool H16>
 __device__ __forceinline__ void half_AB_at(const void* __restrict__ h0T_, float descale, const float* __restrict__ omegaT,
@@ -796,7 +864,11 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
     const uint32_t x2 = (N - x) & (N - 1);
     c32 A[E], B[E];
     OCEAN_TL(0);
+#ifdef OCEAN_SKEW_DUP
+    half_load_AB_skewed<N, E, H16>(h0T, descale, omegaT, x, j, time, A, B);
+#else
     half_load_AB<N, E, H16>(h0T, descale, omegaT, x, j, time, A, B);
+#endif
     OCEAN_TL(1);
     const c32 kxv = mk(wave_index_q1(x, N), wave_index_q1(x2, N)) * kscale;
 
