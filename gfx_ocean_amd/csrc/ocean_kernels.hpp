@@ -957,6 +957,9 @@ __device__ __forceinline__ void half_load_AB_pairs(const void* __restrict__ h0T_
     const float* om = omegaT + (size_t)x * N + 2 * e0 * TS;
     const float* om2 = omegaT + (size_t)x2 * N - 2 * e0 * TS;
     c32 mineA[EH], mineB[EH];
+#ifdef OCEAN_X_NODUP
+    const bool nodup_skip = (tid / (2 * TS)) != 0;                 // the workgroup's second column (wave-uniform)
+#endif
     constexpr int PER = 2;                                         // iterations per load batch (4 elements, as half_load_AB)
     int jj = j;
 #pragma unroll
@@ -967,6 +970,14 @@ __device__ __forceinline__ void half_load_AB_pairs(const void* __restrict__ h0T_
         Spec<H16>::load2((own + 2 * t * TS) + 2 * jj, descale, a0, a1);
         Spec<H16>::load2((mir + (N - 2 * (t + 1) * TS)) + 2 * (TS - 1 - jj), descale, m1, m0);   // mir[N-2-2m], mir[N-1-2m]
         { const float* wp = (om + 2 * t * TS) + 2 * jj; w0 = OCEAN_OMEGA_LOAD(wp); w1 = OCEAN_OMEGA_LOAD(wp + 1); }
+#ifdef OCEAN_X_NODUP   // timing experiment only (wrong results): column 1 of the workgroup does not load the two streams that
+                       // re-read column 0's lines (its own2 = column 0's mirror, its mirror2 = column 0's own)
+        if (nodup_skip) {
+            b0 = m0; b1 = m1; n0 = a0; n1 = a1;
+            const float* wp = (om2 + (N - 1 - 2 * (t + 1) * TS)) + 2 * (TS - jj);
+            v1 = OCEAN_OMEGA_LOAD(wp); v0 = OCEAN_OMEGA_LOAD(wp + (t == 0 && jj == 0 ? 0 : 1));
+        } else
+#endif
         if (t == 0) {                                              // m may be 0: y2 = (N - y) % N and ym = (y - 1) % N wrap
             const int y0 = 2 * (jj + e0 * TS), y1 = y0 + 1;
             const int y20 = (N - y0) & (N - 1), y21 = (N - y1) & (N - 1);
