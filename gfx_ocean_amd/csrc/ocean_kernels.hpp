@@ -240,7 +240,7 @@ struct InterLayout { size_t sx, sy, fs; int bshift; };
 // B = 1 is pass-2-contiguous (the chunks of one chunk row adjacent, sx = 16: pass 2 streams 64 KiB runs while pass 1
 // scatters single chunks 64 KiB apart); B = N / 4 is pass-1-contiguous (all the chunks of one chunk column adjacent);
 // in between a pass-1 workgroup writes B * 128 contiguous bytes and a pass-2 workgroup finds its row's lines B * 128
-// bytes apart.  Shipped: B = 4 at N >= 4096, B = 1 below (Geo::inter_bshift, measurements there and in DESIGN 4.4).
+// bytes apart.  Shipped: B = 4 at N >= 2048, B = 1 below (Geo::inter_bshift, measurements there and in DESIGN 4.4).
 // The staged hand-off and the A/B c2c kernels always use B = 1.
 __device__ __forceinline__ size_t chunk_row_offset(const InterLayout& lay, int Y) {
     return (size_t)(Y >> lay.bshift) * lay.sy + (size_t)(Y & ((1 << lay.bshift) - 1)) * (size_t)16;   // one chunk = 16 elements
@@ -1442,17 +1442,18 @@ template <int N, int PSEL = 0> struct Geo {
 #endif
     // Intermediate layout of the fused frame (InterLayout): blocks of B = 2^inter_bshift chunk rows.
     // B = 1 is pass-2-contiguous (pass 2 streams, pass 1 scatters single 128-byte chunks), B = N / 4 pass-1-contiguous.
-    // At N >= 4096, where pass 1 is bound by its scattered stores, B = 4: a pass-1 wave stores 512-byte pieces, and the
+    // At N >= 2048, where pass 1 is bound by its scattered stores, B = 4: a pass-1 wave stores 512-byte pieces, and the
     // workgroups of pass 2 that read one block (4 chunk rows = 16 rows) plus the next one run in adjacent slots of
     // one XCD (p2_group = 8 chunk rows).  Measured (runs r02_run20-22, four repetitions per box): N = 4096 5440-5500
     // frames/s against 4905-5270 with B = 1 and 5170-5220 with B = N / 4 (pass 1 93-95 us against 101-115 and 92-98,
-    // pass 2 88-91 us against 88-92 and 99-100); N = 8192 1047-1065 against 1034-1054; N = 2048 indifferent (B = 1 kept).
+    // pass 2 88-91 us against 88-92 and 99-100); N = 8192 1047-1065 against 1034-1054; N = 2048 19.6-19.9k against
+    // 19.3-19.5k (run 31; four lines per pass-1 workgroup there: 17.2k).
     // A/B knobs: OCEAN_INTER_BSHIFT, OCEAN_INTER_PADX, OCEAN_P2_GROUP.
     static constexpr int chunk_rows_log2() { int l = 0; while ((CHUNK_R << l) < N) ++l; return l; }
 #ifdef OCEAN_INTER_BSHIFT
     static constexpr int inter_bshift = (OCEAN_INTER_BSHIFT < chunk_rows_log2()) ? OCEAN_INTER_BSHIFT : chunk_rows_log2();
 #else
-    static constexpr int inter_bshift = (N >= 4096) ? 2 : 0;
+    static constexpr int inter_bshift = (N >= 2048) ? 2 : 0;
 #endif
 #ifdef OCEAN_INTER_PADX                                                // elements added to the pitch between chunk columns (B > 1)
     static constexpr int inter_padx = (inter_bshift > 0) ? OCEAN_INTER_PADX : 0;
