@@ -94,3 +94,33 @@ def test_failed_rank_fails_the_launch():
                        capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode != 0
     assert not [l for l in p.stdout.splitlines() if l.strip().startswith("{")]   # and no fabricated line
+
+
+def test_committed_bench_lines_carry_the_contract_fields():
+    """The lines the GPU box produced (profiles/) have every field of the bench contract, with the roofline computed from
+    the bytes the kernels move and the three-complex-transform accounting beside it, never as `achieved`."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_run*_bench*.json")))
+    assert paths
+    for path in paths:
+        with open(path) as f:
+            r = json.loads(f.read())
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                  "vs_baseline", "dtype", "data", "config", "roofline"):
+            assert k in r, (path, k)
+        assert r["unit"] == "frames/s" and r["dtype"] == "f32" and r["data"] == "synthetic" and r["vs_baseline"] is None
+        assert "workload" in r["config"] and "model" not in r["config"]
+        ro = r["roofline"]
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert k in ro, (path, k)
+        assert ro["bound"] == "hbm" and ro["peak"] == 8000.0 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-9
+        n, spec = r["config"]["n"], r["config"].get("spectrum", "f32")
+        dom = [k for k in ro["kernels"] if k["name"] == ro["kernel"]][0]
+        moved = bench.MOVED_BYTES_PER_TEXEL[spec][bench.pass_of(dom["name"])] * n * n
+        assert abs(dom["algorithmic_bytes"] - moved) < 1 and abs(ro["achieved"] - moved / dom["avg_ms"] / 1e6) < 1e-6 * ro["achieved"]
+        assert ro["contract_frac"] > ro["frac"]                      # the 76-byte accounting is reported, but not as `achieved`
+        assert 0.0 < ro["frac"] < 0.79                               # nothing above the part's measured copy ceiling (6.29 TB/s)
+        if "cpu_baseline" in r:
+            for k in ("value", "unit", "cores", "kind", "sample"):
+                assert k in r["cpu_baseline"], (path, k)
+            assert r["cpu_baseline"]["kind"] == "port"
