@@ -156,3 +156,52 @@ pub mod fft {
         pub fn destroy(self) { unsafe { ffi::ocean_fft_destroy(self.h) } }
     }
 }
+
+pub mod shard {
+    //! One N x N tile over several GPUs (include/ocean_hip.h "sharded tile"; no counterpart in the reference, whose
+    //! only ordering constraint -- all row passes, barrier, all column passes, src/render.rs:1158-1231 -- becomes the
+    //! all-to-all the caller runs between `rows` and `cols` (RCCL `ncclSend`/`ncclRecv` group, or any other transport).
+    use super::*;
+    use std::os::raw::c_void;
+
+    pub struct Shard { h: *mut ffi::OceanShard, n: usize, rows: usize }
+
+    impl Shard {
+        pub fn new(device: i32, resolution: i32, rank: i32, world: i32) -> Result<Self, Box<dyn Error>> {
+            let mut h = ptr::null_mut();
+            let st = unsafe { ffi::ocean_shard_create(device, resolution, rank, world, &mut h) };
+            if st != 0 { return Err(Box::new(shard_error(ptr::null(), st))); }
+            Ok(Shard { h, n: resolution as usize, rows: (resolution / world) as usize })
+        }
+        fn check(&self, st: i32) -> Result<(), Box<dyn Error>> {
+            if st == 0 { Ok(()) } else { Err(Box::new(shard_error(self.h, st))) }
+        }
+        /// The rank's rows of h0 and omega, and the opposite row block of h0 (where its "-k" partners live).
+        pub fn upload(&self, h0_own: &[[f32; 2]], h0_partner: &[[f32; 2]], omega_own: &[f32]) -> Result<(), Box<dyn Error>> {
+            let block = self.rows * self.n;
+            if h0_own.len() != block || h0_partner.len() != block || omega_own.len() != block {
+                return Err(Box::new(OceanError { status: -1, message: format!("upload: expected {} entries per block", block) }));
+            }
+            self.check(unsafe { ffi::ocean_shard_upload(self.h, h0_own.as_ptr() as *const f32, h0_partner.as_ptr() as *const f32, omega_own.as_ptr()) })
+        }
+        /// Propagate + row pass on the rank's rows into `send` (device memory, [world][3][rows][cols] complex fp32).
+        /// # Safety
+        /// `send` must be a device allocation of 3 * rows * N complex fp32 values; `stream` a hipStream_t or null.
+        pub unsafe fn rows(&self, locals: &ffi::OceanPropagateLocals, send: *mut c_void, stream: *mut c_void) -> Result<(), Box<dyn Error>> {
+            self.check(ffi::ocean_shard_rows(self.h, locals, send, stream))
+        }
+        /// Column pass + correction on the received block; `out_t` = float4[(N / world) * N], column block transposed.
+        /// # Safety
+        /// `recv` and `out_t` must be device allocations of the sizes above, `out_t` 16-byte aligned.
+        pub unsafe fn cols(&self, recv: *const c_void, out_t: *mut c_void, stream: *mut c_void) -> Result<(), Box<dyn Error>> {
+            self.check(ffi::ocean_shard_cols(self.h, recv, out_t, stream))
+        }
+        pub fn sync(&self) -> Result<(), Box<dyn Error>> { self.check(unsafe { ffi::ocean_shard_sync(self.h) }) }
+    }
+    impl Drop for Shard { fn drop(&mut self) { unsafe { ffi::ocean_shard_destroy(self.h) } } }
+
+    fn shard_error(h: *const ffi::OceanShard, status: i32) -> OceanError {
+        let message = unsafe { CStr::from_ptr(ffi::ocean_shard_last_error(h)) }.to_string_lossy().into_owned();
+        OceanError { status, message }
+    }
+}
