@@ -198,6 +198,24 @@ def test_full_size_against_c_oracle(n):
         r.dispose()
 
 
+def test_full_size_large_time_4096():
+    """Phases omega * t of thousands of radians at the headline size (the fused kernels reduce the fp32 phase to
+    revolutions with a two-constant product before the hardware sin/cos): every texel against the C oracle's sincosf."""
+    n, t = 4096, 1000.0
+    h0, om = g.synth.make_inputs(n, seed=11)
+    cc.set_threads(min(32, cc.max_threads()))
+    refc = cc.FrameRunner(h0, om).frame(t)
+    d = g.OceanDevice(n)
+    try:
+        d.upload_spectrum(h0, om)
+        d.frame(t)
+        out = d.read_displacement()
+        nmax, rl2 = assert_parity(out[..., :3], refc[..., :3], TOL, "N=4096 t=1000 fused vs C oracle")
+        assert nmax.max() < 3e-5
+    finally:
+        d.destroy()
+
+
 @pytest.mark.parametrize("n", [4096, 8192])
 def test_full_size_properties(n):
     """BASELINE full sizes through size-independent properties (the oracle would take minutes):
