@@ -1152,22 +1152,46 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
 
     float keep_h[E];
     OCEAN_TL(0);
+    // N <= 2048: all three fields' loads are issued before the first transform (a workgroup has 8, then 16, 8-byte loads
+    // per thread in flight otherwise).  Run 34: N = 2048 20.07-20.24k frames/s against 19.84-19.94k; at N = 4096 the same
+    // costs 2-3 us (pass 2 91-94 us against 88-91): more lines in flight than the L2 keeps for the four sharers.
+#ifdef OCEAN_P2_PREFETCH
+    constexpr bool PREFETCH = (OCEAN_P2_PREFETCH != 0);
+#else
+    constexpr bool PREFETCH = (N <= 2048);
+#endif
+    c32 pre_x[EH], pre_z[EH];
+    if constexpr (PREFETCH) {
+        const size_t off0 = chunk_row_offset(lay, ly / CR) + (size_t)(lk0 / P1) * lay.sx + (ly % CR) * P1 + (lk0 % P1);
+        const c32* sx_ = inter + off0;
+        const c32* sz_ = inter + (size_t)2 * lay.fs + off0;
+#pragma unroll
+        for (int e = 0; e < EH; ++e) { pre_x[e] = sx_[(size_t)e * (T / P1) * lay.sx]; pre_z[e] = sz_[(size_t)e * (T / P1) * lay.sx]; }
+    }
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {                         // 0: height, 1: (disp_x, disp_z)
         const int jf = opaque_lane(j);
         const int lk = (R2 == 1) ? jf : opaque_lane(lk0);
         const size_t off = chunk_row_offset(lay, ly / CR) + (size_t)(lk / P1) * lay.sx + (ly % CR) * P1 + (lk % P1);
         c32 a[EH], b[EH];
+#ifdef OCEAN_X2_NOLOAD   // timing experiment only: no reads of the intermediate (the write side alone)
+#pragma unroll
+        for (int e = 0; e < EH; ++e) { a[e] = mk((float)(off & 7) + e, 1.0f); b[e] = mk(2.0f, (float)e); }
+#else
         if (pass == 0) {
             const c32* src = inter + (size_t)1 * lay.fs + off;
 #pragma unroll
             for (int e = 0; e < EH; ++e) a[e] = src[(size_t)e * (T / P1) * lay.sx];
+        } else if constexpr (PREFETCH) {
+#pragma unroll
+            for (int e = 0; e < EH; ++e) { a[e] = pre_x[e]; b[e] = pre_z[e]; }
         } else {
             const c32* sx_ = inter + off;
             const c32* sz_ = inter + (size_t)2 * lay.fs + off;
 #pragma unroll
             for (int e = 0; e < EH; ++e) { a[e] = sx_[(size_t)e * (T / P1) * lay.sx]; b[e] = sz_[(size_t)e * (T / P1) * lay.sx]; }
         }
+#endif
         if (pass > 0) __syncthreads();                             // previous FFT's LDS reads done
         // rebuild the full row: C[k] = A + iB, C[N-k] = conj(A) + i conj(B).  Column 0 of the intermediate
         // holds two real columns, (kx = 0, kx = N/2) as (re, im): C[0] = re(A) + i re(B), C[N/2] = im(A) + i im(B)
@@ -1204,7 +1228,9 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
 #pragma unroll
         for (int e = 0; e < E; ++e) reg[e] = g[e * (T + T / 16)];
         __syncthreads();
+#ifndef OCEAN_X2_NOFFT   // timing experiment only (wrong results): pass 2 without its transforms
         fft_line<N, E>(reg, jf, tw, lds_line);
+#endif
         OCEAN_TL(2 + 3 * pass);
         if (pass == 0) {
 #pragma unroll
@@ -1216,6 +1242,9 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
                 const int xo = j + e * T;
                 const float s = (((xo + y) & 1) == 0) ? -0.5f : 0.5f;   // correction.comp:29 and the 1/2 of S(F)
                 const c32 d = reg[e] * s;
+#ifdef OCEAN_X2_NOSTORE   // timing experiment only: one store per thread instead of 16 (the read side alone)
+                if (e == 0 && d.x == 12345.678f)
+#endif
                 store_float4_nt(orow + xo, make_float4(d.x, keep_h[e] * s, d.y, 0.0f));
             }
             OCEAN_TL(6);
