@@ -72,6 +72,20 @@ def measured_traffic(n, kernel_name, spectrum="f32"):
     return v["hbm_bytes"] if v else None
 
 
+def traffic_source(n, spectrum="f32"):
+    """Where `roofline.traffic` comes from: never from the timed run (counters perturb timing and need rocprofv3
+    around the process) but from a committed PMC pass of this same command."""
+    suffix = "" if spectrum == "f32" else "_f16"
+    rel = os.path.join("profiles", f"hbm_traffic_n{n}{suffix}.json")
+    try:
+        with open(os.path.join(ROOT, rel)) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None
+    return {"file": rel, "run": rec.get("run"), "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, "
+            "hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 correction, DESIGN.md 7); NOT measured in this run"}
+
+
 def tile_seed(n, rank):
     return n + rank     # SURVEY.md 8d: tile r of a multi-GPU run uses seed N + r
 
@@ -136,8 +150,8 @@ class GpuRuntime:
     def __init__(self, torch, dev):
         self.torch, self.dev = torch, dev
 
-    def empty_tile(self, n):
-        return self.torch.empty((n, n, 4), dtype=self.torch.float32, device="cuda")
+    def empty_tile(self, n, channels=4):
+        return self.torch.empty((n, n, channels), dtype=self.torch.float32, device="cuda")
 
     def stream(self, name):
         return self.torch.cuda.Stream()
@@ -157,6 +171,12 @@ class GpuRuntime:
     def frame(self, out, t, stream):
         self.dev.bind_displacement(out.data_ptr())
         self.dev.frame(t, stream=stream.cuda_stream)
+
+    def frame_packed(self, packed, fmt, t, stream):
+        """Frame into the context's own RGBA map, then the packed copy the collective ships (12 or 4 B/texel)."""
+        self.dev.bind_displacement(None)
+        self.dev.frame(t, stream=stream.cuda_stream)
+        self.dev.pack_displacement(fmt, packed.data_ptr(), stream=stream.cuda_stream)
 
     def unbind(self):
         self.dev.bind_displacement(None)
@@ -185,8 +205,8 @@ class PlumbingRuntime:
     def __init__(self, torch, rank):
         self.torch, self.rank, self.log = torch, rank, []
 
-    def empty_tile(self, n):
-        return self.torch.zeros((n, n, 4), dtype=self.torch.float32)
+    def empty_tile(self, n, channels=4):
+        return self.torch.zeros((n, n, channels), dtype=self.torch.float32)
 
     def stream(self, name):
         return self._Named(name)
@@ -208,6 +228,11 @@ class PlumbingRuntime:
         out.fill_(float(self.rank + 1))            # a recognisable tile: rank r writes r + 1
         self.log.append(("frame", stream.name, id(out)))
 
+    def frame_packed(self, packed, fmt, t, stream):
+        packed.fill_(float(self.rank + 1))
+        self.log.append(("frame", stream.name, None))
+        self.log.append(("pack", stream.name, fmt, id(packed)))
+
     def unbind(self):
         pass
 
@@ -218,15 +243,22 @@ class PlumbingRuntime:
         return self.torch.tensor([v], dtype=self.torch.float64)
 
 
-def gather_leg(rt, dist, n, n_gpus, rank, steps, warm=3):
+GATHER_FORMATS = {"rgba32f": (0, 4), "rgb32f": (1, 3), "height32f": (2, 1)}   # name -> (OCEAN_PACK_*, floats per texel)
+
+
+def gather_leg(rt, dist, n, n_gpus, rank, steps, warm=3, fmt="rgba32f"):
     """Every tile's RGBA map gathered to rank 0 with one collective per frame (root ingest N*N*16 B per peer
     over xGMI).  Two schedules, both reported, neither part of `value`:
     `ordered`    -- frame and collective on one stream;
     `overlapped` -- two output buffers; the collective of frame f runs on a second stream while frame f+1 is
                     computed (the frame is ~0.2 ms, the root's ingest of 7 x 256 MiB ~1.8 ms: the pipeline is
                     gather-bound and the overlap hides the compute, not the other way round)."""
-    outs = [rt.empty_tile(n) for _ in range(2)]
-    dsts = [[rt.empty_tile(n) for _ in range(n_gpus)] if rank == 0 else None for _ in range(2)]
+    pack_id, channels = GATHER_FORMATS[fmt]
+    # rgba32f: the frame writes straight into the buffer the collective ships (ocean_bind_displacement);
+    # rgb32f / height32f: the frame writes the context's own map and ocean_pack_displacement fills the shipped buffer
+    # (SURVEY 8e: 12 or 4 instead of 16 B/texel over xGMI; the root's ingest is what bounds the with-gather rate)
+    outs = [rt.empty_tile(n, channels) for _ in range(2)]
+    dsts = [[rt.empty_tile(n, channels) for _ in range(n_gpus)] if rank == 0 else None for _ in range(2)]
     cs, gs = rt.stream("compute"), rt.stream("gather")
     frame_done = [rt.event(f"frame_done{b}") for b in range(2)]
     gather_done = [rt.event(f"gather_done{b}") for b in range(2)]
@@ -236,7 +268,10 @@ def gather_leg(rt, dist, n, n_gpus, rank, steps, warm=3):
             b = i % 2 if overlapped else 0
             if overlapped:
                 rt.wait(cs, gather_done[b])                         # buffer b is free again (frame i-2 gathered)
-            rt.frame(outs[b], i / 60.0, cs)
+            if pack_id == 0:
+                rt.frame(outs[b], i / 60.0, cs)
+            else:
+                rt.frame_packed(outs[b], pack_id, i / 60.0, cs)
             if overlapped:
                 rt.record(frame_done[b], cs)
                 rt.wait(gs, frame_done[b])
@@ -248,7 +283,7 @@ def gather_leg(rt, dist, n, n_gpus, rank, steps, warm=3):
                     dist.gather(outs[b], dsts[b], dst=0)
         rt.synchronize()
 
-    res = {"steps": steps, "bytes_per_peer_per_frame": n * n * 16,
+    res = {"steps": steps, "format": fmt, "bytes_per_peer_per_frame": n * n * 4 * channels,
            "collective": "torch.distributed.gather (RCCL send/recv group), one per frame"}
     for name, overlapped in (("ordered", False), ("overlapped", True)):
         for e in gather_done:
@@ -263,7 +298,7 @@ def gather_leg(rt, dist, n, n_gpus, rank, steps, warm=3):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ms = float(t.item())
         res[name] = {"ms_per_step": ms / steps, "frames_per_s": n_gpus * 1000.0 * steps / ms,
-                     "root_ingest_GBps": (n_gpus - 1) * n * n * 16 / (ms / steps) / 1e6}
+                     "root_ingest_GBps": (n_gpus - 1) * n * n * 4 * channels / (ms / steps) / 1e6}
     rt.unbind()
     if rank == 0:       # what arrived: one scalar per peer tile (checked by the plumbing test; cheap on the GPU)
         res["peer_tile_first_texel"] = [float(d.reshape(-1)[0].item()) for d in dsts[(steps - 1) % 2]]
@@ -329,6 +364,9 @@ def main():
                     help="time frames followed by an RCCL gather of every tile's RGBA map to rank 0 (BASELINE config 4; "
                          "reported separately, never part of `value`).  Default: on when more than one rank runs")
     ap.add_argument("--no-gather", dest="gather", action="store_false")
+    ap.add_argument("--gather-format", choices=sorted(GATHER_FORMATS), default="rgba32f",
+                    help="payload of the gather: the RGBA32F map as the reference's image (16 B/texel), or packed by "
+                         "ocean_pack_displacement to (disp_x, height, disp_z) (12) or the height alone (4)")
     ap.add_argument("--gather-steps", type=int, default=30)
     ap.add_argument("--gather-timeout", type=float, default=120.0, help="seconds before a stuck gather leg is abandoned")
     ap.add_argument("--profile-frames", type=int, default=20, help="frames averaged for the per-kernel durations")
@@ -387,7 +425,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         seeds = [None] * world
         dist.all_gather_object(seeds, seed)
-        gather = gather_leg(rt, dist, min(n, 64), n_gpus, rank, max(1, min(args.gather_steps, 4)), warm=1) if want_gather else None
+        gather = gather_leg(rt, dist, min(n, 64), n_gpus, rank, max(1, min(args.gather_steps, 4)), warm=1,
+                            fmt=args.gather_format) if want_gather else None
         if rank == 0:
             line = {"metric": "plumbing only (no device work)", "value": None, "unit": "frames/s", "n_gpus": n_gpus,
                     "steps": args.steps, "warmup": args.warmup, "plumbing": True, "max_rank_ms": float(t.item()),
@@ -446,7 +485,7 @@ def main():
     frame_ms = event_ms / args.steps
     fb, fcb = sum(moved.values()) * n * n, sum(contract.values()) * n * n
     roofline = {"bound": "hbm", "kernel": dom["name"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": dom["frac"], "traffic": dom["traffic"],
+                "frac": dom["frac"], "traffic": dom["traffic"], "traffic_source": traffic_source(n, args.spectrum),
                 "algorithmic_bytes_per_launch": dom["algorithmic_bytes"], "avg_launch_ms": dom["avg_ms"],
                 "accounting": f"achieved = bytes the shipped half-spectrum algorithm must move ({moved['pass1']:.0f} + "
                               f"{moved['pass2']:.0f} B/texel) / kernel time; contract_* = SURVEY 8d's three-complex-"
@@ -471,18 +510,22 @@ def main():
                        "n": n, "spectrum": args.spectrum, "tiles": n_gpus,
                        "parallelism": f"tile-parallel x{n_gpus}, no data-path collective",
                        "gpu_event_ms_per_step": frame_ms,
+                       "effective_warmup_frames": args.ramp_frames + 3 * args.profile_frames + args.warmup,
                        "untimed_before_timed_region": f"{args.ramp_frames} clock-ramp frames + {3 * args.profile_frames} frames of "
-                                                      f"per-kernel profiling + {args.warmup} warmup"},
+                                                      f"per-kernel profiling + {args.warmup} warmup (`warmup` above is W as "
+                                                      f"given; effective_warmup_frames counts everything untimed)"},
             "roofline": roofline,
         }
 
     emitted = threading.Event()
+    emit_lock = threading.Lock()
 
     def emit(extra=None):
-        """Print the one line (rank 0) exactly once."""
-        if emitted.is_set():
-            return
-        emitted.set()
+        """Print the one line (rank 0) exactly once (the watchdog thread may race the main thread here)."""
+        with emit_lock:
+            if emitted.is_set():
+                return
+            emitted.set()
         if rank == 0:
             if extra:
                 line.update(extra)
@@ -495,13 +538,15 @@ def main():
         # A collective that never completes must not take the measured line with it: on timeout rank 0 prints the
         # line without the leg and every rank leaves.
         def abandon():
-            emit({"gather": {"error": f"abandoned after {args.gather_timeout:.0f} s"}})
-            os._exit(0)
+            # the main metric was measured and is printed; the exit status still says that a collective hung
+            emit({"gather": {"error": f"abandoned after {args.gather_timeout:.0f} s"}, "gather_abandoned": True})
+            json_out.flush()
+            os._exit(3)
         watchdog = threading.Timer(args.gather_timeout, abandon)
         watchdog.daemon = True
         watchdog.start()
         try:
-            gather = gather_leg(GpuRuntime(torch, dev), dist, n, n_gpus, rank, max(1, args.gather_steps))
+            gather = gather_leg(GpuRuntime(torch, dev), dist, n, n_gpus, rank, max(1, args.gather_steps), fmt=args.gather_format)
         except Exception as e:  # noqa: BLE001 -- reported, never fatal for the main metric
             gather = {"error": f"{type(e).__name__}: {e}"}
         watchdog.cancel()

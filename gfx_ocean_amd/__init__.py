@@ -13,13 +13,14 @@ from .ocean import (Correction, CorrectionLocals, Propagation, PropagateLocals, 
                     DOMAIN_SIZE, RESOLUTION)
 from .fft import Fft  # noqa: F401
 from .render import (OceanDevice, OceanRenderer, FIELD_DX, FIELD_DY, FIELD_DZ, FIELD_ALL,  # noqa: F401
-                     QUIRK_Q1, QUIRK_Q2, QUIRKS_REFERENCE)
+                     QUIRK_Q1, QUIRK_Q2, QUIRKS_REFERENCE, PACK_RGBA32F, PACK_RGB32F, PACK_HEIGHT32F,
+                     PACK_BYTES_PER_TEXEL)
 from . import bincode, synth  # noqa: F401
 
 __all__ = [
     "OceanError", "build_library", "library_path", "load_library",
     "Correction", "CorrectionLocals", "Propagation", "PropagateLocals", "Fft",
     "OceanDevice", "OceanRenderer", "FIELD_DX", "FIELD_DY", "FIELD_DZ", "FIELD_ALL",
-    "QUIRK_Q1", "QUIRK_Q2", "QUIRKS_REFERENCE",
+    "QUIRK_Q1", "QUIRK_Q2", "QUIRKS_REFERENCE", "PACK_RGBA32F", "PACK_RGB32F", "PACK_HEIGHT32F", "PACK_BYTES_PER_TEXEL",
     "DOMAIN_SIZE", "RESOLUTION", "bincode", "synth",
 ]

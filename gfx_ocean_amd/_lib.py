@@ -24,6 +24,7 @@ SYMBOLS = [
     "ocean_fft_rows", "ocean_fft_cols", "ocean_correct", "ocean_frame", "ocean_frame_ex", "ocean_sync",
     "ocean_set_quirks", "ocean_quirks",
     "ocean_normals", "ocean_read_normals", "ocean_positions", "ocean_read_positions",
+    "ocean_checksum_displacement", "ocean_packed_bytes", "ocean_pack_displacement",
     "ocean_read_displacement", "ocean_read_field", "ocean_write_field", "ocean_displacement_device_ptr",
     "ocean_bind_displacement", "ocean_stream", "ocean_time_frames", "ocean_profile_frame", "ocean_profile_staged",
     "ocean_shard_create", "ocean_shard_destroy", "ocean_shard_last_error", "ocean_shard_upload", "ocean_shard_rows",
@@ -108,6 +109,9 @@ def load_library():
         "ocean_read_normals": (i32, [vp, vp]),
         "ocean_positions": (i32, [vp, i32, f32, f32, vp]),
         "ocean_read_positions": (i32, [vp, vp]),
+        "ocean_checksum_displacement": (i32, [vp, vp, ctypes.POINTER(ctypes.c_uint64)]),
+        "ocean_packed_bytes": (ctypes.c_int64, [vp, i32]),
+        "ocean_pack_displacement": (i32, [vp, i32, vp, vp]),
         "ocean_read_displacement": (i32, [vp, vp]),
         "ocean_read_field": (i32, [vp, i32, vp]),
         "ocean_write_field": (i32, [vp, i32, vp]),

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -19,6 +20,7 @@
 
 #include "../../include/ocean_hip.h"
 #include "ocean_kernels.hpp"
+#include "ocean_aux_kernels.hpp"
 
 using namespace ocean;
 
@@ -42,14 +44,19 @@ std::unordered_set<const void*> g_live;
 void live_add(const void* p) { std::lock_guard<std::mutex> l(g_live_mu); g_live.insert(p); }
 void live_remove(const void* p) { std::lock_guard<std::mutex> l(g_live_mu); g_live.erase(p); }
 bool live(const void* p) { if (!p) return false; std::lock_guard<std::mutex> l(g_live_mu); return g_live.count(p) != 0; }
+// A context's address can be reused by a later context; stage handles therefore remember the generation of the
+// context they were made for, and a stale handle is rejected instead of silently driving the new context.
+std::atomic<uint64_t> g_generation{1};
 
 }  // namespace
 
 struct OceanContext {
     uint32_t magic = MAGIC_CTX;
+    uint64_t generation = 0;    // unique per ocean_context_create (stage handles compare it)
     int device = 0;
     int n = 0;
     hipStream_t stream = nullptr;
+    bool foreign_stream = false;  // some dispatch ran on a caller stream: readbacks then wait for the whole device
     hipEvent_t ev_a = nullptr, ev_b = nullptr;   // reused by ocean_time_frames (event creation is not free)
     // natural-layout buffers of the staged path (src/render.rs:608-670)
     c32* h0 = nullptr;          // initial_spec
@@ -80,15 +87,16 @@ struct OceanContext {
     float4* normals = nullptr;    // allocated on first ocean_normals call
     float4* positions = nullptr;  // ocean_positions: verts x verts float4, (re)allocated on demand
     int32_t position_verts = 0;
+    unsigned long long* checksum_acc = nullptr;   // ocean_checksum_displacement
     bool uploaded = false;
     bool pass2_thin = true;           // OCEAN_PASS2=fat selects the 1024-thread variant (A/B measurements)
     float default_domain = 1000.0f;   // src/render.rs:46
     uint32_t quirks = OCEAN_QUIRKS_REFERENCE;   // ocean_set_quirks
     std::string err;
 };
-struct OceanFft { uint32_t magic = MAGIC_FFT; OceanContext* ctx = nullptr; };
-struct OceanPropagation { uint32_t magic = MAGIC_PRO; OceanContext* ctx = nullptr; };
-struct OceanCorrection { uint32_t magic = MAGIC_COR; OceanContext* ctx = nullptr; };
+struct OceanFft { uint32_t magic = MAGIC_FFT; OceanContext* ctx = nullptr; uint64_t generation = 0; };
+struct OceanPropagation { uint32_t magic = MAGIC_PRO; OceanContext* ctx = nullptr; uint64_t generation = 0; };
+struct OceanCorrection { uint32_t magic = MAGIC_COR; OceanContext* ctx = nullptr; uint64_t generation = 0; };
 
 namespace {
 
@@ -107,7 +115,9 @@ int32_t hip_fail(OceanContext* ctx, hipError_t e, const char* what) {
     } while (0)
 
 bool valid(const OceanContext* c) { return live(c) && c->magic == MAGIC_CTX; }
-template <class H> bool valid_stage(const H* h, uint32_t magic) { return live(h) && h->magic == magic && valid(h->ctx); }
+template <class H> bool valid_stage(const H* h, uint32_t magic) {
+    return live(h) && h->magic == magic && valid(h->ctx) && h->ctx->generation == h->generation;
+}
 
 struct DeviceGuard {
     int prev = -1;
@@ -339,7 +349,13 @@ template <int N> struct Launch {
 
 int frame_p(int n) { int p = 0; OCEAN_DISPATCH(n, p = L::G::P); return p; }
 
-hipStream_t pick(OceanContext* c, void* stream) { return stream ? (hipStream_t)stream : c->stream; }
+hipStream_t pick(OceanContext* c, void* stream) {
+    if (stream && (hipStream_t)stream != c->stream) c->foreign_stream = true;
+    return stream ? (hipStream_t)stream : c->stream;
+}
+// Readbacks wait for the context stream; once a dispatch has been put on a caller stream they wait for the device
+// (the library cannot know whether that stream still exists, so it does not name it).
+hipError_t sync_for_readback(OceanContext* c) { return c->foreign_stream ? hipDeviceSynchronize() : hipStreamSynchronize(c->stream); }
 
 void launch_propagate(OceanContext* c, float time, float domain, hipStream_t s) {
     const unsigned grid = (unsigned)(((size_t)c->n * c->n / 2 + 255) / 256);
@@ -410,7 +426,7 @@ void free_all(OceanContext* c) {
     auto f = [](void* p) { if (p) (void)hipFree(p); };
     f(c->h0); f(c->omega); f(c->field[0]); f(c->field[1]); f(c->field[2]);
     f(c->cfield[0]); f(c->cfield[1]); f(c->cfield[2]);
-    f(c->h0T); f(c->omegaT); f(c->inter); f(c->nyq); f(c->tw); f(c->out_own); f(c->normals); f(c->positions);
+    f(c->h0T); f(c->omegaT); f(c->inter); f(c->nyq); f(c->tw); f(c->out_own); f(c->normals); f(c->positions); f(c->checksum_acc);
     if (c->ev_a) (void)hipEventDestroy(c->ev_a);
     if (c->ev_b) (void)hipEventDestroy(c->ev_b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -435,6 +451,7 @@ int32_t ocean_context_create(int32_t device, int32_t resolution, OceanContext** 
     if (!c) return fail(nullptr, OCEAN_E_OOM, "host allocation failed");
     c->device = device;
     c->n = resolution;
+    c->generation = g_generation.fetch_add(1);
     DeviceGuard guard(device);
     const size_t n2 = (size_t)resolution * resolution;
     c->P = frame_p(resolution);
@@ -627,6 +644,7 @@ int32_t ocean_fft_init(OceanContext* ctx, OceanFft** out) {
     OceanFft* f = new (std::nothrow) OceanFft();
     if (!f) return fail(ctx, OCEAN_E_OOM, "host allocation failed");
     f->ctx = ctx;
+    f->generation = ctx->generation;
     live_add(f);
     *out = f;
     return OCEAN_OK;
@@ -639,6 +657,7 @@ int32_t ocean_propagation_init(OceanContext* ctx, OceanPropagation** out) {
     OceanPropagation* p = new (std::nothrow) OceanPropagation();
     if (!p) return fail(ctx, OCEAN_E_OOM, "host allocation failed");
     p->ctx = ctx;
+    p->generation = ctx->generation;
     live_add(p);
     *out = p;
     return OCEAN_OK;
@@ -651,6 +670,7 @@ int32_t ocean_correction_init(OceanContext* ctx, OceanCorrection** out) {
     OceanCorrection* c = new (std::nothrow) OceanCorrection();
     if (!c) return fail(ctx, OCEAN_E_OOM, "host allocation failed");
     c->ctx = ctx;
+    c->generation = ctx->generation;
     live_add(c);
     *out = c;
     return OCEAN_OK;
@@ -733,7 +753,7 @@ int32_t ocean_read_normals(OceanContext* ctx, float* host_xyz0) {
     if (!host_xyz0) return fail(ctx, OCEAN_E_INVALID_ARG, "NULL output");
     if (!ctx->normals) return fail(ctx, OCEAN_E_STATE, "ocean_normals has not been called");
     DeviceGuard guard(ctx->device);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, sync_for_readback(ctx));
     HIP_TRY(ctx, hipMemcpy(host_xyz0, ctx->normals, (size_t)ctx->n * ctx->n * sizeof(float4), hipMemcpyDeviceToHost));
     return OCEAN_OK;
 }
@@ -760,7 +780,7 @@ int32_t ocean_read_positions(OceanContext* ctx, float* host_xyz1) {
     if (!host_xyz1) return fail(ctx, OCEAN_E_INVALID_ARG, "NULL output");
     if (!ctx->positions) return fail(ctx, OCEAN_E_STATE, "ocean_positions has not been called");
     DeviceGuard guard(ctx->device);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, sync_for_readback(ctx));
     HIP_TRY(ctx, hipMemcpy(host_xyz1, ctx->positions, (size_t)ctx->position_verts * ctx->position_verts * sizeof(float4),
                            hipMemcpyDeviceToHost));
     return OCEAN_OK;
@@ -773,12 +793,60 @@ int32_t ocean_sync(OceanContext* ctx) {
     return OCEAN_OK;
 }
 
+// ---- device-side consumers of the map: checksum (reproducibility tests), packed copies (final gather) ----------
+int32_t ocean_checksum_displacement(OceanContext* ctx, void* stream, uint64_t* out_sum) {
+    if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    if (!out_sum) return fail(ctx, OCEAN_E_INVALID_ARG, "NULL output");
+    DeviceGuard guard(ctx->device);
+    hipStream_t s = pick(ctx, stream);
+    if (!ctx->checksum_acc) HIP_TRY(ctx, hipMalloc((void**)&ctx->checksum_acc, sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->checksum_acc, 0, sizeof(unsigned long long), s));
+    const size_t vecs = (size_t)ctx->n * ctx->n;                     // one uint4 per RGBA32F texel
+    const unsigned grid = (unsigned)((vecs / 256 < 2048) ? (vecs / 256) : 2048);
+    hipLaunchKernelGGL(k_checksum, dim3(grid), dim3(256), 0, s, (const uint4*)ctx->out, vecs, ctx->checksum_acc);
+    { const int32_t st = check_launch(ctx, "k_checksum launch"); if (st != OCEAN_OK) return st; }
+    unsigned long long host = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&host, ctx->checksum_acc, sizeof host, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    *out_sum = (uint64_t)host;
+    return OCEAN_OK;
+}
+
+int64_t ocean_packed_bytes(const OceanContext* ctx, int32_t format) {
+    if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    const int64_t n2 = (int64_t)ctx->n * ctx->n;
+    switch (format) {
+        case OCEAN_PACK_RGBA32F: return n2 * 16;
+        case OCEAN_PACK_RGB32F: return n2 * 12;
+        case OCEAN_PACK_HEIGHT32F: return n2 * 4;
+        default: return OCEAN_E_INVALID_ARG;
+    }
+}
+int32_t ocean_pack_displacement(OceanContext* ctx, int32_t format, void* device_out, void* stream) {
+    if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    if (!device_out || (reinterpret_cast<uintptr_t>(device_out) & 15u))
+        return fail(ctx, OCEAN_E_INVALID_ARG, "packed output must be a 16-byte aligned device pointer");
+    if (format != OCEAN_PACK_RGBA32F && format != OCEAN_PACK_RGB32F && format != OCEAN_PACK_HEIGHT32F)
+        return fail(ctx, OCEAN_E_INVALID_ARG, "unknown pack format");
+    DeviceGuard guard(ctx->device);
+    hipStream_t s = pick(ctx, stream);
+    const size_t quads = (size_t)ctx->n * ctx->n / 4;
+    const unsigned grid = (unsigned)((quads + 255) / 256);
+    if (format == OCEAN_PACK_RGBA32F)
+        HIP_TRY(ctx, hipMemcpyAsync(device_out, ctx->out, quads * 64, hipMemcpyDeviceToDevice, s));
+    else if (format == OCEAN_PACK_RGB32F)
+        hipLaunchKernelGGL(k_pack_rgb32f, dim3(grid), dim3(256), 0, s, (const float4*)ctx->out, (float4*)device_out, quads);
+    else
+        hipLaunchKernelGGL(k_pack_height32f, dim3(grid), dim3(256), 0, s, (const float4*)ctx->out, (float4*)device_out, quads);
+    return check_launch(ctx, "k_pack launch");
+}
+
 // ---- readback / injection ---------------------------------------------------------------------
 int32_t ocean_read_displacement(OceanContext* ctx, float* host_rgba) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
     if (!host_rgba) return fail(ctx, OCEAN_E_INVALID_ARG, "NULL output");
     DeviceGuard guard(ctx->device);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, sync_for_readback(ctx));
     HIP_TRY(ctx, hipMemcpy(host_rgba, ctx->out, (size_t)ctx->n * ctx->n * sizeof(float4), hipMemcpyDeviceToHost));
     return OCEAN_OK;
 }
@@ -786,7 +854,11 @@ int32_t ocean_read_field(OceanContext* ctx, int32_t field, float* host_re_im) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
     if (!host_re_im || field < 0 || field > 2) return fail(ctx, OCEAN_E_INVALID_ARG, "bad field or NULL output");
     DeviceGuard guard(ctx->device);
-    launch_unchunk(ctx, field, ctx->stream);       // the field may live in the chunked hand-off layout: natural copy first
+    // The field may live in the chunked hand-off layout: natural copy first.  The un-chunk runs on the context stream,
+    // so whatever produced the chunked copy (possibly on a caller stream) has to be complete before it starts.
+    if (ctx->foreign_stream) HIP_TRY(ctx, hipDeviceSynchronize());
+    launch_unchunk(ctx, field, ctx->stream);
+    { const int32_t st = check_launch(ctx, "k_unchunk launch"); if (st != OCEAN_OK) return st; }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(host_re_im, ctx->field[field], (size_t)ctx->n * ctx->n * sizeof(c32), hipMemcpyDeviceToHost));
     return OCEAN_OK;
@@ -795,7 +867,7 @@ int32_t ocean_write_field(OceanContext* ctx, int32_t field, const float* host_re
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
     if (!host_re_im || field < 0 || field > 2) return fail(ctx, OCEAN_E_INVALID_ARG, "bad field or NULL input");
     DeviceGuard guard(ctx->device);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, sync_for_readback(ctx));
     HIP_TRY(ctx, hipMemcpy(ctx->field[field], host_re_im, (size_t)ctx->n * ctx->n * sizeof(c32), hipMemcpyHostToDevice));
     ctx->nat_valid[field] = true;
     ctx->chk_valid[field] = false;

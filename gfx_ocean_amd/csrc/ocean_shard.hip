@@ -10,6 +10,8 @@
 struct OceanShard {
     int device = 0, n = 0, rank = 0, world = 1, rows = 0;      // rows = columns per rank = n / world
     hipStream_t stream = nullptr;
+    hipEvent_t last = nullptr;    // recorded behind the most recent rows / cols launches on whichever stream they ran on:
+    bool last_valid = false;      // sync / upload / destroy wait for it (the caller's stream is never named again)
     c32* h0_own = nullptr;        // rows [rank rows, (rank+1) rows) of the initial spectrum
     c32* h0_partner = nullptr;    // rows [n - (rank+1) rows, n - rank rows): where the "-k" partners live (propagate.comp:48)
     float* omega = nullptr;       // own rows of the dispersion
@@ -76,7 +78,13 @@ template <int N> struct ShardLaunch {
 void shard_free_all(OceanShard* s) {
     auto f = [](void* p) { if (p) (void)hipFree(p); };
     f(s->h0_own); f(s->h0_partner); f(s->omega); f(s->fld[0]); f(s->fld[1]); f(s->fld[2]); f(s->tw);
+    if (s->last) (void)hipEventDestroy(s->last);
     if (s->stream) (void)hipStreamDestroy(s->stream);
+}
+// Everything this shard has launched, on its own stream or a caller's, has completed.
+hipError_t shard_wait_all(OceanShard* s) {
+    if (s->last_valid) { hipError_t e = hipEventSynchronize(s->last); if (e != hipSuccess) return e; }
+    return hipStreamSynchronize(s->stream);
 }
 
 }  // namespace
@@ -102,6 +110,7 @@ int32_t ocean_shard_create(int32_t device, int32_t resolution, int32_t rank, int
     auto bail = [&](hipError_t err, const char* what) { const int32_t c = shard_hip_fail(nullptr, err, what); shard_free_all(s); delete s; return c; };
 #define CREATE_TRY(expr) do { hipError_t e2_ = (expr); if (e2_ != hipSuccess) return bail(e2_, #expr); } while (0)
     CREATE_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreateWithFlags(&s->last, hipEventDisableTiming));
     CREATE_TRY(hipMalloc((void**)&s->h0_own, block * sizeof(c32)));
     CREATE_TRY(hipMalloc((void**)&s->h0_partner, block * sizeof(c32)));
     CREATE_TRY(hipMalloc((void**)&s->omega, block * sizeof(float)));
@@ -130,7 +139,7 @@ void ocean_shard_destroy(OceanShard* s) {
     if (!shard_live(s)) return;
     { std::lock_guard<std::mutex> l(g_shard_mu); g_shard_live.erase(s); }
     ShardDeviceGuard guard(s->device);
-    (void)hipStreamSynchronize(s->stream);
+    (void)shard_wait_all(s);
     shard_free_all(s);
     delete s;
 }
@@ -143,7 +152,7 @@ int32_t ocean_shard_upload(OceanShard* s, const float* h0_own_rows, const float*
     if (!h0_own_rows || !h0_partner_rows || !omega_own_rows) return shard_fail(s, OCEAN_E_INVALID_ARG, "NULL input");
     ShardDeviceGuard guard(s->device);
     const size_t block = (size_t)s->rows * s->n;
-    SHARD_TRY(s, hipStreamSynchronize(s->stream));
+    SHARD_TRY(s, shard_wait_all(s));              // frames in flight (on any stream) still read the old inputs
     SHARD_TRY(s, hipMemcpy(s->h0_own, h0_own_rows, block * sizeof(c32), hipMemcpyHostToDevice));
     SHARD_TRY(s, hipMemcpy(s->h0_partner, h0_partner_rows, block * sizeof(c32), hipMemcpyHostToDevice));
     SHARD_TRY(s, hipMemcpy(s->omega, omega_own_rows, block * sizeof(float), hipMemcpyHostToDevice));
@@ -169,6 +178,8 @@ int32_t ocean_shard_rows(OceanShard* s, const OceanPropagateLocals* locals, void
     for (int f = 0; f < 3; ++f) SHARD_DISPATCH(s->n, L::rows(s, f, (c32*)send_device, st));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return shard_hip_fail(s, e, "ocean_shard_rows launch");
+    SHARD_TRY(s, hipEventRecord(s->last, st));
+    s->last_valid = true;
     return OCEAN_OK;
 }
 
@@ -176,6 +187,7 @@ int32_t ocean_shard_cols(OceanShard* s, const void* recv_device, void* out_rgba_
     if (!shard_live(s)) return OCEAN_E_INVALID_ARG;
     if (!recv_device || !out_rgba_T_device) return shard_fail(s, OCEAN_E_INVALID_ARG, "NULL argument");
     if (reinterpret_cast<uintptr_t>(out_rgba_T_device) & 15u) return shard_fail(s, OCEAN_E_INVALID_ARG, "output must be 16-byte aligned");
+    if (!s->uploaded) return shard_fail(s, OCEAN_E_STATE, "ocean_shard_upload has not been called");
     ShardDeviceGuard guard(s->device);
     hipStream_t st = stream ? (hipStream_t)stream : s->stream;
     const int cols = s->rows;
@@ -192,13 +204,15 @@ int32_t ocean_shard_cols(OceanShard* s, const void* recv_device, void* out_rgba_
                        s->rank * cols, cols);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return shard_hip_fail(s, e, "ocean_shard_cols launch");
+    SHARD_TRY(s, hipEventRecord(s->last, st));
+    s->last_valid = true;
     return OCEAN_OK;
 }
 
 int32_t ocean_shard_sync(OceanShard* s) {
     if (!shard_live(s)) return OCEAN_E_INVALID_ARG;
     ShardDeviceGuard guard(s->device);
-    SHARD_TRY(s, hipStreamSynchronize(s->stream));
+    SHARD_TRY(s, shard_wait_all(s));
     return OCEAN_OK;
 }
 

@@ -10,6 +10,8 @@ from ._lib import OCEAN_OK, OceanError, load_library
 from .fft import FIELD_ALL, FIELD_DX, FIELD_DY, FIELD_DZ, Fft
 
 QUIRK_Q1, QUIRK_Q2, QUIRKS_REFERENCE = 1, 2, 3      # include/ocean_hip.h OCEAN_QUIRK_*
+PACK_RGBA32F, PACK_RGB32F, PACK_HEIGHT32F = 0, 1, 2   # include/ocean_hip.h OCEAN_PACK_*
+PACK_BYTES_PER_TEXEL = {PACK_RGBA32F: 16, PACK_RGB32F: 12, PACK_HEIGHT32F: 4}
 from .ocean import DOMAIN_SIZE, Correction, CorrectionLocals, Propagation, PropagateLocals
 
 
@@ -138,6 +140,24 @@ class OceanDevice:
         if data.shape != (n, n):
             raise OceanError(-1, f"expected ({n},{n}) array, got {data.shape}")
         self._check(load_library().ocean_write_field(self._ctx, int(field), data.ctypes.data))
+
+    def checksum(self, stream=None) -> int:
+        """Order-independent 64-bit checksum of the current displacement map, computed on the device
+        (ocean_checksum_displacement): equal maps <=> equal sums.  Synchronous."""
+        out = ctypes.c_uint64()
+        self._check(load_library().ocean_checksum_displacement(self._ctx, stream, ctypes.byref(out)))
+        return int(out.value)
+
+    def packed_bytes(self, fmt: int) -> int:
+        v = int(load_library().ocean_packed_bytes(self._ctx, int(fmt)))
+        if v < 0:
+            raise OceanError(v, "unknown pack format")
+        return v
+
+    def pack_displacement(self, fmt: int, device_ptr, stream=None):
+        """Packed copy of the current map into caller device memory (PACK_RGB32F: 12 B/texel, PACK_HEIGHT32F: 4):
+        the payload of the final gather of a multi-GPU run."""
+        self._check(load_library().ocean_pack_displacement(self._ctx, int(fmt), device_ptr, stream))
 
     def displacement_device_ptr(self) -> int:
         return int(load_library().ocean_displacement_device_ptr(self._ctx) or 0)

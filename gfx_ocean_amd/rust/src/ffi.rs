@@ -49,6 +49,9 @@ extern "C" {
     pub fn ocean_positions(ctx: *mut OceanContext, verts: i32, offset_x: f32, offset_z: f32, stream: *mut c_void) -> i32;
     pub fn ocean_read_positions(ctx: *mut OceanContext, host_xyz1: *mut f32) -> i32;
     pub fn ocean_sync(ctx: *mut OceanContext) -> i32;
+    pub fn ocean_checksum_displacement(ctx: *mut OceanContext, stream: *mut c_void, out_sum: *mut u64) -> i32;
+    pub fn ocean_packed_bytes(ctx: *const OceanContext, format: i32) -> i64;
+    pub fn ocean_pack_displacement(ctx: *mut OceanContext, format: i32, device_out: *mut c_void, stream: *mut c_void) -> i32;
     pub fn ocean_set_quirks(ctx: *mut OceanContext, quirks: u32) -> i32;
     pub fn ocean_quirks(ctx: *const OceanContext) -> u32;
     pub fn ocean_read_displacement(ctx: *mut OceanContext, host_rgba: *mut f32) -> i32;

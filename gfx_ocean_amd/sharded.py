@@ -104,6 +104,11 @@ class ShardedTile:
     GPUs, gloo in the CPU tests); None (world == 1 only) skips the collective."""
 
     def __init__(self, backend, dist=None, domain_size: float = DOMAIN_SIZE):
+        if dist is None and backend.world != 1:
+            # without a process group the send buffer would be consumed as if it were the column block: a wrong tile,
+            # silently.  (Multi-rank RCCL runs of the shard are unmeasured until a box with >= 2 GPUs runs them; the
+            # multi-rank kernels themselves are checked on one device, tests/test_sharded.py.)
+            raise OceanError(-1, f"ShardedTile: world = {backend.world} needs an initialised torch.distributed (dist=None is world 1 only)")
         self.b, self.dist, self.domain_size = backend, dist, float(domain_size)
         self.send = backend.alloc_exchange()
         self.recv = backend.alloc_exchange()

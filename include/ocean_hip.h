@@ -18,7 +18,10 @@
  *     replacing the reference's Rgba32Sfloat storage image (src/render.rs:820-869).
  *   - `stream` is a `hipStream_t` passed as `void*`; NULL = the context's own
  *     stream.  Stream order replaces the reference's pipeline barriers
- *     (src/render.rs:1132-1156,1181-1208,1233-1278,1289-1310).
+ *     (src/render.rs:1132-1156,1181-1208,1233-1278,1289-1310).  The staged calls keep
+ *     per-field layout state on the host: issue the calls of one field on ONE stream.
+ *     The synchronous readbacks (ocean_read_*) wait for the context stream, and for the
+ *     whole device once any dispatch of this context has been put on a caller stream.
  *   - A context is bound to one GPU and is not thread-safe (the reference is
  *     single-threaded: winit loop, src/lib.rs:100-170).  One context per GPU for
  *     tile-parallel runs.
@@ -32,7 +35,9 @@
 extern "C" {
 #endif
 
-#define OCEAN_ABI_VERSION 1
+/* 2: + ocean_checksum_displacement, ocean_pack_displacement, ocean_packed_bytes, the ocean_shard_* family (additive);
+ *    readbacks wait for the whole device once a dispatch has been put on a caller stream */
+#define OCEAN_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------------------------- */
 #define OCEAN_OK 0
@@ -149,6 +154,20 @@ int32_t ocean_sync(OceanContext* ctx); /* wait for the context stream (the refer
 int32_t ocean_read_displacement(OceanContext* ctx, float* host_rgba /* N*N*4 */);
 int32_t ocean_read_field(OceanContext* ctx, int32_t field, float* host_re_im /* N*N*2 */);
 int32_t ocean_write_field(OceanContext* ctx, int32_t field, const float* host_re_im);
+
+/* ---- device-side consumers of the displacement map ----------------------------------------------- */
+/* Order-independent 64-bit checksum of the current map (sum of (word + c) * (2 index + 1) over its 32-bit words,
+ * mod 2^64), computed on the device behind whatever `stream` holds: equal maps <=> equal sums whatever the launch
+ * geometry.  Used to assert that repeated frames are bit-identical without reading N*N*16 bytes back (SURVEY 5:
+ * the race discipline the reference gets from its barrier chain, shader/fft_row.comp:48-59).  Synchronous. */
+int32_t ocean_checksum_displacement(OceanContext* ctx, void* stream, uint64_t* out_sum);
+/* Packed copies of the map for the final gather of a multi-GPU run (N*N*16 B per tile and frame
+ * RGBA32F; 12 without the always-zero alpha of shader/correction.comp:31-34; 4 height only). */
+#define OCEAN_PACK_RGBA32F 0  /* plain copy, 16 B/texel */
+#define OCEAN_PACK_RGB32F 1   /* (disp_x, height, disp_z), 12 B/texel */
+#define OCEAN_PACK_HEIGHT32F 2 /* height, 4 B/texel */
+int64_t ocean_packed_bytes(const OceanContext* ctx, int32_t format);   /* < 0: error status */
+int32_t ocean_pack_displacement(OceanContext* ctx, int32_t format, void* device_out /* 16-byte aligned */, void* stream);
 
 /* ---- zero-copy hooks for device-side consumers ----------------------------------------------- */
 void* ocean_displacement_device_ptr(OceanContext* ctx);           /* float4[N*N] in HBM */

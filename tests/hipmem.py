@@ -1,0 +1,61 @@
+"""Raw device memory for the GPU tests, straight from the HIP runtime libocean_hip.so is linked against (ctypes on
+libamdhip64: no torch in the test process, so there is exactly one HIP runtime in it)."""
+import ctypes
+
+import numpy as np
+
+_HIP = None
+
+
+def hip():
+    global _HIP
+    if _HIP is None:
+        import gfx_ocean_amd as g
+        g.load_library()                                    # pulls in /opt/rocm's libamdhip64 first
+        _HIP = ctypes.CDLL("libamdhip64.so")
+        _HIP.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+        _HIP.hipFree.argtypes = [ctypes.c_void_p]
+        _HIP.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        _HIP.hipMemset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
+        _HIP.hipDeviceSynchronize.argtypes = []
+    return _HIP
+
+
+class DeviceBuffer:
+    """hipMalloc'ed bytes; .ptr is the device address the C ABI takes."""
+
+    def __init__(self, nbytes: int):
+        p = ctypes.c_void_p()
+        st = hip().hipMalloc(ctypes.byref(p), int(nbytes))
+        assert st == 0, f"hipMalloc({nbytes}) -> {st}"
+        self.ptr, self.nbytes = p.value, int(nbytes)
+
+    def to_host(self, dtype=np.float32, nbytes=None) -> np.ndarray:
+        nbytes = self.nbytes if nbytes is None else nbytes
+        out = np.empty(nbytes // np.dtype(dtype).itemsize, dtype)
+        assert hip().hipDeviceSynchronize() == 0
+        assert hip().hipMemcpy(out.ctypes.data, self.ptr, nbytes, 2) == 0          # hipMemcpyDeviceToHost
+        return out
+
+    def from_host(self, a: np.ndarray, offset: int = 0):
+        a = np.ascontiguousarray(a)
+        assert offset + a.nbytes <= self.nbytes
+        assert hip().hipMemcpy(self.ptr + offset, a.ctypes.data, a.nbytes, 1) == 0  # hipMemcpyHostToDevice
+
+    def copy_from_device(self, src_ptr: int, nbytes: int, offset: int = 0):
+        assert offset + nbytes <= self.nbytes
+        assert hip().hipMemcpy(self.ptr + offset, src_ptr, nbytes, 3) == 0          # hipMemcpyDeviceToDevice
+
+    def fill(self, byte: int = 0):
+        assert hip().hipMemset(self.ptr, byte, self.nbytes) == 0
+
+    def free(self):
+        if self.ptr:
+            hip().hipFree(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -10,6 +10,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 import bench
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -74,6 +76,28 @@ def test_plain_gpus_2_self_launches_two_ranks():
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     r = _check_two_rank_line(p.stdout)
     _overlapped_schedule_is_double_buffered(r["gather_log"], 4)
+
+
+@pytest.mark.parametrize("fmt,floats", [("rgb32f", 3), ("height32f", 1)])
+def test_packed_gather_formats(fmt, floats):
+    """VERDICT r02 #8 / SURVEY 8e: the gather can ship 12 (alpha dropped) or 4 (height) instead of 16 B/texel.  Byte
+    counts, slot order and that every gathered buffer was packed on the compute stream right behind its frame."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--plumbing", "--gather-steps", "4", "--gather-format", fmt],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    gth, log = r["gather"], r["gather_log"]
+    assert gth["format"] == fmt and gth["bytes_per_peer_per_frame"] == 64 * 64 * 4 * floats
+    assert gth["peer_tile_first_texel"] == [1.0, 2.0]
+    frames = [k for k, e in enumerate(log) if e[0] == "frame"]
+    packs = [k for k, e in enumerate(log) if e[0] == "pack"]
+    assert len(frames) == len(packs) and all(pk == fk + 1 for fk, pk in zip(frames, packs))
+    assert all(log[k][1] == "compute" and log[k][2] == bench.GATHER_FORMATS[fmt][0] for k in packs)
+    tail = [log[k][3] for k in packs[-4:]]                      # overlapped run: two packed buffers, alternating
+    assert tail[0] == tail[2] and tail[1] == tail[3] and tail[0] != tail[1]
 
 
 def test_two_ranks_under_torch_distributed_run():
