@@ -201,10 +201,10 @@ template <int N> struct Launch {
         using H = Geo<N, PSEL>;
         hipError_t e = hipSuccess;
         if constexpr (plain_built<PSEL>()) {
-            e = hipFuncSetAttribute((const void*)k_half_pass1<N, H::E1, H::P, false>,
+            e = hipFuncSetAttribute((const void*)k_half_pass1<N, H::E1, H::P, false, H::handover>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, H::frame_lds);
             if (e != hipSuccess) return e;
-            e = hipFuncSetAttribute((const void*)k_half_pass1<N, H::E1, H::P, true>,
+            e = hipFuncSetAttribute((const void*)k_half_pass1<N, H::E1, H::P, true, H::handover>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, H::frame_lds);
             if (e != hipSuccess) return e;
             e = hipFuncSetAttribute((const void*)k_half_pass2<N, H::E, CHUNK_W, H::R2, H::p2_group>,
@@ -212,10 +212,10 @@ template <int N> struct Launch {
             if (e != hipSuccess) return e;
         }
         if constexpr (split_built<PSEL>()) {
-            e = hipFuncSetAttribute((const void*)k_half_pass1_split<N, H::E1S, H::P, false>,
+            e = hipFuncSetAttribute((const void*)k_half_pass1_split<N, H::E1S, H::P, false, H::handover>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, H::split_lds1);
             if (e != hipSuccess) return e;
-            e = hipFuncSetAttribute((const void*)k_half_pass1_split<N, H::E1S, H::P, true>,
+            e = hipFuncSetAttribute((const void*)k_half_pass1_split<N, H::E1S, H::P, true, H::handover>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, H::split_lds1);
             if (e != hipSuccess) return e;
             e = hipFuncSetAttribute((const void*)k_half_pass2_split<N, H::E, CHUNK_W, H::p2_group>,
@@ -229,11 +229,11 @@ template <int N> struct Launch {
         if constexpr (split_built<PSEL>()) {
             if (c->split) {
                 if (c->h0_f16)
-                    launch(k_half_pass1_split<N, H::E1S, H::P, true>, dim3(H::half_grid1), dim3(H::split_threads1),
+                    launch(k_half_pass1_split<N, H::E1S, H::P, true, H::handover>, dim3(H::half_grid1), dim3(H::split_threads1),
                            H::split_lds1, s, t, (const void*)c->h0T, descale, (const float*)c->omegaT, c->inter, c->nyq,
                            (const c32*)c->tw, c->lay_h, time, domain);
                 else
-                    launch(k_half_pass1_split<N, H::E1S, H::P, false>, dim3(H::half_grid1), dim3(H::split_threads1),
+                    launch(k_half_pass1_split<N, H::E1S, H::P, false, H::handover>, dim3(H::half_grid1), dim3(H::split_threads1),
                            H::split_lds1, s, t, (const void*)c->h0T, 1.0f, (const float*)c->omegaT, c->inter, c->nyq,
                            (const c32*)c->tw, c->lay_h, time, domain);
                 return;
@@ -241,11 +241,11 @@ template <int N> struct Launch {
         }
         if constexpr (plain_built<PSEL>()) {
             if (c->h0_f16)
-                launch(k_half_pass1<N, H::E1, H::P, true>, dim3(H::half_grid1), dim3(H::half_threads1), H::frame_lds, s, t,
+                launch(k_half_pass1<N, H::E1, H::P, true, H::handover>, dim3(H::half_grid1), dim3(H::half_threads1), H::frame_lds, s, t,
                        (const void*)c->h0T, descale, (const float*)c->omegaT, c->inter, c->nyq, (const c32*)c->tw,
                        c->lay_h, time, domain);
             else
-                launch(k_half_pass1<N, H::E1, H::P, false>, dim3(H::half_grid1), dim3(H::half_threads1), H::frame_lds, s, t,
+                launch(k_half_pass1<N, H::E1, H::P, false, H::handover>, dim3(H::half_grid1), dim3(H::half_threads1), H::frame_lds, s, t,
                        (const void*)c->h0T, 1.0f, (const float*)c->omegaT, c->inter, c->nyq, (const c32*)c->tw,
                        c->lay_h, time, domain);
         }

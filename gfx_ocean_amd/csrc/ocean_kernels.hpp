@@ -720,6 +720,121 @@ __device__ __forceinline__ void half_load_AB(const void* __restrict__ h0T_, floa
     }
 }
 
+// half_load_AB with the intra-workgroup duplicate streams handed over through LDS instead of re-read from memory.
+// Column x + 1 of a workgroup asks for two lines its left neighbour x asks for as well:
+//     own2 (x + 1) = h0T[N - x - 1][.] = mirror (x),      mirror2 (x + 1) = h0T[x][.] = own (x),
+// displaced by one element:  a2(c, y) = m(c - 1, (y - 1) % N),   m2(c, y) = a(c - 1, (y - 1) % N)
+// (a = own[y], m = mirror[N - 1 - y] as loaded by the thread of column c - 1 that sits at position y - 1).  In the
+// lock-step load phase of 256 one-per-CU workgroups those twin requests are issued within a microsecond of each other
+// and mostly miss the L2 together (counters, DESIGN 4.4: 269 MB fetched where the distinct lines of the workgroups are
+// 235 MB; at N = 8192 every line twice).  The LDS is idle during the load phase, so, per load batch of PER elements:
+//   * columns 0 .. P-2 park (a, m) of their elements (16 bytes each) in region c + 1 of a batch buffer, one slot to the
+//     right of their own position;
+//   * region 0 is column 0's left neighbour, which lives in another workgroup: all threads of the workgroup together
+//     load the batch's stretch of its two lines (own2 / mirror2 of column 0: one pair per thread when PER == P);
+//   * ONE barrier; then every column reads (m2, a2) of its PER elements from its region -- no column-dependent control
+//     flow (branches around the loads cost 25-50 spilled VGPRs at the 128-register budget of this kernel).
+// Slot 0 of regions 1 .. P-1 is position y0 - 1 of the line, which belongs to the previous batch (to the end of the
+// line for y0 = 0): lane j == 0 takes that pair from memory -- a wave-uniform address, i.e. a scalar load.
+// Two batch buffers make one barrier per batch enough: batch b + 2 overwrites buffer b & 1 only after barrier b + 1,
+// which every thread reaches after its reads of batch b.
+template <int N, int E, int P, bool H16>
+__device__ __forceinline__ void half_load_AB_handover(const void* __restrict__ h0T_, float descale, const float* __restrict__ omegaT,
+                                                      uint32_t x, int c, int j, int tid, float time, float4* xbuf,
+                                                      c32 (&A)[E], c32 (&B)[E]) {
+    typedef typename Spec<H16>::elem Sp;
+    constexpr int T = N / E;
+    const Sp* h0T = reinterpret_cast<const Sp*>(h0T_);
+    const uint32_t x0 = x - (uint32_t)c;                           // the workgroup's first column
+    const uint32_t x2 = (N - x) & (N - 1);
+    const uint32_t xm = (x - 1u) & (N - 1);
+    const Sp* own = h0T + (size_t)x * N;
+    const Sp* mir = h0T + (size_t)(N - 1 - x) * N;
+    const Sp* nb_own2 = h0T + (size_t)((N - x0) & (N - 1)) * N;    // column 0's own2 and mirror2 lines (region 0)
+    const Sp* nb_mir2 = h0T + (size_t)((x0 - 1u) & (N - 1)) * N;
+    const float* om = omegaT + (size_t)x * N;
+    const float* om2 = omegaT + (size_t)x2 * N;
+    constexpr int LOAD_BATCHES = 4;
+    constexpr int PER = E / LOAD_BATCHES;
+    constexpr int SPAN = PER * T;                                  // positions of a line per batch
+    constexpr int THREADS = P * T;
+    constexpr int REG = SPAN + 4;                                  // slots per region (+1 for the shift, padded)
+    constexpr int BUF = P * REG;                                   // one batch buffer
+    static_assert(2 * BUF * (int)sizeof(float4) <= P * LinePitch<N>::elems * (int)sizeof(c32), "hand-over buffers fit the line buffers");
+    static_assert(SPAN % THREADS == 0 || THREADS % SPAN == 0, "region 0 is loaded by whole rounds of the workgroup");
+    constexpr int NB_ROUNDS = (SPAN + THREADS - 1) / THREADS;
+    // Software-pipelined by one batch: the loads of batch b + 1 are issued before the barrier of batch b (behind the
+    // arithmetic that frees batch b's own / mirror / omega registers), so that the memory system is never left without
+    // requests while the workgroup meets at a barrier.
+    c32 a[PER], m[PER];
+    float w[PER], w2[PER];
+    c32 nb_n2[NB_ROUNDS], nb_o2[NB_ROUNDS];
+    auto issue = [&](int b, int jq, int tq) {
+#pragma unroll
+        for (int t = 0; t < PER; ++t) {
+            const int e = b * PER + t;
+            a[t] = Spec<H16>::load((own + e * T) + jq, descale);
+            m[t] = Spec<H16>::load((mir + (N - 1 - (e + 1) * T + 1)) + (T - 1 - jq), descale);   // mir[N - 1 - y]
+            w[t] = OCEAN_OMEGA_LOAD((om + e * T) + jq);
+        }
+        // region 0: (m2, a2) of column 0 at positions y0 + k, k < SPAN
+#pragma unroll
+        for (int r = 0; r < NB_ROUNDS; ++r) {
+            const int y = b * SPAN + tq + r * THREADS;
+            nb_n2[r] = Spec<H16>::load(nb_mir2 + ((y - 1) & (N - 1)), descale);    // mirror2[y - 1]
+            nb_o2[r] = Spec<H16>::load(nb_own2 + ((N - y) & (N - 1)), descale);    // own2[N - y]
+        }
+    };
+    auto issue_w2 = [&](int b, int jq) {
+#pragma unroll
+        for (int t = 0; t < PER; ++t) {
+            const int e = b * PER + t;
+            if (e == 0) w2[t] = OCEAN_OMEGA_LOAD((omegaT + (size_t)x2 * N) + ((N - jq) & (N - 1)));   // y may be 0: (N - y) % N wraps
+            else w2[t] = OCEAN_OMEGA_LOAD((om2 + (N - (e + 1) * T)) + (T - jq));
+        }
+    };
+    issue(0, j, tid);
+    issue_w2(0, j);
+#pragma unroll
+    for (int b = 0; b < LOAD_BATCHES; ++b) {
+        const int y0 = b * SPAN;                                   // a constant per unrolled batch
+        float4* buf = xbuf + (b & 1) * BUF;
+#pragma unroll
+        for (int r = 0; r < NB_ROUNDS; ++r) {
+            const int k = tid + r * THREADS;
+            if (SPAN % THREADS == 0 || k < SPAN) buf[k] = make_float4(nb_n2[r].x, nb_n2[r].y, nb_o2[r].x, nb_o2[r].y);
+        }
+        // slot 0 of the other regions (position y0 - 1 of the left neighbour's lines)
+        const c32 edge_a2 = Spec<H16>::load(h0T + (size_t)x2 * N + ((N - y0) & (N - 1)), descale);
+        const c32 edge_m2 = Spec<H16>::load(h0T + (size_t)xm * N + ((y0 - 1) & (N - 1)), descale);
+        if (c < P - 1) {                                           // stores only: nothing is defined inside the branch
+            float4* dst = buf + (c + 1) * REG + 1 + j;
+#pragma unroll
+            for (int t = 0; t < PER; ++t) dst[t * T] = make_float4(a[t].x, a[t].y, m[t].x, m[t].y);
+        }
+#pragma unroll
+        for (int t = 0; t < PER; ++t) A[b * PER + t] = propagate_height(a[t], m[t], w[t], time);   // frees a, m, w
+        float w2c[PER];
+#pragma unroll
+        for (int t = 0; t < PER; ++t) w2c[t] = w2[t];
+        if (b + 1 < LOAD_BATCHES) {                                // next batch's loads, behind this batch's arithmetic
+            const float dep = A[b * PER + PER - 1].x + A[b * PER].y;
+            issue(b + 1, opaque_after(j, dep), opaque_after(tid, dep));
+        }
+        __syncthreads();
+        const float4* src = buf + c * REG + j;
+        const bool edge = (j == 0) && (c > 0);                     // region 0 holds column 0's true left neighbour, unshifted
+#pragma unroll
+        for (int t = 0; t < PER; ++t) {
+            const float4 v = src[t * T];
+            c32 m2 = mk(v.x, v.y), a2 = mk(v.z, v.w);
+            if (t == 0) { m2 = edge ? edge_m2 : m2; a2 = edge ? edge_a2 : a2; }
+            B[b * PER + t] = cconj(propagate_height(a2, m2, w2c[t], time));
+        }
+        if (b + 1 < LOAD_BATCHES) issue_w2(b + 1, opaque_after(j, B[b * PER + PER - 1].y));
+    }
+}
+
 // A/B variant of half_load_AB (whole lines, S = 1): every line of the spectrum is asked for twice within a microsecond --
 // own[x + c] by wave group c and mirror2 of column x + c + 1 by wave group c + 1 (the next workgroup for c = 3), likewise
 // mirror / own2 -- and most of those pairs miss the L2 together.  Here the second-use streams (own2,
@@ -836,7 +951,7 @@ __device__ __forceinline__ void nyquist_spectra(const void* __restrict__ h0T, fl
 template <int E> constexpr int pass1_waves_per_simd(int threads) {
     return (E == 16) ? ((threads >= 512) ? 4 : 1) : ((threads / 256) > 1 ? (threads / 256) : 1);
 }
-template <int N, int E, int P, bool H16>
+template <int N, int E, int P, bool H16, bool HAND = false>
 __global__ void __launch_bounds__((N / E) * P, pass1_waves_per_simd<E>((N / E) * P))
 k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restrict__ omegaT, c32* __restrict__ inter,
              c32* nyq_spec, const c32* __restrict__ tw, InterLayout lay, float time, float domain_size) {
@@ -867,7 +982,8 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
 #ifdef OCEAN_SKEW_DUP
     half_load_AB_skewed<N, E, H16>(h0T, descale, omegaT, x, j, time, A, B);
 #else
-    half_load_AB<N, E, H16>(h0T, descale, omegaT, x, j, time, A, B);
+    if constexpr (HAND) half_load_AB_handover<N, E, P, H16>(h0T, descale, omegaT, x, c, j, tid, time, reinterpret_cast<float4*>(smem), A, B);
+    else half_load_AB<N, E, H16>(h0T, descale, omegaT, x, j, time, A, B);
 #endif
     OCEAN_TL(1);
     const c32 kxv = mk(wave_index_q1(x, N), wave_index_q1(x2, N)) * kscale;
@@ -896,7 +1012,7 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
                 reg[e] = cadd_i(reg[e], z[e * T]);                 // + i * Sn
             }
         }
-        if (ff > 0) __syncthreads();
+        if (HAND || ff > 0) __syncthreads();                      // the line buffers' previous readers (hand-over / chunk stores) are done
 #ifdef OCEAN_X_NOFFT   // timing experiment only (wrong results): the transform replaced by its final LDS scatter
         {
             c32* g = lds_line + lds_pad(jf);
@@ -1014,6 +1130,141 @@ __device__ __forceinline__ void half_load_AB_pairs(const void* __restrict__ h0T_
     __syncthreads();                                               // the exchange buffer is the FFT's line buffer next
 }
 
+// half_load_AB_pairs with the hand-over of half_load_AB_handover: the workgroup's second column takes its own2 / mirror2
+// pairs from what the first column loaded as mirror / own (at N = 8192 every 64 KiB spectrum line was fetched twice:
+// 1306 MB where 940 MB are the workgroups' distinct lines).  Per batch of PER pair loads, column 0 parks
+// (a0, a1) and (m0, m1) by position in one of two batch buffers; after the batch's barrier column 1 reads positions
+// y - 1 and y:  n0 = a(y0 - 1), n1 = a(y0), b0 = m(y0 - 1), b1 = m(y0).  The parity exchange of half_load_AB_pairs
+// moves into the same loop (two batch buffers as well; batch b's exchange is read behind barrier b + 1), so the load
+// phase has NB + 2 barriers instead of 2.  Position y0 - 1 of a batch's first pair belongs to the previous batch: that
+// lane takes the pair from memory (a wave-uniform address: scalar loads).
+template <int N, int E, bool H16, int THREADS>
+__device__ __forceinline__ void half_load_AB_pairs_handover(const void* __restrict__ h0T_, float descale,
+                                                            const float* __restrict__ omegaT, uint32_t x, int j, int p, int c,
+                                                            int tid, float time, float4* lds4, c32 (&A)[E], c32 (&B)[E]) {
+    typedef typename Spec<H16>::elem Sp;
+    constexpr int TS = N / (2 * E);                                // threads per sub-line
+    constexpr int EH = E / 2;
+    constexpr int PER = 2;                                         // pair loads per batch
+    constexpr int NB = EH / PER;
+    constexpr int XB = PER * THREADS;                              // parity exchange: 16-byte slots per batch
+    constexpr int DP = 2 * PER * TS;                               // pairs column 0 loads per batch (both parities' spans)
+    static_assert(THREADS == 4 * TS, "two columns of two sub-lines");
+    static_assert((2 * XB + 4 * DP) * (int)sizeof(float4) <= 4 * LinePitch<N / 2>::elems * (int)sizeof(c32), "exchange buffers fit the line buffers");
+    float4* xchg = lds4;                                           // [2][PER][THREADS]
+    float4* dupA = lds4 + 2 * XB;                                  // [2][DP]: (a(2m), a(2m + 1)) of column 0
+    float4* dupM = dupA + 2 * DP;                                  // [2][DP]: (m(2m), m(2m + 1))
+    const Sp* h0T = reinterpret_cast<const Sp*>(h0T_);
+    const uint32_t x2 = (N - x) & (N - 1);
+    const uint32_t xm = (x - 1u) & (N - 1);
+    const int e0 = EH * p;                                         // this thread loads m = j + (e0 + t) TS, t < EH
+    const Sp* own = h0T + (size_t)x * N + 2 * e0 * TS;             // pair at 2m
+    const Sp* mir = h0T + (size_t)(N - 1 - x) * N - 2 * e0 * TS;   // pair at N - 2 - 2m
+    const Sp* own2 = h0T + (size_t)x2 * N - 2 * e0 * TS;           // pair at N - 1 - 2m
+    const Sp* mir2 = h0T + (size_t)xm * N + 2 * e0 * TS;           // pair at 2m - 1
+    const float* om = omegaT + (size_t)x * N + 2 * e0 * TS;
+    const float* om2 = omegaT + (size_t)x2 * N - 2 * e0 * TS;
+    c32 mineA[EH], mineB[EH];
+    int jj = j;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        if (b > 0) jj = opaque_after(j, mineA[b * PER - 1].x + mineB[b * PER - 1].y);
+        c32 a0[PER], a1[PER], m0[PER], m1[PER], b0[PER], b1[PER], n0[PER], n1[PER];
+        float w0[PER], w1[PER], v0[PER], v1[PER];
+#pragma unroll
+        for (int tb = 0; tb < PER; ++tb) {
+            const int t = b * PER + tb;
+            Spec<H16>::load2((own + 2 * t * TS) + 2 * jj, descale, a0[tb], a1[tb]);
+            Spec<H16>::load2((mir + (N - 2 * (t + 1) * TS)) + 2 * (TS - 1 - jj), descale, m1[tb], m0[tb]);   // mir[N-2-2m], mir[N-1-2m]
+            { const float* wp = (om + 2 * t * TS) + 2 * jj; w0[tb] = OCEAN_OMEGA_LOAD(wp); w1[tb] = OCEAN_OMEGA_LOAD(wp + 1); }
+            if (t == 0) {                                          // m may be 0: y2 = (N - y) % N wraps
+                const int y0 = 2 * (jj + e0 * TS), y1 = y0 + 1;
+                const float* o2 = omegaT + (size_t)x2 * N;
+                v0[tb] = OCEAN_OMEGA_LOAD(o2 + ((N - y0) & (N - 1))); v1[tb] = OCEAN_OMEGA_LOAD(o2 + ((N - y1) & (N - 1)));
+            } else {
+                const float* wp = (om2 + (N - 1 - 2 * (t + 1) * TS)) + 2 * (TS - jj);
+                v1[tb] = OCEAN_OMEGA_LOAD(wp); v0[tb] = OCEAN_OMEGA_LOAD(wp + 1);
+            }
+        }
+        // position y - 1 of the batch's first pair (previous batch / end of the line): wave-uniform, scalar loads
+        const int ye = 2 * (e0 + b * PER) * TS;
+        const c32 edge_n0 = Spec<H16>::load(h0T + (size_t)xm * N + ((ye - 1) & (N - 1)), descale);
+        const c32 edge_b0 = Spec<H16>::load(h0T + (size_t)x2 * N + ((N - ye) & (N - 1)), descale);
+        float4* dA = dupA + (b & 1) * DP + p * (PER * TS) + jj;
+        float4* dM = dupM + (b & 1) * DP + p * (PER * TS) + jj;
+        if (c == 0) {                                              // wave-uniform: the first column's own2 / mirror2 come from memory
+#pragma unroll
+            for (int tb = 0; tb < PER; ++tb) {
+                const int t = b * PER + tb;
+                if (t == 0) {
+                    const int y0 = 2 * (jj + e0 * TS), y1 = y0 + 1;
+                    const Sp* r2 = h0T + (size_t)x2 * N;
+                    const Sp* rm = h0T + (size_t)xm * N;
+                    b0[tb] = Spec<H16>::load(r2 + ((N - y0) & (N - 1)), descale); b1[tb] = Spec<H16>::load(r2 + ((N - y1) & (N - 1)), descale);
+                    n0[tb] = Spec<H16>::load(rm + ((y0 - 1) & (N - 1)), descale); n1[tb] = Spec<H16>::load(rm + y0, descale);
+                } else {
+                    Spec<H16>::load2((own2 + (N - 1 - 2 * (t + 1) * TS)) + 2 * (TS - jj), descale, b1[tb], b0[tb]);   // own2[N-1-2m], own2[N-2m]
+                    Spec<H16>::load2((mir2 + (2 * t * TS - 1)) + 2 * jj, descale, n0[tb], n1[tb]);                      // mir2[2m-1], mir2[2m]
+                }
+                dA[tb * TS] = make_float4(a0[tb].x, a0[tb].y, a1[tb].x, a1[tb].y);
+                dM[tb * TS] = make_float4(m0[tb].x, m0[tb].y, m1[tb].x, m1[tb].y);
+            }
+        }
+        c32 Aev[PER], Aod[PER];
+#pragma unroll
+        for (int tb = 0; tb < PER; ++tb) {                         // before the barrier: frees a, m, w
+            Aev[tb] = propagate_height(a0[tb], m0[tb], w0[tb], time);
+            Aod[tb] = propagate_height(a1[tb], m1[tb], w1[tb], time);
+        }
+        __syncthreads();
+        if (b > 0) {                                               // the previous batch's parity exchange
+#pragma unroll
+            for (int tb = 0; tb < PER; ++tb) {
+                const int t = (b - 1) * PER + tb;
+                const float4 r = xchg[((b - 1) & 1) * XB + tb * THREADS + (tid ^ TS)];
+                const c32 rA = mk(r.x, r.y), rB = mk(r.z, r.w);
+                A[t] = p ? rA : mineA[t];
+                B[t] = p ? rB : mineB[t];
+                A[EH + t] = p ? mineA[t] : rA;
+                B[EH + t] = p ? mineB[t] : rB;
+            }
+        }
+        if (c != 0) {
+#pragma unroll
+            for (int tb = 0; tb < PER; ++tb) {
+                const bool first = (tb == 0) && (jj == 0);
+                const float4 ca = dA[tb * TS], cm = dM[tb * TS];
+                const float4 pa = dA[tb * TS - (first ? 0 : 1)], pm = dM[tb * TS - (first ? 0 : 1)];
+                n1[tb] = mk(ca.x, ca.y);                            // a(y0)
+                b1[tb] = mk(cm.x, cm.y);                            // m(y0)
+                n0[tb] = first ? edge_n0 : mk(pa.z, pa.w);          // a(y0 - 1)
+                b0[tb] = first ? edge_b0 : mk(pm.z, pm.w);          // m(y0 - 1)
+            }
+        }
+#pragma unroll
+        for (int tb = 0; tb < PER; ++tb) {
+            const int t = b * PER + tb;
+            const c32 Bev = cconj(propagate_height(b0[tb], n0[tb], v0[tb], time)), Bod = cconj(propagate_height(b1[tb], n1[tb], v1[tb], time));
+            mineA[t] = p ? Aod[tb] : Aev[tb];
+            mineB[t] = p ? Bod : Bev;
+            const c32 sA = p ? Aev[tb] : Aod[tb], sB = p ? Bev : Bod;
+            xchg[(b & 1) * XB + tb * THREADS + tid] = make_float4(sA.x, sA.y, sB.x, sB.y);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tb = 0; tb < PER; ++tb) {
+        const int t = (NB - 1) * PER + tb;
+        const float4 r = xchg[((NB - 1) & 1) * XB + tb * THREADS + (tid ^ TS)];
+        const c32 rA = mk(r.x, r.y), rB = mk(r.z, r.w);
+        A[t] = p ? rA : mineA[t];
+        B[t] = p ? rB : mineB[t];
+        A[EH + t] = p ? mineA[t] : rA;
+        B[EH + t] = p ? mineB[t] : rB;
+    }
+    __syncthreads();                                               // the exchange buffers are the FFT's line buffers next
+}
+
 // The same pass for lines too long for a three-pass plan (N = 8192 = 2 * 16^3): every column is transformed
 // as TWO interleaved half-length lines (decimation in time: E = DFT_{N/2}(x[2m]), O = DFT_{N/2}(x[2m+1])), which
 // have the geometry of the N/2 kernel (2P sub-lines of N/(2E) threads, three passes, same LDS), and the last
@@ -1021,7 +1272,7 @@ __device__ __forceinline__ void half_load_AB_pairs(const void* __restrict__ h0T_
 // threads that read the lines out of LDS for the chunk stores.  Replaces a leading radix-2 pass with its own
 // LDS exchange and barriers (run 16: FFT phases 14 / 10 / 13 us per field at 8192 against 6 / 6 / 7.5 for the
 // same amount of data at 4096).
-template <int N, int E, int P, bool H16>
+template <int N, int E, int P, bool H16, bool HAND = false>
 __global__ void __launch_bounds__((N / E) * P, pass1_waves_per_simd<E>((N / E) * P))
 k_half_pass1_split(const void* __restrict__ h0T, float descale, const float* __restrict__ omegaT, c32* __restrict__ inter,
                    c32* nyq_spec, const c32* __restrict__ tw, InterLayout lay, float time, float domain_size) {
@@ -1050,7 +1301,8 @@ k_half_pass1_split(const void* __restrict__ h0T, float descale, const float* __r
     c32 A[E], B[E];
     OCEAN_TL(0);
     static_assert(E / 2 * THREADS * (int)sizeof(float4) <= 2 * P * LinePitch<M>::elems * (int)sizeof(c32), "exchange fits the line buffers");
-    half_load_AB_pairs<N, E, H16, THREADS>(h0T, descale, omegaT, x, j, par, tid, time, reinterpret_cast<float4*>(smem), A, B);
+    if constexpr (HAND) half_load_AB_pairs_handover<N, E, H16, THREADS>(h0T, descale, omegaT, x, j, par, c, tid, time, reinterpret_cast<float4*>(smem), A, B);
+    else half_load_AB_pairs<N, E, H16, THREADS>(h0T, descale, omegaT, x, j, par, tid, time, reinterpret_cast<float4*>(smem), A, B);
     OCEAN_TL(1);
     const c32 kxv = mk(wave_index_q1(x, N), wave_index_q1(x2, N)) * kscale;
 
@@ -1494,6 +1746,18 @@ template <int N, int PSEL = 0> struct Geo {
 #else
     static constexpr int p2_group = (inter_bshift > 0) ? 8 : 1;
 #endif
+    // Fused pass 1 hands the intra-workgroup duplicate spectrum streams over through LDS (the split kernels' pair
+    // loader half_load_AB_pairs_handover; half_load_AB_handover for whole lines) instead of asking the memory system
+    // twice.  Shipped at N = 8192, where every 64 KiB line was fetched twice: pass 1 486-490 -> 444-460 us, 1044-1049 ->
+    // 1091-1094 frames/s (run r03_run2, two interleaved repetitions).  NOT at 4096: there the L2 already merges most
+    // twins (269 MB fetched against 235 MB of distinct lines), and the four barriers the hand-over puts into the load
+    // phase cost more than the 30 MB are worth -- 96.0-100.0 us against 91.8-96.6 (runs r03_run2/3; software-pipelining
+    // the batches across the barriers changed nothing).  Below 4096 the working set is cache-resident.
+    // A/B knob: OCEAN_HANDOVER_MIN_N (the CPU emulation builds with 256 to run the hand-over geometry of every size).
+#ifndef OCEAN_HANDOVER_MIN_N
+#define OCEAN_HANDOVER_MIN_N 8192
+#endif
+    static constexpr bool handover = (N >= OCEAN_HANDOVER_MIN_N) && (P >= 2);
     static constexpr int thin_threads = T * R2;
     static constexpr int thin_lds = R2 * Pitch2<N, R2>::elems * (int)sizeof(c32);
     static constexpr int thin_grid = N / R2;

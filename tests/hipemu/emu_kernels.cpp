@@ -76,9 +76,9 @@ template <int N, int PSEL> static int run_half_p(const void* h0T, int f16, float
                                                  float4* out, const c32* tw, InterLayout lay, float time, float L) {
     using G = Geo<N, PSEL>;
     if (f16) emu_launch(G::half_grid1, G::half_threads1,
-                        [&] { k_half_pass1<N, G::E1, G::P, true>(h0T, descale, omT, inter, nyq, tw, lay, time, L); });
+                        [&] { k_half_pass1<N, G::E1, G::P, true, G::handover>(h0T, descale, omT, inter, nyq, tw, lay, time, L); });
     else emu_launch(G::half_grid1, G::half_threads1,
-                    [&] { k_half_pass1<N, G::E1, G::P, false>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L); });
+                    [&] { k_half_pass1<N, G::E1, G::P, false, G::handover>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L); });
     emu_launch(G::thin_grid, G::thin_threads,
                [&] { k_half_pass2<N, G::E, CHUNK_W, G::R2, G::p2_group>(inter, out, tw, lay); });
     return 0;
@@ -88,9 +88,9 @@ template <int N> static int run_half_split(const void* h0T, int f16, float desca
     using G = Geo<N, 2>;
     static_assert(G::can_split, "split geometry");
     if (f16) emu_launch(G::half_grid1, G::split_threads1,
-                        [&] { k_half_pass1_split<N, G::E1S, G::P, true>(h0T, descale, omT, inter, nyq, tw, lay, time, L); });
+                        [&] { k_half_pass1_split<N, G::E1S, G::P, true, G::handover>(h0T, descale, omT, inter, nyq, tw, lay, time, L); });
     else emu_launch(G::half_grid1, G::split_threads1,
-                    [&] { k_half_pass1_split<N, G::E1S, G::P, false>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L); });
+                    [&] { k_half_pass1_split<N, G::E1S, G::P, false, G::handover>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L); });
     emu_launch(N, G::split_threads2, [&] { k_half_pass2_split<N, G::E, CHUNK_W, G::p2_group>(inter, out, tw, lay); });
     return 0;
 }

@@ -12,7 +12,16 @@ def hip():
     if _HIP is None:
         import gfx_ocean_amd as g
         g.load_library()                                    # pulls in /opt/rocm's libamdhip64 first
-        _HIP = ctypes.CDLL("libamdhip64.so")
+        # the very file that is already mapped (dlopen by soname could resolve to another copy of the runtime, which
+        # then finds no device: the process already holds the first one's)
+        path = None
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    path = line.split()[-1]
+                    break
+        assert path, "libocean_hip.so did not pull in libamdhip64"
+        _HIP = ctypes.CDLL(path)
         _HIP.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
         _HIP.hipFree.argtypes = [ctypes.c_void_p]
         _HIP.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]

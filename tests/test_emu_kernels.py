@@ -233,3 +233,36 @@ def test_emu_staged_chunked_handoff(n, ref_inputs, ref_inputs_256):
         assert_parity(got, ref, 5e-6, f"chunked row + column pass n={n}")
     want = oc.correction_literal(*[b for b in both])                 # same inputs, the literal correction
     assert np.array_equal(rgba, want)
+
+
+def test_emu_handover_loaders_in_a_variant_build():
+    """The LDS hand-over of the duplicate spectrum streams (half_load_AB_pairs_handover: shipped at N = 8192;
+    half_load_AB_handover: whole lines, A/B only) runs in a build of the emulation with the hand-over enabled at every
+    size: the split geometry at 512 / 1024 (fp32 and fp16-stored spectrum), whole lines with four columns per workgroup
+    at 256 and two at 512.  Own process: the flags are read at import."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import emu, gfx_ocean_amd as g
+from oracle import ocean_oracle as oc
+from conftest import GOLDEN, assert_parity
+h0, om = oc.load_reference_inputs(GOLDEN + "/spectrum.bin", GOLDEN + "/omega.bin")
+h256, o256 = oc.centre_crop(h0, 256), oc.centre_crop(om, 256)
+h1k, o1k = g.synth.make_inputs(1024, seed=4)
+for (h, o, kw, what) in ((h0, om, dict(split=True), "split 512"), (h1k, o1k, dict(split=True), "split 1024"),
+                         (h256, o256, dict(), "lines 256 P=4"), (h0, om, dict(), "lines 512 P=2")):
+    out = emu.frame_half(h, o, 2.5, **kw)
+    assert_parity(out[..., :3], oc.frame_f64(h, o, 2.5)[..., :3], 5e-6, what)
+_, deq, _ = emu.quantize_f16(h0)
+for kw in (dict(split=True),):
+    out = emu.frame_half(h0, om, 1.0, spectrum_fp16=True, **kw)
+    assert_parity(out[..., :3], oc.frame_f64(deq, om, 1.0)[..., :3], 5e-6, "fp16 spectrum " + str(kw))
+print("HANDOVER_EMU_OK")
+"""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OCEAN_EMU_FLAGS="-DOCEAN_HANDOVER_MIN_N=256")
+    p = subprocess.run([sys.executable, "-c", code, root], capture_output=True, text=True, timeout=1500, env=env)
+    assert p.returncode == 0 and "HANDOVER_EMU_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]

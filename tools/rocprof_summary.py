@@ -28,10 +28,33 @@ def from_db(path):
             print(f"{k.split('(')[0].replace('void ', '')},{p},{v:.1f},{n}")
 
 
+def steady_state(d, skip=100):
+    """Per kernel from the dispatch trace: the average over ALL dispatches (what --stats prints: it includes the
+    process's cold first frames, when the GPU has not reached its running clocks) next to the average over the
+    dispatches after the first `skip` of that kernel (the steady state bench.py's dispatch-bound events measure;
+    VERDICT r02 #7: the two pieces of evidence must agree without prose), minimum and median."""
+    for f in sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)):
+        per = {}
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                name = row["Kernel_Name"].split("(")[0].replace("void ", "")
+                per.setdefault(name, []).append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
+        print(f"# {os.path.relpath(f, d)}  (durations in ns; steady = dispatches after the first {skip} of each kernel, or the second half)")
+        print("kernel,dispatches,avg_all_ns,steady_dispatches,avg_steady_ns,median_steady_ns,min_ns")
+        for name, v in sorted(per.items(), key=lambda kv: -sum(x[1] for x in kv[1])):
+            v.sort()
+            dur = [x[1] for x in v]
+            k = skip if len(dur) > 2 * skip else len(dur) // 2
+            st = sorted(dur[k:]) or dur
+            print(f"{name},{len(dur)},{sum(dur) / len(dur):.0f},{len(st)},{sum(st) / len(st):.0f},{st[len(st) // 2]},{min(dur)}")
+        print()
+
+
 def from_csv_dir(d):
     for f in sorted(glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)):
         print(f"# {os.path.relpath(f, d)}")
         print(open(f).read())
+    steady_state(d)
     for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
         acc = {}
         with open(f) as fh:
