@@ -29,15 +29,18 @@
                            defined(OCEAN_X2_NOLOAD) || defined(OCEAN_X2_NOSTORE) || defined(OCEAN_X2_NOFFT))
 #error "OCEAN_X* switches produce wrong results on purpose (timing ablations): they require -DOCEAN_AB (tools/ab_variants.sh)"
 #endif
+// The exchanges of a line synchronise the threads OF THAT LINE: a workgroup barrier in general; a wave-level fence when
+// the caller guarantees that the T <= 64 threads of a line are T consecutive lanes of one wave (template flag CONTIG of
+// fft_line / fft_line_to_lds; line_sync<T>, ocean_device_intrinsics.hpp).  SYNC_T below is T with CONTIG, "many" without.
 #if defined(OCEAN_X_NOBAR) && OCEAN_X_NOBAR >= 1
-#define OCEAN_FFT_WAR_BARRIER() ((void)0)
+#define OCEAN_FFT_WAR_BARRIER(T) ((void)0)
 #else
-#define OCEAN_FFT_WAR_BARRIER() __syncthreads()
+#define OCEAN_FFT_WAR_BARRIER(T) line_sync<T>()
 #endif
 #if defined(OCEAN_X_NOBAR) && OCEAN_X_NOBAR >= 2
-#define OCEAN_FFT_RAW_BARRIER() ((void)0)
+#define OCEAN_FFT_RAW_BARRIER(T) ((void)0)
 #else
-#define OCEAN_FFT_RAW_BARRIER() __syncthreads()
+#define OCEAN_FFT_RAW_BARRIER(T) line_sync<T>()
 #endif
 
 namespace ocean {
@@ -251,11 +254,11 @@ __device__ __forceinline__ void fft_pass(c32 (&reg)[E], int j, const c32* __rest
 
 // Exchange through one padded LDS line buffer: scatter `reg` outputs of a pass, then gather
 // positions j + e*T.  `bar()` is the workgroup barrier (all threads of the WG call it).
-template <int N, int E, int R, int NS, int TWS = 1>
+template <int N, int E, int R, int NS, int TWS = 1, int SYNC_T = 1024>
 __device__ __forceinline__ void fft_pass_exchange(c32 (&reg)[E], int j, const c32* __restrict__ tw, c32* lds_line) {
     constexpr int T = N / E;
     fft_pass<N, E, R, NS, TWS>(reg, j, tw, [&](int, int ppos, c32 v, int) { lds_line[ppos] = v; });
-    OCEAN_FFT_RAW_BARRIER();
+    OCEAN_FFT_RAW_BARRIER(SYNC_T);
     // lds_pad(j + e*T) == lds_pad(j) + e*(T + T/16)   (T is a multiple of 16)
     const c32* g = lds_line + lds_pad(j);
 #pragma unroll
@@ -264,17 +267,18 @@ __device__ __forceinline__ void fft_pass_exchange(c32 (&reg)[E], int j, const c3
 
 // Whole line transform.  On entry reg[e] = x[j + e*T]; on exit reg[e] = X[j + e*T].
 // lds_line: LdsLine<N>::elems c32 owned by this line.  Every thread of the workgroup must call
-// this the same number of times (it contains __syncthreads()).
-template <int N, int E, int TWS = 1>
+// this the same number of times (with T > 64 it contains __syncthreads()).
+template <int N, int E, int TWS = 1, bool CONTIG = false>
 __device__ __forceinline__ void fft_line(c32 (&reg)[E], int j, const c32* __restrict__ tw, c32* lds_line) {
+    constexpr int SYNC_T = (CONTIG && N / E <= 64) ? N / E : 1024;
     constexpr int R0 = Plan<N, E>::first_radix();
     constexpr int Q = Plan<N, E>::full_passes();
     static_assert(Q >= 1 && Q <= 3, "unsupported N/E combination");
     int ns = 1;
     (void)ns;
     if constexpr (R0 > 1) {
-        fft_pass_exchange<N, E, R0, 1, TWS>(reg, j, tw, lds_line);
-        OCEAN_FFT_WAR_BARRIER();   // WAR: next scatter reuses the buffer
+        fft_pass_exchange<N, E, R0, 1, TWS, SYNC_T>(reg, j, tw, lds_line);
+        OCEAN_FFT_WAR_BARRIER(SYNC_T);   // WAR: next scatter reuses the buffer
     }
     constexpr int NS1 = R0;                  // after the optional small pass
     if constexpr (Q == 1) {
@@ -283,7 +287,7 @@ __device__ __forceinline__ void fft_line(c32 (&reg)[E], int j, const c32* __rest
 #pragma unroll
         for (int e = 0; e < E; ++e) reg[e] = out[e];
     } else {
-        fft_pass_exchange<N, E, E, NS1, TWS>(reg, j, tw, lds_line);
+        fft_pass_exchange<N, E, E, NS1, TWS, SYNC_T>(reg, j, tw, lds_line);
         constexpr int NS2 = NS1 * E;
         if constexpr (Q == 2) {
             c32 out[E];
@@ -291,8 +295,8 @@ __device__ __forceinline__ void fft_line(c32 (&reg)[E], int j, const c32* __rest
 #pragma unroll
             for (int e = 0; e < E; ++e) reg[e] = out[e];
         } else {
-            OCEAN_FFT_WAR_BARRIER();
-            fft_pass_exchange<N, E, E, NS2, TWS>(reg, j, tw, lds_line);
+            OCEAN_FFT_WAR_BARRIER(SYNC_T);
+            fft_pass_exchange<N, E, E, NS2, TWS, SYNC_T>(reg, j, tw, lds_line);
             constexpr int NS3 = NS2 * E;
             c32 out[E];
             fft_pass<N, E, E, NS3, TWS>(reg, j, tw, [&](int, int, c32 v, int slot) { out[slot] = v; });
@@ -305,24 +309,25 @@ __device__ __forceinline__ void fft_line(c32 (&reg)[E], int j, const c32* __rest
 // Same transform, but the final pass scatters into the LDS line (padded positions) and the
 // function returns after a barrier: lds_line[lds_pad(n)] = X[n] for the whole line.  Used when
 // the global store wants a different thread->element mapping than the FFT's (chunked layouts).
-template <int N, int E, int TWS = 1>
+template <int N, int E, int TWS = 1, bool CONTIG = false>
 __device__ __forceinline__ void fft_line_to_lds(c32 (&reg)[E], int j, const c32* __restrict__ tw, c32* lds_line) {
+    constexpr int SYNC_T = (CONTIG && N / E <= 64) ? N / E : 1024;
     constexpr int R0 = Plan<N, E>::first_radix();
     constexpr int Q = Plan<N, E>::full_passes();
     static_assert(Q >= 2 && Q <= 3, "unsupported N/E combination");
     if constexpr (R0 > 1) {
-        fft_pass_exchange<N, E, R0, 1, TWS>(reg, j, tw, lds_line);
-        OCEAN_FFT_WAR_BARRIER();
+        fft_pass_exchange<N, E, R0, 1, TWS, SYNC_T>(reg, j, tw, lds_line);
+        OCEAN_FFT_WAR_BARRIER(SYNC_T);
     }
     constexpr int NS1 = R0;
-    fft_pass_exchange<N, E, E, NS1, TWS>(reg, j, tw, lds_line);
-    OCEAN_FFT_WAR_BARRIER();
+    fft_pass_exchange<N, E, E, NS1, TWS, SYNC_T>(reg, j, tw, lds_line);
+    OCEAN_FFT_WAR_BARRIER(SYNC_T);
     constexpr int NS2 = NS1 * E;
     if constexpr (Q == 2) {
         fft_pass<N, E, E, NS2, TWS>(reg, j, tw, [&](int, int ppos, c32 v, int) { lds_line[ppos] = v; });
     } else {
-        fft_pass_exchange<N, E, E, NS2, TWS>(reg, j, tw, lds_line);
-        OCEAN_FFT_WAR_BARRIER();
+        fft_pass_exchange<N, E, E, NS2, TWS, SYNC_T>(reg, j, tw, lds_line);
+        OCEAN_FFT_WAR_BARRIER(SYNC_T);
         constexpr int NS3 = NS2 * E;
         fft_pass<N, E, E, NS3, TWS>(reg, j, tw, [&](int, int ppos, c32 v, int) { lds_line[ppos] = v; });
     }

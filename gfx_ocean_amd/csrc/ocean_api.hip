@@ -185,7 +185,7 @@ template <int N> struct Launch {
 #elif defined(OCEAN_P_2048)                                            // A/B knob: lines per pass-1 workgroup at N = 2048
     static constexpr int default_psel() { return (N == 2048) ? OCEAN_P_2048 : ((N == 512 || N > 4096 || CHUNK_W < 4) ? 2 : 4); }
 #else
-    static constexpr int default_psel() { return (N == 512 || N == 2048 || N > 4096 || CHUNK_W < 4) ? 2 : 4; }
+    static constexpr int default_psel() { return (N == 512) ? 1 : ((N <= 2048 || N > 4096 || CHUNK_W < 4) ? 2 : 4); }
 #endif
     static constexpr bool default_split() { return N > 4096; }
     // Which (plain, split) kernel pairs exist in this build: everything selectable in an A/B build, only the
@@ -201,14 +201,14 @@ template <int N> struct Launch {
         using H = Geo<N, PSEL>;
         hipError_t e = hipSuccess;
         if constexpr (plain_built<PSEL>()) {
-            e = hipFuncSetAttribute((const void*)k_half_pass1<N, H::E1, H::P, false, H::handover>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, H::frame_lds);
+            e = hipFuncSetAttribute((const void*)k_half_pass1<N, H::E1, H::P, false, H::handover, H::fpar>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, H::half_lds1);
             if (e != hipSuccess) return e;
-            e = hipFuncSetAttribute((const void*)k_half_pass1<N, H::E1, H::P, true, H::handover>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, H::frame_lds);
+            e = hipFuncSetAttribute((const void*)k_half_pass1<N, H::E1, H::P, true, H::handover, H::fpar>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, H::half_lds1);
             if (e != hipSuccess) return e;
-            e = hipFuncSetAttribute((const void*)k_half_pass2<N, H::E, CHUNK_W, H::R2, H::p2_group>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, H::thin_lds);
+            e = hipFuncSetAttribute((const void*)k_half_pass2<N, H::E2, CHUNK_W, H::R2h, H::p2_group, H::ppar>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, H::half_lds2);
             if (e != hipSuccess) return e;
         }
         if constexpr (split_built<PSEL>()) {
@@ -241,11 +241,11 @@ template <int N> struct Launch {
         }
         if constexpr (plain_built<PSEL>()) {
             if (c->h0_f16)
-                launch(k_half_pass1<N, H::E1, H::P, true, H::handover>, dim3(H::half_grid1), dim3(H::half_threads1), H::frame_lds, s, t,
+                launch(k_half_pass1<N, H::E1, H::P, true, H::handover, H::fpar>, dim3(H::half_grid1), dim3(H::half_threads1), H::half_lds1, s, t,
                        (const void*)c->h0T, descale, (const float*)c->omegaT, c->inter, c->nyq, (const c32*)c->tw,
                        c->lay_h, time, domain);
             else
-                launch(k_half_pass1<N, H::E1, H::P, false, H::handover>, dim3(H::half_grid1), dim3(H::half_threads1), H::frame_lds, s, t,
+                launch(k_half_pass1<N, H::E1, H::P, false, H::handover, H::fpar>, dim3(H::half_grid1), dim3(H::half_threads1), H::half_lds1, s, t,
                        (const void*)c->h0T, 1.0f, (const float*)c->omegaT, c->inter, c->nyq, (const c32*)c->tw,
                        c->lay_h, time, domain);
         }
@@ -274,7 +274,7 @@ template <int N> struct Launch {
             }
         }
         if constexpr (plain_built<PSEL>())
-            launch(k_half_pass2<N, H::E, CHUNK_W, H::R2, H::p2_group>, dim3(H::thin_grid), dim3(H::thin_threads), H::thin_lds, s, t,
+            launch(k_half_pass2<N, H::E2, CHUNK_W, H::R2h, H::p2_group, H::ppar>, dim3(H::half_grid2), dim3(H::half_threads2), H::half_lds2, s, t,
                    (const c32*)c->inter, c->out, (const c32*)c->tw, c->lay_h);
     }
     static void stage_rows(OceanContext* c, int f, hipStream_t s) {

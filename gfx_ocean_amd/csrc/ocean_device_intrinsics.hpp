@@ -63,6 +63,22 @@ __device__ __forceinline__ void workgroup_publish() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// Synchronisation among the T threads that share one line of an LDS exchange (fft_core.hpp).  T > 64: the line is
+// spread over several waves -> workgroup barrier.  T <= 64 (T divides 64, lines are T consecutive lanes): the whole
+// line lives in ONE wave, whose LDS instructions execute in program order -- a compiler-level fence at wavefront scope
+// is all that is needed, no s_barrier (at N = 512 a pass-1 workgroup is three one-wave lines that would otherwise
+// wait for each other five times per transform).
+template <int T> __device__ __forceinline__ void line_sync() {
+    if constexpr (T <= 64) {
+        static_assert(64 % T == 0, "lines must not straddle waves");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
 // Timeline probes for tools/timeline.hip (compiled in only with -DOCEAN_TIMELINE; the product build has none):
 // lane 0 of a workgroup records the 100 MHz wall clock at a few points, slot 15 the hardware id.
 #ifdef OCEAN_TIMELINE

@@ -679,7 +679,9 @@ __device__ __forceinline__ void half_load_AB(const void* __restrict__ h0T_, floa
     // inputs have been consumed (otherwise 16 x 10 input VGPRs are live at once next to A and B and
     // the kernel spills at the 128-VGPR budget of a 1024-thread workgroup; a spill reload in the
     // load phase also drains every outstanding global load, vmcnt being in-order)
-    constexpr int LOAD_BATCHES = 4;                                // measured: 2 and 8 spill more; issuing a batch ahead: +8 us
+    // (N <= 1024: the frame is latency-bound and a thread has half the elements and no register pressure -- one batch:
+    // the four dependent rounds of L2 latency were 1.1 us of a 3.7 us workgroup at N = 512, timeline r03)
+    constexpr int LOAD_BATCHES = (N <= 1024) ? 1 : 4;              // measured: 2 and 8 spill more; issuing a batch ahead: +8 us
     constexpr int PER = E / LOAD_BATCHES;
     int jj = j;
 #pragma unroll
@@ -951,24 +953,36 @@ __device__ __forceinline__ void nyquist_spectra(const void* __restrict__ h0T, fl
 template <int E> constexpr int pass1_waves_per_simd(int threads) {
     return (E == 16) ? ((threads >= 512) ? 4 : 1) : ((threads / 256) > 1 ? (threads / 256) : 1);
 }
-template <int N, int E, int P, bool H16, bool HAND = false>
-__global__ void __launch_bounds__((N / E) * P, pass1_waves_per_simd<E>((N / E) * P))
+// FPAR ("field-parallel", the launch- and latency-bound sizes N <= 1024): three wave groups per workgroup, one per
+// field -- each loads and propagates the workgroup's columns (the same cache-resident lines, three times), builds ITS
+// field's symmetrised spectrum, transforms and stores it -- instead of one group doing the three fields one after the
+// other.  At N = 512 a workgroup is two waves on a CU with four SIMDs and every instruction's latency is exposed
+// (timeline r03_run4: load 1.0 us, then 1.45 + 1.0 + 1.3 us of transforms, 3 x 0.2 us of stores): the three
+// transforms now run side by side.
+template <int N, int E, int P, bool H16, bool HAND = false, bool FPAR = false>
+__global__ void __launch_bounds__((N / E) * P * (FPAR ? 3 : 1), pass1_waves_per_simd<E>((N / E) * P * (FPAR ? 3 : 1)))
 k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restrict__ omegaT, c32* __restrict__ inter,
              c32* nyq_spec, const c32* __restrict__ tw, InterLayout lay, float time, float domain_size) {
     constexpr int T = N / E;
+    constexpr int GT = T * P;                                      // threads of one field group (= the workgroup without FPAR)
     constexpr int H2 = P / 2;
     constexpr int CR = CHUNK_R, CW = CHUNK_W;                    // row y of a chunk is y % CR, column x % CW
     static_assert((2 * T) % CR == 0 && CW % P == 0, "chunk geometry");
+    static_assert(!FPAR || (GT % 64 == 0 && !HAND), "a field group is whole waves");
+    static_assert(P > 1 || !HAND, "the hand-over needs a left neighbour inside the workgroup");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     c32* lds = reinterpret_cast<c32*>(smem);
     const int tid = threadIdx.x;
-    const int c = (T >= 64) ? wave_uniform(tid / T) : (tid / T);
-    const int j = tid % T;
-    c32* lds_line = lds + c * LinePitch<N>::elems;
+    const int fg = FPAR ? wave_uniform(tid / GT) : 0;              // field group = the field this thread transforms
+    const int gt = FPAR ? (tid - fg * GT) : tid;                   // thread within the group
+    const int c = (T >= 64) ? wave_uniform(gt / T) : (gt / T);
+    const int j = gt % T;
+    c32* lds_grp = lds + fg * (P * LinePitch<N>::elems);           // the group's P line buffers
+    c32* lds_line = lds_grp + c * LinePitch<N>::elems;
     const float kscale = OCEAN_PI_F / domain_size;
 
     const int X = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
-    if (X == 0) nyquist_spectra<N, H16, T * P>(h0T, descale, omegaT, nyq_spec, tid, time, kscale);   // uniform branch
+    if (X == 0) nyquist_spectra<N, H16, GT * (FPAR ? 3 : 1)>(h0T, descale, omegaT, nyq_spec, tid, time, kscale);   // uniform branch
 #ifdef OCEAN_SETPRIO
     // One wave of every line sits on each SIMD (T = 4 waves per line, waves dealt to the SIMDs cyclically):
     // the line index is a priority that differs between the waves sharing a SIMD.
@@ -988,19 +1002,20 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
     OCEAN_TL(1);
     const c32 kxv = mk(wave_index_q1(x, N), wave_index_q1(x2, N)) * kscale;
 
-    const int h = tid % H2;
-    const int i = tid / H2;
-    const c32* l0 = lds + (2 * h) * LinePitch<N>::elems;
-    const c32* l1 = lds + (2 * h + 1) * LinePitch<N>::elems;
+    constexpr int H2S = (H2 > 0) ? H2 : 1;                        // (P == 1 stores straight from registers, below)
+    const int h = gt % H2S;
+    const int i = gt / H2S;
+    const c32* l0 = lds_grp + (2 * h) * LinePitch<N>::elems;
+    const c32* l1 = lds_grp + (2 * h + 1) * LinePitch<N>::elems;
 #ifdef OCEAN_ROTQ
     const int rotq = (OCEAN_ROTQ == 2) ? (int)((blockIdx.x * 5u + (blockIdx.x >> 3)) & (E / 2 - 1)) : (X & (E / 2 - 1));
 #endif
 #pragma unroll
-    for (int ff = 0; ff < 3; ++ff) {
+    for (int ff = 0; ff < (FPAR ? 1 : 3); ++ff) {
 #ifdef OCEAN_FIELD_ORDER   // A/B knob: height first (its spectrum is the cheapest and the first transform of a round is exposed)
-        const int f = (ff == 0) ? 1 : ((ff == 1) ? 0 : 2);
+        const int f = FPAR ? fg : ((ff == 0) ? 1 : ((ff == 1) ? 0 : 2));
 #else
-        const int f = ff;
+        const int f = FPAR ? fg : ff;
 #endif
         c32 reg[E];
         const int jf = opaque_lane(j);
@@ -1021,9 +1036,25 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
             __syncthreads();
         }
 #else
-        fft_line_to_lds<N, E>(reg, jf, tw, lds_line);
+        if constexpr (P == 1) {
+            // One column per workgroup (the latency-bound sizes, where a column per CU is the whole grid): the transform
+            // ends in registers, X[j + e T], and every lane stores its 8-byte elements straight into the chunks (a
+            // quarter of a chunk row each; the four column workgroups of a chunk column run on one XCD and the
+            // cache-resident intermediate merges there).
+            fft_line<N, E, 1, true>(reg, jf, tw, lds_line);      // the threads of a line are consecutive lanes
+            OCEAN_TL(2 + 2 * (FPAR ? f : ff));
+            c32* dcol = inter + (size_t)f * lay.fs + (size_t)(X / CW) * lay.sx + (X % CW);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int y = jf + e * T;
+                dcol[chunk_row_offset(lay, y / CR) + (y % CR) * CW] = reg[e];
+            }
+            OCEAN_TL(3 + 2 * (FPAR ? f : ff));
+            continue;
+        }
+        fft_line_to_lds<N, E, 1, true>(reg, jf, tw, lds_line);
 #endif
-        OCEAN_TL(2 + 2 * ff);
+        OCEAN_TL(2 + 2 * (FPAR ? f : ff));
         // chunk row Y = i / CR + q * (2T / CR): the thread's part and the (wave-uniform, scalar) part of the address add
         // up because 2T / CR is a power of two > i / CR (no carry between them in chunk_row_offset)
         c32* dst = inter + (size_t)f * lay.fs + (size_t)((X * P) / CW) * lay.sx + chunk_row_offset(lay, i / CR) + (i % CR) * CW +
@@ -1046,7 +1077,7 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
             if constexpr (P == CW) store_float4_nt(o, make_float4(v0.x, v0.y, v1.x, v1.y));
             else *o = make_float4(v0.x, v0.y, v1.x, v1.y);        // half a chunk row: must meet its other half in L2
         }
-        OCEAN_TL(3 + 2 * ff);
+        OCEAN_TL(3 + 2 * (FPAR ? f : ff));
     }
 }
 
@@ -1369,17 +1400,25 @@ template <int N, int R2> struct Pitch2 { static constexpr int elems = LdsLine<N>
 // __launch_bounds__(.., 4 waves/SIMD): 1024 threads per CU (LDS: 4 x 35 KiB or 2 x 70 KiB), i.e. at most 128 VGPRs.
 // GRP: this many consecutive chunk rows run in adjacent dispatch slots of one XCD (with the pass-1-contiguous layout the
 // chunks (X, Y), (X, Y + 1), ... are adjacent in memory: the workgroups that read one DRAM page run together).
-template <int N, int E, int P1, int R2, int GRP = 1>
-__global__ void __launch_bounds__((N / E) * R2, (E == 16) ? 4 : 2)
+// PPAR (the latency-bound sizes N <= 1024): two wave groups per workgroup, one per transform -- group 0 gathers and
+// transforms the height rows, group 1 the (disp_x, disp_z) rows, side by side instead of one after the other; group 0
+// hands its real parts over through LDS and group 1 writes the RGBA rows.  (Timeline r03_run4 at N = 512: gather
+// 0.9 + transform 0.9 us, then gather 0.4 + transform 1.65 us, one after the other, on a CU with two waves.)
+template <int N, int E, int P1, int R2, int GRP = 1, bool PPAR = false>
+__global__ void __launch_bounds__((N / E) * R2 * (PPAR ? 2 : 1), (E == 16) ? 4 : 2)
 k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32* __restrict__ tw, InterLayout lay) {
     constexpr int T = N / E;
+    constexpr int GT = T * R2;                                     // threads of one transform group (= the workgroup without PPAR)
     constexpr int EH = E / 2;                                      // elements of the half spectrum per thread
     static_assert(T % P1 == 0 && (E % 2) == 0, "geometry");
+    static_assert(!PPAR || GT % 64 == 0, "a transform group is whole waves");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     c32* lds = reinterpret_cast<c32*>(smem);
     const int tid = threadIdx.x;
-    const int ll = (T >= 64) ? wave_uniform(tid / T) : (tid / T);
-    const int j = tid % T;
+    const int pg = PPAR ? wave_uniform(tid / GT) : 0;              // 0: height, 1: (disp_x, disp_z)
+    const int gt = PPAR ? (tid - pg * GT) : tid;
+    const int ll = (T >= 64) ? wave_uniform(gt / T) : (gt / T);
+    const int j = gt % T;
     constexpr int CR = CHUNK_R;
     constexpr int LP = Pitch2<N, R2>::elems;
     static_assert(P1 == CHUNK_W, "pass 2 reads whole chunk rows");
@@ -1394,13 +1433,15 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
 #ifdef OCEAN_SETPRIO2
     wave_priority(wave_uniform((int)(blockIdx.x >> 3) & 3));        // co-resident workgroups: one wave each per SIMD
 #endif
-    c32* lds_line = lds + ll * LP;
+    c32* lds_grp = lds + pg * (R2 * LP);                           // the group's R2 line buffers
+    c32* lds_line = lds_grp + ll * LP;
+    float* hbuf = reinterpret_cast<float*>(lds + 2 * R2 * LP);     // PPAR: R2 rows of N height values
     // loader coordinates
     constexpr int RL = (R2 < CR) ? R2 : CR;                        // rows of one chunk this workgroup owns
-    const int lr = (R2 == 1) ? 0 : ((tid / P1) % RL + (tid / (T * RL)) * RL);   // row within the workgroup
-    const int lk0 = (R2 == 1) ? tid : (((tid % (T * RL)) / (P1 * RL)) * P1 + tid % P1);   // kx of element e = 0
+    const int lr = (R2 == 1) ? 0 : ((gt / P1) % RL + (gt / (T * RL)) * RL);   // row within the workgroup
+    const int lk0 = (R2 == 1) ? gt : (((gt % (T * RL)) / (P1 * RL)) * P1 + gt % P1);   // kx of element e = 0
     const int ly = rb * R2 + lr;
-    c32* load_line = lds + lr * LP;
+    c32* load_line = lds_grp + lr * LP;
 
     float keep_h[E];
     OCEAN_TL(0);
@@ -1408,9 +1449,9 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
     // per thread in flight otherwise).  Run 34: N = 2048 20.07-20.24k frames/s against 19.84-19.94k; at N = 4096 the same
     // costs 2-3 us (pass 2 91-94 us against 88-91): more lines in flight than the L2 keeps for the four sharers.
 #ifdef OCEAN_P2_PREFETCH
-    constexpr bool PREFETCH = (OCEAN_P2_PREFETCH != 0);
+    constexpr bool PREFETCH = (OCEAN_P2_PREFETCH != 0) && !PPAR;
 #else
-    constexpr bool PREFETCH = (N <= 2048);
+    constexpr bool PREFETCH = (N <= 2048) && !PPAR;
 #endif
     c32 pre_x[EH], pre_z[EH];
     if constexpr (PREFETCH) {
@@ -1421,7 +1462,8 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
         for (int e = 0; e < EH; ++e) { pre_x[e] = sx_[(size_t)e * (T / P1) * lay.sx]; pre_z[e] = sz_[(size_t)e * (T / P1) * lay.sx]; }
     }
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {                         // 0: height, 1: (disp_x, disp_z)
+    for (int it = 0; it < (PPAR ? 1 : 2); ++it) {                  // pass 0: height, 1: (disp_x, disp_z)
+        const int pass = PPAR ? pg : it;
         const int jf = opaque_lane(j);
         const int lk = (R2 == 1) ? jf : opaque_lane(lk0);
         const size_t off = chunk_row_offset(lay, ly / CR) + (size_t)(lk / P1) * lay.sx + (ly % CR) * P1 + (lk % P1);
@@ -1433,7 +1475,7 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
         if (pass == 0) {
             const c32* src = inter + (size_t)1 * lay.fs + off;
 #pragma unroll
-            for (int e = 0; e < EH; ++e) a[e] = src[(size_t)e * (T / P1) * lay.sx];
+            for (int e = 0; e < EH; ++e) { a[e] = src[(size_t)e * (T / P1) * lay.sx]; b[e] = mk(0.0f, 0.0f); }
         } else if constexpr (PREFETCH) {
 #pragma unroll
             for (int e = 0; e < EH; ++e) { a[e] = pre_x[e]; b[e] = pre_z[e]; }
@@ -1444,7 +1486,7 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
             for (int e = 0; e < EH; ++e) { a[e] = sx_[(size_t)e * (T / P1) * lay.sx]; b[e] = sz_[(size_t)e * (T / P1) * lay.sx]; }
         }
 #endif
-        if (pass > 0) __syncthreads();                             // previous FFT's LDS reads done
+        if (it > 0) __syncthreads();                               // previous FFT's LDS reads done
         // rebuild the full row: C[k] = A + iB, C[N-k] = conj(A) + i conj(B).  Column 0 of the intermediate
         // holds two real columns, (kx = 0, kx = N/2) as (re, im): C[0] = re(A) + i re(B), C[N/2] = im(A) + i im(B)
         c32* lo = load_line + lds_pad(lk);                         // lds_pad(lk + e*T) = lds_pad(lk) + e*(T + T/16)
@@ -1481,12 +1523,27 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
         for (int e = 0; e < E; ++e) reg[e] = g[e * (T + T / 16)];
         __syncthreads();
 #ifndef OCEAN_X2_NOFFT   // timing experiment only (wrong results): pass 2 without its transforms
-        fft_line<N, E>(reg, jf, tw, lds_line);
+        fft_line<N, E, 1, true>(reg, jf, tw, lds_line);          // (ll, j): the threads of a row are consecutive lanes
 #endif
         OCEAN_TL(2 + 3 * pass);
-        if (pass == 0) {
+        if constexpr (PPAR) {                                      // group 0 hands its row of heights to group 1
+            if (pass == 0) {
+                float* hrow = hbuf + ll * N + j;
 #pragma unroll
-            for (int e = 0; e < E; ++e) keep_h[e] = reg[e].x;
+                for (int e = 0; e < E; ++e) hrow[e * T] = reg[e].x;
+            }
+            __syncthreads();
+            if (pass == 1) {
+                const float* hrow = hbuf + ll * N + j;
+#pragma unroll
+                for (int e = 0; e < E; ++e) keep_h[e] = hrow[e * T];
+            }
+        }
+        if (pass == 0) {
+            if constexpr (!PPAR) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) keep_h[e] = reg[e].x;
+            }
         } else {
             float4* orow = out + (size_t)y * N;
 #pragma unroll
@@ -1702,12 +1759,19 @@ template <int N, int PSEL = 0> struct Geo {
     static constexpr int row_threads = T * ROW_LPW;
     static constexpr int col_threads = T * COL_LPW;
     static constexpr int frame_threads = T * P;
-    static constexpr int half_threads1 = (N / E1) * P;             // fused pass 1 (half-spectrum path)
+    // Field-parallel pass 1 (k_half_pass1<.., FPAR>): three wave groups per workgroup, one per field, at the latency-bound
+    // sizes.  A/B knob: OCEAN_FPAR_MAX_N (0 = off).
+#ifndef OCEAN_FPAR_MAX_N
+#define OCEAN_FPAR_MAX_N 512
+#endif
+    static constexpr bool fpar = (N <= OCEAN_FPAR_MAX_N) && (((N / E1) * P) % 64 == 0) && (3 * (N / E1) * P <= 1024);
+    static constexpr int half_threads1 = (N / E1) * P * (fpar ? 3 : 1);   // fused pass 1 (half-spectrum path)
     static constexpr int split_threads1 = (N / E1S) * P;
     static constexpr int line_bytes = LinePitch<N>::elems * (int)sizeof(c32);
     static constexpr int row_lds = ROW_LPW * line_bytes;
     static constexpr int col_lds = COL_LPW * line_bytes;
     static constexpr int frame_lds = P * line_bytes;
+    static constexpr int half_lds1 = P * line_bytes * (fpar ? 3 : 1);
     static constexpr int row_grid = N / ROW_LPW;
     static constexpr int col_grid = N / COL_LPW;
     static constexpr int frame_grid = N / P;
@@ -1719,8 +1783,22 @@ template <int N, int PSEL = 0> struct Geo {
 #elif defined(OCEAN_R2_SMALL)
     static constexpr int R2 = (ROW_LPW > OCEAN_R2_SMALL) ? OCEAN_R2_SMALL : ROW_LPW;
 #else
-    static constexpr int R2 = (N <= 1024 && ROW_LPW > 2) ? 2 : ROW_LPW;
+    static constexpr int R2 = (N <= 1024 && ROW_LPW > 2) ? ((T * 2 >= 64) ? 2 : (64 / T)) : ROW_LPW;   // >= one wave per transform group
 #endif
+    // Transform-parallel pass 2 (k_half_pass2<.., PPAR>): two wave groups per workgroup, height and (disp_x, disp_z), at
+    // the latency-bound sizes.  A/B knob: OCEAN_PPAR_MAX_N (0 = off).
+#ifndef OCEAN_PPAR_MAX_N
+#define OCEAN_PPAR_MAX_N 1024
+#endif
+    // Elements per thread of fused pass 2: 8 at the smallest sizes (a 512-point row is then one wave instead of half of
+    // one, and a workgroup is one row: twice the workgroups, four waves per CU).  A/B knob: OCEAN_E2_SMALL_MAX_N (0 = off).
+#ifndef OCEAN_E2_SMALL_MAX_N
+#define OCEAN_E2_SMALL_MAX_N 512
+#endif
+    static constexpr int E2 = (N <= OCEAN_E2_SMALL_MAX_N) ? 8 : E;
+    static constexpr int T2 = N / E2;                              // threads per row of fused pass 2
+    static constexpr int R2h = (E2 == E) ? R2 : ((T2 >= 64) ? 1 : (64 / T2));   // rows per workgroup (whole waves per transform group)
+    static constexpr bool ppar = (N <= OCEAN_PPAR_MAX_N) && ((T2 * R2h) % 64 == 0) && (2 * T2 * R2h <= 1024);
     // Intermediate layout of the fused frame (InterLayout): blocks of B = 2^inter_bshift chunk rows.
     // B = 1 is pass-2-contiguous (pass 2 streams, pass 1 scatters single 128-byte chunks), B = N / 4 pass-1-contiguous.
     // At N >= 2048, where pass 1 is bound by its scattered stores, B = 4: a pass-1 wave stores 512-byte pieces, and the
@@ -1760,6 +1838,10 @@ template <int N, int PSEL = 0> struct Geo {
     static constexpr bool handover = (N >= OCEAN_HANDOVER_MIN_N) && (P >= 2);
     static constexpr int thin_threads = T * R2;
     static constexpr int thin_lds = R2 * Pitch2<N, R2>::elems * (int)sizeof(c32);
+    static constexpr int half_threads2 = T2 * R2h * (ppar ? 2 : 1);  // fused pass 2 (half-spectrum path)
+    static constexpr int half_grid2 = N / R2h;
+    static constexpr int half_lines2 = R2h * Pitch2<N, R2h>::elems * (int)sizeof(c32);
+    static constexpr int half_lds2 = ppar ? (2 * half_lines2 + R2h * N * (int)sizeof(float)) : half_lines2;
     static constexpr int thin_grid = N / R2;
     static constexpr int half_grid1 = (N / 2) / P;                 // column groups
     // staged path with the chunked hand-off (k_stage_rows / k_stage_cols): 4 lines per workgroup

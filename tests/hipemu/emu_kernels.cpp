@@ -76,11 +76,11 @@ template <int N, int PSEL> static int run_half_p(const void* h0T, int f16, float
                                                  float4* out, const c32* tw, InterLayout lay, float time, float L) {
     using G = Geo<N, PSEL>;
     if (f16) emu_launch(G::half_grid1, G::half_threads1,
-                        [&] { k_half_pass1<N, G::E1, G::P, true, G::handover>(h0T, descale, omT, inter, nyq, tw, lay, time, L); });
+                        [&] { k_half_pass1<N, G::E1, G::P, true, G::handover, G::fpar>(h0T, descale, omT, inter, nyq, tw, lay, time, L); });
     else emu_launch(G::half_grid1, G::half_threads1,
-                    [&] { k_half_pass1<N, G::E1, G::P, false, G::handover>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L); });
-    emu_launch(G::thin_grid, G::thin_threads,
-               [&] { k_half_pass2<N, G::E, CHUNK_W, G::R2, G::p2_group>(inter, out, tw, lay); });
+                    [&] { k_half_pass1<N, G::E1, G::P, false, G::handover, G::fpar>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L); });
+    emu_launch(G::half_grid2, G::half_threads2,
+               [&] { k_half_pass2<N, G::E2, CHUNK_W, G::R2h, G::p2_group, G::ppar>(inter, out, tw, lay); });
     return 0;
 }
 template <int N> static int run_half_split(const void* h0T, int f16, float descale, const float* omT, c32* inter, c32* nyq,
@@ -101,6 +101,7 @@ template <int N> static int run_half(int psel, const void* h0T, int f16, float d
         else return -3;
     }
     if (psel == 2) return run_half_p<N, 2>(h0T, f16, descale, omT, inter, nyq, out, tw, lay, time, L);
+    if (psel == 1) return run_half_p<N, 1>(h0T, f16, descale, omT, inter, nyq, out, tw, lay, time, L);
     if constexpr (CHUNK_W % Geo<N, 0>::P != 0) return -4;
     else return run_half_p<N, 0>(h0T, f16, descale, omT, inter, nyq, out, tw, lay, time, L);
 }

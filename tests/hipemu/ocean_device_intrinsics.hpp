@@ -40,6 +40,7 @@ static inline float cos_rev(float x) { return (float)std::cos(6.283185307179586 
 static inline void store_float4_nt(float4* p, float4 v) { *p = v; }
 static inline float load_float_nt(const float* p) { return *p; }
 static inline int opaque_after(int x, float) { return x; }
+template <int T> static inline void line_sync() { __syncthreads(); }   // host threads are not a wave: always the full barrier
 static inline void workgroup_publish() { __syncthreads(); }       // the emulation's barrier is a full fence
 }  // namespace ocean
 #define OCEAN_TL(k)

@@ -14,13 +14,16 @@ def hip():
         g.load_library()                                    # pulls in /opt/rocm's libamdhip64 first
         # the very file that is already mapped (dlopen by soname could resolve to another copy of the runtime, which
         # then finds no device: the process already holds the first one's)
-        path = None
+        paths = []
         with open("/proc/self/maps") as f:
             for line in f:
-                if "libamdhip64" in line:
-                    path = line.split()[-1]
-                    break
-        assert path, "libocean_hip.so did not pull in libamdhip64"
+                if "libamdhip64" in line and line.split()[-1] not in paths:
+                    paths.append(line.split()[-1])
+        assert paths, "libocean_hip.so did not pull in libamdhip64"
+        # a test that imported torch has mapped torch's bundled copy as well (same soname, second runtime): ours is the
+        # one libocean_hip.so is linked against, /opt/rocm's
+        ours = [q for q in paths if "/torch/" not in q]
+        path = (ours or paths)[0]
         _HIP = ctypes.CDLL(path)
         _HIP.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
         _HIP.hipFree.argtypes = [ctypes.c_void_p]

@@ -175,9 +175,12 @@ def test_emu_half_spectrum_frame(ref_inputs_256, t, P):
     assert np.all(out[..., 3] == 0.0)
 
 
-def test_emu_half_spectrum_frame_512(ref_inputs):
+@pytest.mark.parametrize("P", [2, 1])
+def test_emu_half_spectrum_frame_512(ref_inputs, P):
+    """N = 512 as shipped: ONE column per pass-1 workgroup, three field groups (FPAR), stores from registers; one row per
+    pass-2 workgroup with 8 elements per thread and two transform groups (PPAR).  And two columns per workgroup."""
     h0, om = ref_inputs
-    assert_parity(emu.frame_half(h0, om, 10.0)[..., :3], oc.frame_f64(h0, om, 10.0)[..., :3], 5e-6, "emu half 512")
+    assert_parity(emu.frame_half(h0, om, 10.0, P=P)[..., :3], oc.frame_f64(h0, om, 10.0)[..., :3], 5e-6, f"emu half 512 P={P}")
 
 
 def test_emu_fp16_spectrum_config5(ref_inputs_256):

@@ -12,6 +12,7 @@ Parity metric as everywhere: normalised max and relative L2 per chan
 usage: python tools/inter16_numerics.py [N] [t]"""
 import json
 import os
+import re
 import sys
 
 import numpy as np
@@ -52,6 +53,17 @@ def requantise(c, mode):
         scale = 2.0 ** (14 - e)                                               # max lands in [2^14, 2^15)
         q = (blk * scale).astype(np.float16).astype(np.float64) / scale
         v = q.reshape(n, n // 2, 2)
+    elif mode.startswith("bfp16_r"):
+        # int16 mantissas, ONE exponent per block of R rows x C columns kept in a side array: the blocks a
+        # pass-1 wave stores with one instruction -- 64 lanes x (2 columns of one row) = 64 rows x 2 columns at N = 8192
+        # (P = 2), 32 rows x 4 columns at N = 4096 (P = 4) -- so that the exponent is a wave max-reduction
+        r_, c_ = (int(x) for x in re.match(r"bfp16_r(\d+)c(\d+)", mode).groups())
+        blk = v.reshape(n // r_, r_, (n // 2) // c_, c_, 2)
+        mx = np.abs(blk).max(axis=(1, 3, 4), keepdims=True)
+        e = np.where(mx > 0, np.floor(np.log2(np.maximum(mx, 1e-300))) + 1, 0)
+        step = 2.0 ** (e - 15)
+        q = np.clip(np.rint(blk / step), -(2 ** 15), 2 ** 15 - 1) * step
+        v = q.reshape(n, n // 2, 2)
     else:
         bits = 16 if mode == "bfp16" else 15
         blk = v.reshape(n, n // 8, 4, 2)                                      # row piece: 4 complex
@@ -71,16 +83,23 @@ def requantise(c, mode):
 
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-    t = float(sys.argv[2]) if len(sys.argv) > 2 else 1.25
+    pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+    n = int(pos[0]) if len(pos) > 0 else 2048
+    t = float(pos[1]) if len(pos) > 1 else 1.25
     h0, om = g.synth.make_inputs(n)
+    if "--f16-spectrum" in sys.argv:                  # config 5: the spectrum the kernels use is the fp16-quantised one
+        s_ = 14 - int(np.floor(np.log2(np.abs(h0.view(np.float32)).max())))
+        q = (h0.view(np.float32) * np.float32(2.0 ** s_)).astype(np.float16).astype(np.float32) * np.float32(2.0 ** -s_)
+        h0 = q.view(np.complex64).reshape(h0.shape)
     H, DX, DZ = oc.propagate_f64(h0, om, t)
     cols = symmetrised_column_transforms([DX, H, DZ])
     ref = np.stack(finish(cols, n), -1)
-    chk = oc.frame_f64(h0, om, t)[..., :3]
-    base = oc.parity_errors(ref, chk)
-    res = {"n": n, "t": t, "self_check_vs_frame_f64": [float(base[0].max()), float(base[1].max())]}
-    for mode in ("fp16", "bfp16", "bfp15"):
+    res = {"n": n, "t": t, "f16_spectrum": "--f16-spectrum" in sys.argv}
+    if n <= 4096:
+        chk = oc.frame_f64(h0, om, t)[..., :3]
+        base = oc.parity_errors(ref, chk)
+        res["self_check_vs_frame_f64"] = [float(base[0].max()), float(base[1].max())]
+    for mode in ("fp16", "bfp16", "bfp15", "bfp16_r4c4", "bfp16_r32c4", "bfp16_r64c2", "bfp16_r16c2"):
         out = np.stack(finish([requantise(c, mode) for c in cols], n), -1)
         nmax, rl2 = oc.parity_errors(out, ref)
         res[mode] = {"normalised_max": [float(x) for x in nmax], "rel_l2": [float(x) for x in rl2]}

@@ -5,6 +5,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -DOCEAN_TIMELINE -I gfx_ocean_amd/csrc tools/timeline.hip -o tools/timeline
 #include "../gfx_ocean_amd/csrc/ocean_api.hip"
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <random>
 
@@ -49,6 +50,17 @@ int main(int argc, char** argv) {
     ocean_debug_pass(ctx, 2, 0.5f); ocean_sync(ctx);
     ocean_time_frames(ctx, 20, 0.f, 1.f / 60, &ms);
     printf("N=%d frame %.1f us (with probes)\n", N, ms / 20 * 1000);
+    {   // which side bounds a frame loop: the host's submission of the two launches, or the GPU?
+        const int K = 4000;
+        ocean_sync(ctx);
+        const auto h0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < K; ++i) ocean_frame(ctx, i / 60.f, nullptr);
+        const auto h1 = std::chrono::steady_clock::now();
+        ocean_sync(ctx);
+        const auto h2 = std::chrono::steady_clock::now();
+        printf("frame loop of %d frames: host submit %.2f us/frame, until the GPU is idle %.2f us/frame\n", K,
+               std::chrono::duration<double, std::micro>(h1 - h0).count() / K, std::chrono::duration<double, std::micro>(h2 - h0).count() / K);
+    }
     std::vector<unsigned long long> tl((size_t)maxblocks * 16 * 2);
     hipMemcpy(tl.data(), d_tl, tl.size() * 8, hipMemcpyDeviceToHost);
     for (int pass = 1; pass <= 2; ++pass) {
