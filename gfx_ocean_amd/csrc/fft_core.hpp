@@ -225,19 +225,33 @@ __device__ __forceinline__ void apply_twiddles(c32 (&a)[R], c32 w, const c32* __
 // would occupy after the exchange of the last pass.
 // TWS: stride of the twiddle table (the table holds e^{+2 pi i k / (N*TWS)}: a length-N transform inside a
 // context whose table was made for N*TWS points, see the split kernels of ocean_kernels.hpp).
-template <int N, int E, int R, int NS, int TWS = 1, class Emit>
+// HWTW: the pass' base twiddle e^{+2 pi i step / (N TWS)} comes from the transcendental unit (v_cos_f32 / v_sin_f32 take
+// revolutions, step / (N TWS) is exact in fp32; max abs error 1.25e-7, tools/sincos_acc.hip) instead of the table in
+// memory: at the latency-bound sizes the dependent table load of every pass (~0.3 us of L2 latency with one wave per
+// SIMD) is the longest single item of a transform.  R <= 16 only (larger radices read high powers from the table).
+template <int TABLE, bool HWTW>
+__device__ __forceinline__ c32 base_twiddle(const c32* __restrict__ tw, int step) {
+    if constexpr (HWTW) {
+        const float rev = (float)step * (1.0f / (float)TABLE);
+        return mk(cos_rev(rev), sin_rev(rev));
+    } else {
+        return tw[step];
+    }
+}
+template <int N, int E, int R, int NS, int TWS = 1, bool HWTW = false, class Emit>
 __device__ __forceinline__ void fft_pass(c32 (&reg)[E], int j, const c32* __restrict__ tw, Emit&& emit) {
     constexpr int T = N / E;
     constexpr int U = E / R;
+    static_assert(!HWTW || R <= 16, "hardware twiddles: radix <= 16");
     c32 w = mk(1.0f, 0.0f);
     constexpr int TW_MASK = N * TWS - 1;                               // the table holds e^{+2 pi i k / (N TWS)}, k < N TWS
     int step = 0;
-    if constexpr (NS > 1 && U == 1) { step = (j & (NS - 1)) * (TWS * (N / (NS * R))); w = tw[step]; }
+    if constexpr (NS > 1 && U == 1) { step = (j & (NS - 1)) * (TWS * (N / (NS * R))); w = base_twiddle<N * TWS, HWTW>(tw, step); }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int jv = j + u * T;
         const int k = jv & (NS - 1);
-        if constexpr (NS > 1 && U > 1) { step = k * (TWS * (N / (NS * R))); w = tw[step]; }
+        if constexpr (NS > 1 && U > 1) { step = k * (TWS * (N / (NS * R))); w = base_twiddle<N * TWS, HWTW>(tw, step); }
         c32 a[R], b[R];
 #pragma unroll
         for (int t = 0; t < R; ++t) a[t] = reg[u + t * U];
@@ -254,10 +268,10 @@ __device__ __forceinline__ void fft_pass(c32 (&reg)[E], int j, const c32* __rest
 
 // Exchange through one padded LDS line buffer: scatter `reg` outputs of a pass, then gather
 // positions j + e*T.  `bar()` is the workgroup barrier (all threads of the WG call it).
-template <int N, int E, int R, int NS, int TWS = 1, int SYNC_T = 1024>
+template <int N, int E, int R, int NS, int TWS = 1, int SYNC_T = 1024, bool HWTW = false>
 __device__ __forceinline__ void fft_pass_exchange(c32 (&reg)[E], int j, const c32* __restrict__ tw, c32* lds_line) {
     constexpr int T = N / E;
-    fft_pass<N, E, R, NS, TWS>(reg, j, tw, [&](int, int ppos, c32 v, int) { lds_line[ppos] = v; });
+    fft_pass<N, E, R, NS, TWS, HWTW>(reg, j, tw, [&](int, int ppos, c32 v, int) { lds_line[ppos] = v; });
     OCEAN_FFT_RAW_BARRIER(SYNC_T);
     // lds_pad(j + e*T) == lds_pad(j) + e*(T + T/16)   (T is a multiple of 16)
     const c32* g = lds_line + lds_pad(j);
@@ -268,7 +282,7 @@ __device__ __forceinline__ void fft_pass_exchange(c32 (&reg)[E], int j, const c3
 // Whole line transform.  On entry reg[e] = x[j + e*T]; on exit reg[e] = X[j + e*T].
 // lds_line: LdsLine<N>::elems c32 owned by this line.  Every thread of the workgroup must call
 // this the same number of times (with T > 64 it contains __syncthreads()).
-template <int N, int E, int TWS = 1, bool CONTIG = false>
+template <int N, int E, int TWS = 1, bool CONTIG = false, bool HWTW = false>
 __device__ __forceinline__ void fft_line(c32 (&reg)[E], int j, const c32* __restrict__ tw, c32* lds_line) {
     constexpr int SYNC_T = (CONTIG && N / E <= 64) ? N / E : 1024;
     constexpr int R0 = Plan<N, E>::first_radix();
@@ -277,29 +291,29 @@ __device__ __forceinline__ void fft_line(c32 (&reg)[E], int j, const c32* __rest
     int ns = 1;
     (void)ns;
     if constexpr (R0 > 1) {
-        fft_pass_exchange<N, E, R0, 1, TWS, SYNC_T>(reg, j, tw, lds_line);
+        fft_pass_exchange<N, E, R0, 1, TWS, SYNC_T, HWTW>(reg, j, tw, lds_line);
         OCEAN_FFT_WAR_BARRIER(SYNC_T);   // WAR: next scatter reuses the buffer
     }
     constexpr int NS1 = R0;                  // after the optional small pass
     if constexpr (Q == 1) {
         c32 out[E];
-        fft_pass<N, E, E, NS1, TWS>(reg, j, tw, [&](int, int, c32 v, int slot) { out[slot] = v; });
+        fft_pass<N, E, E, NS1, TWS, HWTW>(reg, j, tw, [&](int, int, c32 v, int slot) { out[slot] = v; });
 #pragma unroll
         for (int e = 0; e < E; ++e) reg[e] = out[e];
     } else {
-        fft_pass_exchange<N, E, E, NS1, TWS, SYNC_T>(reg, j, tw, lds_line);
+        fft_pass_exchange<N, E, E, NS1, TWS, SYNC_T, HWTW>(reg, j, tw, lds_line);
         constexpr int NS2 = NS1 * E;
         if constexpr (Q == 2) {
             c32 out[E];
-            fft_pass<N, E, E, NS2, TWS>(reg, j, tw, [&](int, int, c32 v, int slot) { out[slot] = v; });
+            fft_pass<N, E, E, NS2, TWS, HWTW>(reg, j, tw, [&](int, int, c32 v, int slot) { out[slot] = v; });
 #pragma unroll
             for (int e = 0; e < E; ++e) reg[e] = out[e];
         } else {
             OCEAN_FFT_WAR_BARRIER(SYNC_T);
-            fft_pass_exchange<N, E, E, NS2, TWS, SYNC_T>(reg, j, tw, lds_line);
+            fft_pass_exchange<N, E, E, NS2, TWS, SYNC_T, HWTW>(reg, j, tw, lds_line);
             constexpr int NS3 = NS2 * E;
             c32 out[E];
-            fft_pass<N, E, E, NS3, TWS>(reg, j, tw, [&](int, int, c32 v, int slot) { out[slot] = v; });
+            fft_pass<N, E, E, NS3, TWS, HWTW>(reg, j, tw, [&](int, int, c32 v, int slot) { out[slot] = v; });
 #pragma unroll
             for (int e = 0; e < E; ++e) reg[e] = out[e];
         }
@@ -309,27 +323,27 @@ __device__ __forceinline__ void fft_line(c32 (&reg)[E], int j, const c32* __rest
 // Same transform, but the final pass scatters into the LDS line (padded positions) and the
 // function returns after a barrier: lds_line[lds_pad(n)] = X[n] for the whole line.  Used when
 // the global store wants a different thread->element mapping than the FFT's (chunked layouts).
-template <int N, int E, int TWS = 1, bool CONTIG = false>
+template <int N, int E, int TWS = 1, bool CONTIG = false, bool HWTW = false>
 __device__ __forceinline__ void fft_line_to_lds(c32 (&reg)[E], int j, const c32* __restrict__ tw, c32* lds_line) {
     constexpr int SYNC_T = (CONTIG && N / E <= 64) ? N / E : 1024;
     constexpr int R0 = Plan<N, E>::first_radix();
     constexpr int Q = Plan<N, E>::full_passes();
     static_assert(Q >= 2 && Q <= 3, "unsupported N/E combination");
     if constexpr (R0 > 1) {
-        fft_pass_exchange<N, E, R0, 1, TWS, SYNC_T>(reg, j, tw, lds_line);
+        fft_pass_exchange<N, E, R0, 1, TWS, SYNC_T, HWTW>(reg, j, tw, lds_line);
         OCEAN_FFT_WAR_BARRIER(SYNC_T);
     }
     constexpr int NS1 = R0;
-    fft_pass_exchange<N, E, E, NS1, TWS, SYNC_T>(reg, j, tw, lds_line);
+    fft_pass_exchange<N, E, E, NS1, TWS, SYNC_T, HWTW>(reg, j, tw, lds_line);
     OCEAN_FFT_WAR_BARRIER(SYNC_T);
     constexpr int NS2 = NS1 * E;
     if constexpr (Q == 2) {
-        fft_pass<N, E, E, NS2, TWS>(reg, j, tw, [&](int, int ppos, c32 v, int) { lds_line[ppos] = v; });
+        fft_pass<N, E, E, NS2, TWS, HWTW>(reg, j, tw, [&](int, int ppos, c32 v, int) { lds_line[ppos] = v; });
     } else {
-        fft_pass_exchange<N, E, E, NS2, TWS, SYNC_T>(reg, j, tw, lds_line);
+        fft_pass_exchange<N, E, E, NS2, TWS, SYNC_T, HWTW>(reg, j, tw, lds_line);
         OCEAN_FFT_WAR_BARRIER(SYNC_T);
         constexpr int NS3 = NS2 * E;
-        fft_pass<N, E, E, NS3, TWS>(reg, j, tw, [&](int, int ppos, c32 v, int) { lds_line[ppos] = v; });
+        fft_pass<N, E, E, NS3, TWS, HWTW>(reg, j, tw, [&](int, int ppos, c32 v, int) { lds_line[ppos] = v; });
     }
     __syncthreads();
 }

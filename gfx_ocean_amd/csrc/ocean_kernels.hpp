@@ -21,6 +21,12 @@
 
 namespace ocean {
 
+// Fused kernels at N <= this take the base twiddle of every pass from v_sin/v_cos instead of the table (fft_core.hpp
+// base_twiddle; the reference evaluates cos/sin per butterfly, shader/fft_row.comp:32-33).  A/B knob (0 = table everywhere).
+#ifndef OCEAN_HWTW_MAX_N
+#define OCEAN_HWTW_MAX_N 1024
+#endif
+
 // shader/propagate.comp:6 -- `const float pi = 3.1415926;` (fp32 0x40490FDA)
 #define OCEAN_PI_F 3.1415926f
 
@@ -1018,7 +1024,7 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
         const int f = FPAR ? fg : ff;
 #endif
         c32 reg[E];
-        const int jf = opaque_lane(j);
+        const int jf = FPAR ? j : opaque_lane(j);                  // (one field per thread: nothing to keep apart, and the twiddle loads may move up)
         half_spectrum<N, E>(f, A, B, kxv, kscale, jf, reg);
         if (packs_nyquist) {
             const c32* z = nyq_spec + (size_t)f * N + jf;
@@ -1041,7 +1047,7 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
             // ends in registers, X[j + e T], and every lane stores its 8-byte elements straight into the chunks (a
             // quarter of a chunk row each; the four column workgroups of a chunk column run on one XCD and the
             // cache-resident intermediate merges there).
-            fft_line<N, E, 1, true>(reg, jf, tw, lds_line);      // the threads of a line are consecutive lanes
+            fft_line<N, E, 1, true, (N <= OCEAN_HWTW_MAX_N)>(reg, jf, tw, lds_line);   // the threads of a line are consecutive lanes
             OCEAN_TL(2 + 2 * (FPAR ? f : ff));
             c32* dcol = inter + (size_t)f * lay.fs + (size_t)(X / CW) * lay.sx + (X % CW);
 #pragma unroll
@@ -1052,7 +1058,7 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
             OCEAN_TL(3 + 2 * (FPAR ? f : ff));
             continue;
         }
-        fft_line_to_lds<N, E, 1, true>(reg, jf, tw, lds_line);
+        fft_line_to_lds<N, E, 1, true, (N <= OCEAN_HWTW_MAX_N)>(reg, jf, tw, lds_line);
 #endif
         OCEAN_TL(2 + 2 * (FPAR ? f : ff));
         // chunk row Y = i / CR + q * (2T / CR): the thread's part and the (wave-uniform, scalar) part of the address add
@@ -1464,7 +1470,7 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
 #pragma unroll
     for (int it = 0; it < (PPAR ? 1 : 2); ++it) {                  // pass 0: height, 1: (disp_x, disp_z)
         const int pass = PPAR ? pg : it;
-        const int jf = opaque_lane(j);
+        const int jf = PPAR ? j : opaque_lane(j);
         const int lk = (R2 == 1) ? jf : opaque_lane(lk0);
         const size_t off = chunk_row_offset(lay, ly / CR) + (size_t)(lk / P1) * lay.sx + (ly % CR) * P1 + (lk % P1);
         c32 a[EH], b[EH];
@@ -1523,7 +1529,7 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
         for (int e = 0; e < E; ++e) reg[e] = g[e * (T + T / 16)];
         __syncthreads();
 #ifndef OCEAN_X2_NOFFT   // timing experiment only (wrong results): pass 2 without its transforms
-        fft_line<N, E, 1, true>(reg, jf, tw, lds_line);          // (ll, j): the threads of a row are consecutive lanes
+        fft_line<N, E, 1, true, (N <= OCEAN_HWTW_MAX_N)>(reg, jf, tw, lds_line);   // (ll, j): the threads of a row are consecutive lanes
 #endif
         OCEAN_TL(2 + 3 * pass);
         if constexpr (PPAR) {                                      // group 0 hands its row of heights to group 1
