@@ -29,6 +29,7 @@ SYMBOLS = [
     "ocean_bind_displacement", "ocean_stream", "ocean_time_frames", "ocean_profile_frame", "ocean_profile_staged",
     "ocean_shard_create", "ocean_shard_destroy", "ocean_shard_last_error", "ocean_shard_upload", "ocean_shard_rows",
     "ocean_shard_cols", "ocean_shard_sync", "ocean_shard_stream",
+    "ocean_tile_exchange_bytes", "ocean_tile_pass1", "ocean_tile_pass2",
 ]
 
 
@@ -131,6 +132,9 @@ def load_library():
         "ocean_shard_cols": (i32, [vp, vp, vp, vp]),
         "ocean_shard_sync": (i32, [vp]),
         "ocean_shard_stream": (vp, [vp]),
+        "ocean_tile_exchange_bytes": (ctypes.c_int64, [vp, i32]),
+        "ocean_tile_pass1": (i32, [vp, ctypes.POINTER(PropagateLocalsC), i32, i32, vp, vp]),
+        "ocean_tile_pass2": (i32, [vp, i32, i32, vp, vp, vp]),
     }
     assert sorted(sig) == sorted(SYMBOLS)
     for name, (res, args) in sig.items():

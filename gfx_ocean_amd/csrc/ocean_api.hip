@@ -210,6 +210,9 @@ template <int N> struct Launch {
             e = hipFuncSetAttribute((const void*)k_half_pass2<N, H::E2, CHUNK_W, H::R2h, H::p2_group, H::ppar>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, H::half_lds2);
             if (e != hipSuccess) return e;
+            e = hipFuncSetAttribute((const void*)k_half_pass2<N, H::E2, CHUNK_W, H::R2h, H::p2_group, H::ppar, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, H::half_lds2);
+            if (e != hipSuccess) return e;
         }
         if constexpr (split_built<PSEL>()) {
             e = hipFuncSetAttribute((const void*)k_half_pass1_split<N, H::E1S, H::P, false, H::handover>,
@@ -219,6 +222,9 @@ template <int N> struct Launch {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, H::split_lds1);
             if (e != hipSuccess) return e;
             e = hipFuncSetAttribute((const void*)k_half_pass2_split<N, H::E, CHUNK_W, H::p2_group>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, H::split_lds2);
+            if (e != hipSuccess) return e;
+            e = hipFuncSetAttribute((const void*)k_half_pass2_split<N, H::E, CHUNK_W, H::p2_group, true>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, H::split_lds2);
         }
         return e;
@@ -231,11 +237,11 @@ template <int N> struct Launch {
                 if (c->h0_f16)
                     launch(k_half_pass1_split<N, H::E1S, H::P, true, H::handover>, dim3(H::half_grid1), dim3(H::split_threads1),
                            H::split_lds1, s, t, (const void*)c->h0T, descale, (const float*)c->omegaT, c->inter, c->nyq,
-                           (const c32*)c->tw, c->lay_h, time, domain);
+                           (const c32*)c->tw, c->lay_h, time, domain, 0);
                 else
                     launch(k_half_pass1_split<N, H::E1S, H::P, false, H::handover>, dim3(H::half_grid1), dim3(H::split_threads1),
                            H::split_lds1, s, t, (const void*)c->h0T, 1.0f, (const float*)c->omegaT, c->inter, c->nyq,
-                           (const c32*)c->tw, c->lay_h, time, domain);
+                           (const c32*)c->tw, c->lay_h, time, domain, 0);
                 return;
             }
         }
@@ -243,11 +249,11 @@ template <int N> struct Launch {
             if (c->h0_f16)
                 launch(k_half_pass1<N, H::E1, H::P, true, H::handover, H::fpar>, dim3(H::half_grid1), dim3(H::half_threads1), H::half_lds1, s, t,
                        (const void*)c->h0T, descale, (const float*)c->omegaT, c->inter, c->nyq, (const c32*)c->tw,
-                       c->lay_h, time, domain);
+                       c->lay_h, time, domain, 0);
             else
                 launch(k_half_pass1<N, H::E1, H::P, false, H::handover, H::fpar>, dim3(H::half_grid1), dim3(H::half_threads1), H::half_lds1, s, t,
                        (const void*)c->h0T, 1.0f, (const float*)c->omegaT, c->inter, c->nyq, (const c32*)c->tw,
-                       c->lay_h, time, domain);
+                       c->lay_h, time, domain, 0);
         }
     }
     template <int PSEL> static void half_pass2(OceanContext* c, hipStream_t s, Timing t) {
@@ -276,6 +282,45 @@ template <int N> struct Launch {
         if constexpr (plain_built<PSEL>())
             launch(k_half_pass2<N, H::E2, CHUNK_W, H::R2h, H::p2_group, H::ppar>, dim3(H::half_grid2), dim3(H::half_threads2), H::half_lds2, s, t,
                    (const c32*)c->inter, c->out, (const c32*)c->tw, c->lay_h);
+    }
+    // ---- one tile sharded over `world` GPUs (ocean_tile_pass1 / ocean_tile_pass2): the same kernels on this rank's
+    // block of half-spectrum columns (pass 1, writing the all-to-all send buffer) and block of rows (pass 2, reading the
+    // receive buffer).
+    static bool tile_supported(int world) {
+        using H = Geo<N, default_psel()>;
+        return H::tile_supported(world);
+    }
+    static void tile_pass1(OceanContext* c, float time, float domain, int rank, int world, c32* send, hipStream_t s) {
+        using H = Geo<N, default_psel()>;
+        const InterLayout lay = H::tile_layout(world);
+        const int groups = (N / 2 / world) / H::P;
+        const float descale = c->h0_f16 ? std::ldexp(1.0f, -c->scale_log2) : 1.0f;
+        if constexpr (split_built<default_psel()>()) {
+            if (c->h0_f16)
+                hipLaunchKernelGGL((k_half_pass1_split<N, H::E1S, H::P, true, H::handover>), dim3(groups), dim3(H::split_threads1), H::split_lds1, s,
+                                   (const void*)c->h0T, descale, (const float*)c->omegaT, send, c->nyq, (const c32*)c->tw, lay, time, domain, rank * groups);
+            else
+                hipLaunchKernelGGL((k_half_pass1_split<N, H::E1S, H::P, false, H::handover>), dim3(groups), dim3(H::split_threads1), H::split_lds1, s,
+                                   (const void*)c->h0T, descale, (const float*)c->omegaT, send, c->nyq, (const c32*)c->tw, lay, time, domain, rank * groups);
+        } else {
+            if (c->h0_f16)
+                hipLaunchKernelGGL((k_half_pass1<N, H::E1, H::P, true, H::handover, H::fpar>), dim3(groups), dim3(H::half_threads1), H::half_lds1, s,
+                                   (const void*)c->h0T, descale, (const float*)c->omegaT, send, c->nyq, (const c32*)c->tw, lay, time, domain, rank * groups);
+            else
+                hipLaunchKernelGGL((k_half_pass1<N, H::E1, H::P, false, H::handover, H::fpar>), dim3(groups), dim3(H::half_threads1), H::half_lds1, s,
+                                   (const void*)c->h0T, descale, (const float*)c->omegaT, send, c->nyq, (const c32*)c->tw, lay, time, domain, rank * groups);
+        }
+    }
+    static void tile_pass2(OceanContext* c, int world, const c32* recv, float4* out_rows, hipStream_t s) {
+        using H = Geo<N, default_psel()>;
+        const InterLayout lay = H::tile_layout(world);
+        const int rows = N / world;
+        if constexpr (split_built<default_psel()>())
+            hipLaunchKernelGGL((k_half_pass2_split<N, H::E, CHUNK_W, H::p2_group, true>), dim3(rows), dim3(H::split_threads2), H::split_lds2, s,
+                               recv, out_rows, (const c32*)c->tw, lay);
+        else
+            hipLaunchKernelGGL((k_half_pass2<N, H::E2, CHUNK_W, H::R2h, H::p2_group, H::ppar, true>), dim3(rows / H::R2h), dim3(H::half_threads2),
+                               H::half_lds2, s, recv, out_rows, (const c32*)c->tw, lay);
     }
     static void stage_rows(OceanContext* c, int f, hipStream_t s) {
 #ifdef OCEAN_STAGE_ROWS_THIN   // A/B: one row per 256-thread workgroup, 32-byte chunk pieces merged in L2
@@ -883,6 +928,43 @@ int32_t ocean_bind_displacement(OceanContext* ctx, void* device_rgba) {
     return OCEAN_OK;
 }
 void* ocean_stream(OceanContext* ctx) { return valid(ctx) ? (void*)ctx->stream : nullptr; }
+
+// ---- one tile over several GPUs, second generation (half-spectrum, fused; include/ocean_hip.h) ------------------------
+static int32_t tile_check(OceanContext* ctx, int32_t rank, int32_t world) {
+    if (!ctx->uploaded) return fail(ctx, OCEAN_E_STATE, "ocean_upload_spectrum has not been called");
+    if (ctx->quirks != OCEAN_QUIRKS_REFERENCE) return fail(ctx, OCEAN_E_STATE, "the fused kernels implement the reference quirks only (ocean_set_quirks)");
+    bool ok = false;
+    OCEAN_DISPATCH(ctx->n, ok = L::tile_supported(world));
+    if (!ok || rank < 0 || rank >= world)
+        return fail(ctx, OCEAN_E_INVALID_ARG, "sharded tile: world must be a power of two with at least 32 rows per rank, 0 <= rank < world");
+    return OCEAN_OK;
+}
+int64_t ocean_tile_exchange_bytes(const OceanContext* ctx, int32_t world) {
+    if (!valid(ctx) || world < 1 || (world & (world - 1)) || ctx->n / world < 32) return OCEAN_E_INVALID_ARG;
+    return (int64_t)3 * (ctx->n / 2) * (int64_t)(ctx->n / world) * 8;          // per rank: send buffer = receive buffer
+}
+int32_t ocean_tile_pass1(OceanContext* ctx, const OceanPropagateLocals* locals, int32_t rank, int32_t world, void* send_device,
+                         void* stream) {
+    if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    if (!locals || !send_device) return fail(ctx, OCEAN_E_INVALID_ARG, "NULL argument");
+    if (locals->resolution != ctx->n) return fail(ctx, OCEAN_E_INVALID_ARG, "PropagateLocals.resolution != context resolution");
+    if (!(locals->domain_size > 0.0f)) return fail(ctx, OCEAN_E_INVALID_ARG, "domain_size must be > 0");
+    if (reinterpret_cast<uintptr_t>(send_device) & 15u) return fail(ctx, OCEAN_E_INVALID_ARG, "send buffer must be 16-byte aligned");
+    { const int32_t st = tile_check(ctx, rank, world); if (st != OCEAN_OK) return st; }
+    DeviceGuard guard(ctx->device);
+    OCEAN_DISPATCH(ctx->n, L::tile_pass1(ctx, locals->time, locals->domain_size, rank, world, (c32*)send_device, pick(ctx, stream)));
+    return check_launch(ctx, "ocean_tile_pass1 launch");
+}
+int32_t ocean_tile_pass2(OceanContext* ctx, int32_t rank, int32_t world, const void* recv_device, void* out_rows_device, void* stream) {
+    if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    if (!recv_device || !out_rows_device) return fail(ctx, OCEAN_E_INVALID_ARG, "NULL argument");
+    if ((reinterpret_cast<uintptr_t>(recv_device) | reinterpret_cast<uintptr_t>(out_rows_device)) & 15u)
+        return fail(ctx, OCEAN_E_INVALID_ARG, "buffers must be 16-byte aligned");
+    { const int32_t st = tile_check(ctx, rank, world); if (st != OCEAN_OK) return st; }
+    DeviceGuard guard(ctx->device);
+    OCEAN_DISPATCH(ctx->n, L::tile_pass2(ctx, world, (const c32*)recv_device, (float4*)out_rows_device, pick(ctx, stream)));
+    return check_launch(ctx, "ocean_tile_pass2 launch");
+}
 
 // ---- measurement ----------------------------------------------------------------------------------
 int32_t ocean_time_frames(OceanContext* ctx, int32_t frames, float t0, float dt, float* out_ms) {

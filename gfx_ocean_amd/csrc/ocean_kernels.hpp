@@ -240,7 +240,15 @@ k_fft_lines(c32* __restrict__ data, const c32* __restrict__ tw) {
 // ---------------------------------------------------------------------------------------------
 // Intermediate (between the two passes): 4 x 4 chunks of c32 (128 bytes).  Chunk (X, Y) holds columns
 // x = 4 X + c and rows y = 4 Y + r at offset 4 r + c.  Field order: 0 = disp_x, 1 = height, 2 = disp_z (OCEAN_FIELD_*).
-struct InterLayout { size_t sx, sy, fs; int bshift; };
+struct InterLayout {
+    size_t sx, sy, fs;
+    int bshift;
+    // One tile sharded over several GPUs (ocean_tile_pass1 / ocean_tile_pass2, SHARD kernels only): the receive buffer
+    // of the all-to-all holds the chunk columns of source rank s in its own slab, chunk column X = s * 2^xs_shift + Xl at
+    //     s * src_stride + (the layout above with X = Xl).   Unsharded: xs_shift = 31 (one slab).
+    int xs_shift = 31;
+    size_t src_stride = 0;
+};
 // Rows of chunks are grouped in blocks of B = 2^bshift: chunk (X, Y) sits at
 //     field * fs + (Y / B) * sy + X * sx + (Y % B) * 16        (elements; 16 = one 128-byte chunk).
 // B = 1 is pass-2-contiguous (the chunks of one chunk row adjacent, sx = 16: pass 2 streams 64 KiB runs while pass 1
@@ -968,7 +976,7 @@ template <int E> constexpr int pass1_waves_per_simd(int threads) {
 template <int N, int E, int P, bool H16, bool HAND = false, bool FPAR = false>
 __global__ void __launch_bounds__((N / E) * P * (FPAR ? 3 : 1), pass1_waves_per_simd<E>((N / E) * P * (FPAR ? 3 : 1)))
 k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restrict__ omegaT, c32* __restrict__ inter,
-             c32* nyq_spec, const c32* __restrict__ tw, InterLayout lay, float time, float domain_size) {
+             c32* nyq_spec, const c32* __restrict__ tw, InterLayout lay, float time, float domain_size, int x_group0) {
     constexpr int T = N / E;
     constexpr int GT = T * P;                                      // threads of one field group (= the workgroup without FPAR)
     constexpr int H2 = P / 2;
@@ -987,15 +995,19 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
     c32* lds_line = lds_grp + c * LinePitch<N>::elems;
     const float kscale = OCEAN_PI_F / domain_size;
 
+    // X: the workgroup's column group within this launch (= within the intermediate it writes); Xg: within the tile.
+    // They differ only when the tile is sharded over several GPUs and this rank transforms the column groups
+    // [x_group0, x_group0 + gridDim.x) (ocean_tile_pass1).
     const int X = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
-    if (X == 0) nyquist_spectra<N, H16, GT * (FPAR ? 3 : 1)>(h0T, descale, omegaT, nyq_spec, tid, time, kscale);   // uniform branch
+    const int Xg = X + x_group0;
+    if (Xg == 0) nyquist_spectra<N, H16, GT * (FPAR ? 3 : 1)>(h0T, descale, omegaT, nyq_spec, tid, time, kscale);   // uniform branch
 #ifdef OCEAN_SETPRIO
     // One wave of every line sits on each SIMD (T = 4 waves per line, waves dealt to the SIMDs cyclically):
     // the line index is a priority that differs between the waves sharing a SIMD.
     if constexpr (T >= 64) wave_priority((OCEAN_SETPRIO == 2) ? (3 - c) : c);
 #endif
-    const bool packs_nyquist = (X == 0) && (c == 0);               // line 0 of that workgroup: column 0 + i * Nyquist
-    const uint32_t x = (uint32_t)(X * P + c);                      // kx in [0, N/2)
+    const bool packs_nyquist = (Xg == 0) && (c == 0);              // line 0 of that workgroup: column 0 + i * Nyquist
+    const uint32_t x = (uint32_t)(Xg * P + c);                     // kx in [0, N/2)
     const uint32_t x2 = (N - x) & (N - 1);
     c32 A[E], B[E];
     OCEAN_TL(0);
@@ -1312,7 +1324,7 @@ __device__ __forceinline__ void half_load_AB_pairs_handover(const void* __restri
 template <int N, int E, int P, bool H16, bool HAND = false>
 __global__ void __launch_bounds__((N / E) * P, pass1_waves_per_simd<E>((N / E) * P))
 k_half_pass1_split(const void* __restrict__ h0T, float descale, const float* __restrict__ omegaT, c32* __restrict__ inter,
-                   c32* nyq_spec, const c32* __restrict__ tw, InterLayout lay, float time, float domain_size) {
+                   c32* nyq_spec, const c32* __restrict__ tw, InterLayout lay, float time, float domain_size, int x_group0) {
     constexpr int M = N / 2;                                       // sub-transform length
     constexpr int TS = M / E;                                      // threads per sub-line
     constexpr int THREADS = 2 * P * TS;
@@ -1327,13 +1339,14 @@ k_half_pass1_split(const void* __restrict__ h0T, float descale, const float* __r
     c32* lds_line = lds + l * LinePitch<M>::elems;
     const float kscale = OCEAN_PI_F / domain_size;
 
-    const int X = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
-    if (X == 0) nyquist_spectra<N, H16, THREADS>(h0T, descale, omegaT, nyq_spec, tid, time, kscale);   // uniform branch
+    const int X = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);   // within this launch; Xg within the tile (k_half_pass1)
+    const int Xg = X + x_group0;
+    if (Xg == 0) nyquist_spectra<N, H16, THREADS>(h0T, descale, omegaT, nyq_spec, tid, time, kscale);   // uniform branch
 #ifdef OCEAN_SETPRIO
     if constexpr (TS >= 64) wave_priority((OCEAN_SETPRIO == 2) ? (3 - l) : l);   // one wave of every sub-line per SIMD
 #endif
-    const bool packs_nyquist = (X == 0) && (c == 0);               // both parities of column 0 carry the Nyquist column
-    const uint32_t x = (uint32_t)(X * P + c);
+    const bool packs_nyquist = (Xg == 0) && (c == 0);              // both parities of column 0 carry the Nyquist column
+    const uint32_t x = (uint32_t)(Xg * P + c);
     const uint32_t x2 = (N - x) & (N - 1);
     c32 A[E], B[E];
     OCEAN_TL(0);
@@ -1410,7 +1423,9 @@ template <int N, int R2> struct Pitch2 { static constexpr int elems = LdsLine<N>
 // transforms the height rows, group 1 the (disp_x, disp_z) rows, side by side instead of one after the other; group 0
 // hands its real parts over through LDS and group 1 writes the RGBA rows.  (Timeline r03_run4 at N = 512: gather
 // 0.9 + transform 0.9 us, then gather 0.4 + transform 1.65 us, one after the other, on a CU with two waves.)
-template <int N, int E, int P1, int R2, int GRP = 1, bool PPAR = false>
+// SHARD: this launch transforms the gridDim.x * R2 rows of ONE rank of a tile sharded over several GPUs; `inter` is the
+// receive buffer of the all-to-all (InterLayout::xs_shift / src_stride), `out` the rank's block of rows.
+template <int N, int E, int P1, int R2, int GRP = 1, bool PPAR = false, bool SHARD = false>
 __global__ void __launch_bounds__((N / E) * R2 * (PPAR ? 2 : 1), (E == 16) ? 4 : 2)
 k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32* __restrict__ tw, InterLayout lay) {
     constexpr int T = N / E;
@@ -1455,9 +1470,9 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
     // per thread in flight otherwise).  Run 34: N = 2048 20.07-20.24k frames/s against 19.84-19.94k; at N = 4096 the same
     // costs 2-3 us (pass 2 91-94 us against 88-91): more lines in flight than the L2 keeps for the four sharers.
 #ifdef OCEAN_P2_PREFETCH
-    constexpr bool PREFETCH = (OCEAN_P2_PREFETCH != 0) && !PPAR;
+    constexpr bool PREFETCH = (OCEAN_P2_PREFETCH != 0) && !PPAR && !SHARD;
 #else
-    constexpr bool PREFETCH = (N <= 2048) && !PPAR;
+    constexpr bool PREFETCH = (N <= 2048) && !PPAR && !SHARD;
 #endif
     c32 pre_x[EH], pre_z[EH];
     if constexpr (PREFETCH) {
@@ -1478,7 +1493,18 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
 #pragma unroll
         for (int e = 0; e < EH; ++e) { a[e] = mk((float)(off & 7) + e, 1.0f); b[e] = mk(2.0f, (float)e); }
 #else
-        if (pass == 0) {
+        if constexpr (SHARD) {
+            // chunk column X of the tile sits in the slab of source rank X >> xs_shift
+            const size_t offy = chunk_row_offset(lay, ly / CR) + (ly % CR) * P1 + (lk % P1);
+            const int xmask = (1 << lay.xs_shift) - 1;
+#pragma unroll
+            for (int e = 0; e < EH; ++e) {
+                const int Xc = lk / P1 + e * (T / P1);
+                const size_t o = offy + (size_t)(Xc >> lay.xs_shift) * lay.src_stride + (size_t)(Xc & xmask) * lay.sx;
+                if (pass == 0) { a[e] = inter[(size_t)1 * lay.fs + o]; b[e] = mk(0.0f, 0.0f); }
+                else { a[e] = inter[o]; b[e] = inter[(size_t)2 * lay.fs + o]; }
+            }
+        } else if (pass == 0) {
             const c32* src = inter + (size_t)1 * lay.fs + off;
 #pragma unroll
             for (int e = 0; e < EH; ++e) { a[e] = src[(size_t)e * (T / P1) * lay.sx]; b[e] = mk(0.0f, 0.0f); }
@@ -1570,7 +1596,7 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
 // Pass 2 for the split geometry (N = 8192): the row is rebuilt in LDS as two interleaved half-length lines
 // (C[2m] and C[2m+1]), each transformed by N/(2E) threads in three passes, and the final radix-2 step is done by
 // the thread that owns outputs n and n + N/2 in the epilogue (see k_half_pass1_split).  One row per workgroup.
-template <int N, int E, int P1, int GRP = 1>
+template <int N, int E, int P1, int GRP = 1, bool SHARD = false>
 __global__ void __launch_bounds__(N / E, ((N / E) >= 512) ? 2 : 1)
 k_half_pass2_split(const c32* __restrict__ inter, float4* __restrict__ out, const c32* __restrict__ tw, InterLayout lay) {
     constexpr int M = N / 2;
@@ -1602,7 +1628,17 @@ k_half_pass2_split(const c32* __restrict__ inter, float4* __restrict__ out, cons
         const int tf = opaque_lane(tid);                           // loads: kx = tf + e*T, e < E/2
         const size_t off = chunk_row_offset(lay, y / CR) + (size_t)(tf / P1) * lay.sx + (y % CR) * P1 + (tf % P1);
         c32 a[EH], b[EH];
-        if (pass == 0) {
+        if constexpr (SHARD) {                                     // see k_half_pass2
+            const size_t offy = chunk_row_offset(lay, y / CR) + (y % CR) * P1 + (tf % P1);
+            const int xmask = (1 << lay.xs_shift) - 1;
+#pragma unroll
+            for (int e = 0; e < EH; ++e) {
+                const int Xc = tf / P1 + e * (T / P1);
+                const size_t o = offy + (size_t)(Xc >> lay.xs_shift) * lay.src_stride + (size_t)(Xc & xmask) * lay.sx;
+                if (pass == 0) a[e] = inter[(size_t)1 * lay.fs + o];
+                else { a[e] = inter[o]; b[e] = inter[(size_t)2 * lay.fs + o]; }
+            }
+        } else if (pass == 0) {
             const c32* src = inter + (size_t)1 * lay.fs + off;
 #pragma unroll
             for (int e = 0; e < EH; ++e) a[e] = src[(size_t)e * (T / P1) * lay.sx];
@@ -1860,6 +1896,27 @@ template <int N, int PSEL = 0> struct Geo {
     static constexpr int split_lds1 = 2 * P * LinePitch<N / 2>::elems * (int)sizeof(c32);
     static constexpr int split_lds2 = 2 * LinePitch<N / 2>::elems * (int)sizeof(c32);
     static constexpr int split_threads2 = T;
+    // One tile sharded over `world` GPUs (ocean_tile_pass1 / ocean_tile_pass2): rank r owns the half-spectrum columns
+    // [r N/(2 world), ..) in pass 1 and the rows [r N/world, ..) in pass 2.  The all-to-all buffers are
+    //     [dest or src][block of B chunk rows][field][chunk column][chunk row in block][16 elements]
+    // -- the intermediate's layout with the peer outermost, so that every (src, dest) message is contiguous.
+    static constexpr bool tile_supported(int world) {
+        return world >= 1 && (world & (world - 1)) == 0 && (N / world) >= 32 && ((N / 2 / world) % P) == 0 && (N / 8 / world) >= 1;
+    }
+    static InterLayout tile_layout(int world) {
+        const size_t gxl = (size_t)N / 8 / world, gyl = (size_t)N / 4 / world;   // chunk columns / chunk rows per rank
+        int bs = inter_bshift;
+        while (((size_t)1 << bs) > gyl) --bs;
+        const size_t B = (size_t)1 << bs;
+        InterLayout l{0, 0, 0, bs};
+        l.sx = B * 16;
+        l.fs = gxl * l.sx;                                         // field stride inside a block of chunk rows
+        l.sy = 3 * l.fs;                                           // block of chunk rows
+        l.xs_shift = 0;
+        while (((size_t)1 << l.xs_shift) < gxl) ++l.xs_shift;
+        l.src_stride = (gyl / B) * l.sy;                           // one (src, dest) message
+        return l;
+    }
     static_assert(row_threads <= 1024 && col_threads <= 1024 && frame_threads <= 1024, "workgroup too large");
     static_assert(col_lds <= 160 * 1024 && frame_lds <= 160 * 1024, "LDS budget (gfx950: 160 KiB)");
 };

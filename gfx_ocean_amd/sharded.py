@@ -143,3 +143,105 @@ class ShardedTile:
         if self.b.rank != 0:
             return None
         return np.ascontiguousarray(np.concatenate(parts, axis=0).transpose(1, 0, 2))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Second generation: the FUSED half-spectrum frame, sharded (include/ocean_hip.h ocean_tile_pass1 / ocean_tile_pass2)
+# ----------------------------------------------------------------------------------------------------------------------
+def fused_exchange_bytes_per_rank(n: int, world: int) -> int:
+    """All-to-all payload per rank and frame of the fused sharded tile: the three symmetrised spectra of the rank's
+    N/(2 world) half-spectrum columns, complex fp32 -- half of `exchange_bytes_per_rank` (the Hermitian half suffices)."""
+    return 3 * (n // 2 // world) * n * 8
+
+
+class HipTileBackend:
+    """ocean_tile_pass1 / ocean_tile_pass2 on an ordinary OceanDevice that holds the whole tile's static inputs; torch
+    supplies the exchange buffers, the stream and the collective."""
+
+    def __init__(self, n: int, rank: int, world: int, device_ordinal: int = 0):
+        import torch
+        from .render import OceanDevice
+        self.torch = torch
+        self.lib = load_library()
+        self.dev = OceanDevice(n, device_ordinal)
+        self.n, self.rank, self.world, self.rows = n, rank, world, n // world
+        self.device = torch.device("cuda", device_ordinal)
+        self.stream = torch.cuda.Stream(self.device)          # see HipShardBackend: one explicit stream for kernels + collective
+        nbytes = int(self.lib.ocean_tile_exchange_bytes(self.dev._ctx, world))
+        if nbytes < 0:
+            raise OceanError(nbytes, f"sharded tile: N = {n} cannot be split over {world} ranks")
+        self.exchange_floats = nbytes // 4
+
+    def upload(self, h0, omega):
+        self.dev.upload_spectrum(h0, omega)                   # every rank keeps the (static) inputs of the whole tile
+
+    def alloc_exchange(self):
+        return self.torch.empty((self.world, self.exchange_floats // self.world), dtype=self.torch.float32, device=self.device)
+
+    def alloc_out(self):
+        return self.torch.empty((self.rows, self.n, 4), dtype=self.torch.float32, device=self.device)
+
+    def on_stream(self):
+        return self.torch.cuda.stream(self.stream)
+
+    def pass1(self, time, domain_size, send):
+        loc = PropagateLocalsC(float(time), int(self.n), float(domain_size))
+        self.dev._check(self.lib.ocean_tile_pass1(self.dev._ctx, ctypes.byref(loc), self.rank, self.world, send.data_ptr(),
+                                                  self.stream.cuda_stream))
+
+    def pass2(self, recv, out):
+        self.dev._check(self.lib.ocean_tile_pass2(self.dev._ctx, self.rank, self.world, recv.data_ptr(), out.data_ptr(),
+                                                  self.stream.cuda_stream))
+
+    def synchronize(self):
+        self.stream.synchronize()
+
+    def to_numpy(self, out):
+        self.stream.synchronize()
+        return out.cpu().numpy()
+
+    def destroy(self):
+        self.dev.destroy()
+
+
+class FusedShardedTile:
+    """frame(t) = pass 1 on the rank's half-spectrum columns -> ONE all-to-all (12 B/texel in total) -> pass 2 on the
+    rank's rows.  The result is distributed by ROW blocks in the natural orientation: out[y - r N/R, x] = (dx, h, dz, 0).
+    `dist`: an initialised torch.distributed (RCCL on GPUs, gloo in the CPU tests); None only for world == 1."""
+
+    def __init__(self, backend, dist=None, domain_size: float = DOMAIN_SIZE):
+        if dist is None and backend.world != 1:
+            raise OceanError(-1, f"FusedShardedTile: world = {backend.world} needs an initialised torch.distributed")
+        self.b, self.dist, self.domain_size = backend, dist, float(domain_size)
+        self.send = backend.alloc_exchange()
+        self.recv = backend.alloc_exchange()
+        self.out = backend.alloc_out()
+
+    def upload(self, h0: np.ndarray, omega: np.ndarray):
+        self.b.upload(np.ascontiguousarray(h0, np.complex64), np.ascontiguousarray(omega, np.float32))
+
+    def frame(self, time: float):
+        self.b.pass1(time, self.domain_size, self.send)
+        if self.dist is not None:
+            with self.b.on_stream():
+                self.dist.all_to_all_single(self.recv, self.send)  # the only collective of the frame
+            recv = self.recv
+        else:
+            recv = self.send
+        self.b.pass2(recv, self.out)
+        return self.out
+
+    def result(self) -> np.ndarray:
+        """The rank's block of rows: [N/world, N, 4]."""
+        return self.b.to_numpy(self.out)
+
+    def gather_tile(self) -> np.ndarray | None:
+        """Whole tile [y, x, 4] on rank 0 (tests / small N only)."""
+        mine = self.result()
+        if self.b.world == 1:
+            return mine
+        parts = [None] * self.b.world if self.b.rank == 0 else None
+        self.dist.gather_object(mine, parts, dst=0)
+        if self.b.rank != 0:
+            return None
+        return np.ascontiguousarray(np.concatenate(parts, axis=0))

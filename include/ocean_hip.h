@@ -211,6 +211,25 @@ int32_t ocean_shard_cols(OceanShard* shard, const void* recv_device, void* out_r
 int32_t ocean_shard_sync(OceanShard* shard);
 void* ocean_shard_stream(OceanShard* shard);
 
+/* ---- one tile over several GPUs, second generation: the fused half-spectrum frame, sharded ------------------------------
+ * The fused frame transforms columns first (ocean_frame: pass 1 = propagate + column transform of the N/2 distinct
+ * columns of the symmetrised spectra, pass 2 = row transform + correction), so the sharded frame is
+ *     ocean_tile_pass1:  rank r transforms the half-spectrum columns [r N/(2 world), (r+1) N/(2 world)) and writes them as
+ *                        the send buffer of ONE all-to-all,  send[dest][...] = the rows of rank `dest`;
+ *     (caller)           all-to-all over xGMI: 3 * N/2 * N/world * 8 bytes per rank and frame (ocean_tile_exchange_bytes)
+ *                        -- half of what the row-block scheme above ships: the Hermitian half is enough;
+ *     ocean_tile_pass2:  rank r rebuilds its rows [r N/world, (r+1) N/world) from recv[src][...], transforms them and
+ *                        writes them in the NATURAL orientation: out_rows[(y - r N/world) * N + x] = (disp_x, height, disp_z, 0).
+ * Both run on an ordinary context that holds the whole tile's static inputs (ocean_upload_spectrum on every rank: the
+ * inputs are static and 12 bytes per texel): no state per rank, so all ranks of a tile can be driven from one context
+ * on one GPU (tests) or one context per GPU (gfx_ocean_amd/sharded.py).  N = 256 .. 8192, world a power of two with at
+ * least 32 rows per rank.  Same barrier as the reference's between its row and column dispatches (src/render.rs:1181-1208). */
+int64_t ocean_tile_exchange_bytes(const OceanContext* ctx, int32_t world);   /* bytes of a rank's send (= receive) buffer; < 0: error */
+int32_t ocean_tile_pass1(OceanContext* ctx, const OceanPropagateLocals* locals, int32_t rank, int32_t world, void* send_device,
+                         void* stream);
+int32_t ocean_tile_pass2(OceanContext* ctx, int32_t rank, int32_t world, const void* recv_device, void* out_rows_device,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,9 +76,9 @@ template <int N, int PSEL> static int run_half_p(const void* h0T, int f16, float
                                                  float4* out, const c32* tw, InterLayout lay, float time, float L) {
     using G = Geo<N, PSEL>;
     if (f16) emu_launch(G::half_grid1, G::half_threads1,
-                        [&] { k_half_pass1<N, G::E1, G::P, true, G::handover, G::fpar>(h0T, descale, omT, inter, nyq, tw, lay, time, L); });
+                        [&] { k_half_pass1<N, G::E1, G::P, true, G::handover, G::fpar>(h0T, descale, omT, inter, nyq, tw, lay, time, L, 0); });
     else emu_launch(G::half_grid1, G::half_threads1,
-                    [&] { k_half_pass1<N, G::E1, G::P, false, G::handover, G::fpar>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L); });
+                    [&] { k_half_pass1<N, G::E1, G::P, false, G::handover, G::fpar>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L, 0); });
     emu_launch(G::half_grid2, G::half_threads2,
                [&] { k_half_pass2<N, G::E2, CHUNK_W, G::R2h, G::p2_group, G::ppar>(inter, out, tw, lay); });
     return 0;
@@ -88,9 +88,9 @@ template <int N> static int run_half_split(const void* h0T, int f16, float desca
     using G = Geo<N, 2>;
     static_assert(G::can_split, "split geometry");
     if (f16) emu_launch(G::half_grid1, G::split_threads1,
-                        [&] { k_half_pass1_split<N, G::E1S, G::P, true, G::handover>(h0T, descale, omT, inter, nyq, tw, lay, time, L); });
+                        [&] { k_half_pass1_split<N, G::E1S, G::P, true, G::handover>(h0T, descale, omT, inter, nyq, tw, lay, time, L, 0); });
     else emu_launch(G::half_grid1, G::split_threads1,
-                    [&] { k_half_pass1_split<N, G::E1S, G::P, false, G::handover>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L); });
+                    [&] { k_half_pass1_split<N, G::E1S, G::P, false, G::handover>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L, 0); });
     emu_launch(N, G::split_threads2, [&] { k_half_pass2_split<N, G::E, CHUNK_W, G::p2_group>(inter, out, tw, lay); });
     return 0;
 }
@@ -104,6 +104,36 @@ template <int N> static int run_half(int psel, const void* h0T, int f16, float d
     if (psel == 1) return run_half_p<N, 1>(h0T, f16, descale, omT, inter, nyq, out, tw, lay, time, L);
     if constexpr (CHUNK_W % Geo<N, 0>::P != 0) return -4;
     else return run_half_p<N, 0>(h0T, f16, descale, omT, inter, nyq, out, tw, lay, time, L);
+}
+
+// one tile sharded over `world` ranks, second generation (ocean_tile_pass1 / ocean_tile_pass2 of csrc/ocean_api.hip: same
+// kernels, same geometry, same layouts)
+template <int N, int PSEL> static int run_tile_pass1(int rank, int world, const void* h0T, int f16, float descale, const float* omT,
+                                                     c32* send, c32* nyq, const c32* tw, float time, float L) {
+    using G = Geo<N, PSEL>;
+    if (!G::tile_supported(world)) return -5;
+    const InterLayout lay = G::tile_layout(world);
+    const int groups = (N / 2 / world) / G::P;
+    if (f16) emu_launch(groups, G::half_threads1,
+                        [&] { k_half_pass1<N, G::E1, G::P, true, G::handover, G::fpar>(h0T, descale, omT, send, nyq, tw, lay, time, L, rank * groups); });
+    else emu_launch(groups, G::half_threads1,
+                    [&] { k_half_pass1<N, G::E1, G::P, false, G::handover, G::fpar>(h0T, 1.0f, omT, send, nyq, tw, lay, time, L, rank * groups); });
+    return 0;
+}
+template <int N, int PSEL> static int run_tile_pass2(int world, const c32* recv, float4* out, const c32* tw) {
+    using G = Geo<N, PSEL>;
+    if (!G::tile_supported(world)) return -5;
+    const InterLayout lay = G::tile_layout(world);
+    emu_launch((N / world) / G::R2h, G::half_threads2,
+               [&] { k_half_pass2<N, G::E2, CHUNK_W, G::R2h, G::p2_group, G::ppar, true>(recv, out, tw, lay); });
+    return 0;
+}
+template <int N> static int run_tile(int what, int psel, int rank, int world, const void* h0T, int f16, float descale, const float* omT,
+                                     c32* buf, c32* nyq, float4* out, const c32* tw, float time, float L) {
+    if (psel == 1) return what == 1 ? run_tile_pass1<N, 1>(rank, world, h0T, f16, descale, omT, buf, nyq, tw, time, L) : run_tile_pass2<N, 1>(world, buf, out, tw);
+    if (psel == 2) return what == 1 ? run_tile_pass1<N, 2>(rank, world, h0T, f16, descale, omT, buf, nyq, tw, time, L) : run_tile_pass2<N, 2>(world, buf, out, tw);
+    if constexpr (CHUNK_W % Geo<N, 0>::P != 0) return -4;
+    else return what == 1 ? run_tile_pass1<N, 0>(rank, world, h0T, f16, descale, omT, buf, nyq, tw, time, L) : run_tile_pass2<N, 0>(world, buf, out, tw);
 }
 
 // staged path with the chunked hand-off: rows (natural -> chunked), cols (in place, chunked), correction / un-chunk
@@ -198,6 +228,12 @@ int emu_frame_pass2_thin(int n, const float* inter, float* out, const float* tw,
 int emu_frame_half(int n, int psel, const void* h0T, int f16, float descale, const float* omT, float* inter, c32* nyq, float* out,
                    const float* tw, size_t sx, size_t sy, size_t fs, int bshift, float time, float L) {
 #define C_(N) run_half<N>(psel, h0T, f16, descale, omT, (c32*)inter, (c32*)nyq, (float4*)out, (const c32*)tw, InterLayout{sx, sy, fs, bshift}, time, L)
+    DISPATCH(n, C_)
+#undef C_
+}
+int emu_tile(int n, int what, int psel, int rank, int world, const void* h0T, int f16, float descale, const float* omT, float* buf,
+             float* nyq, float* out, const float* tw, float time, float L) {
+#define C_(N) run_tile<N>(what, psel, rank, world, h0T, f16, descale, omT, (c32*)buf, (c32*)nyq, (float4*)out, (const c32*)tw, time, L)
     DISPATCH(n, C_)
 #undef C_
 }

@@ -55,11 +55,15 @@ class DeviceBuffer:
         assert hip().hipMemcpy(self.ptr + offset, a.ctypes.data, a.nbytes, 1) == 0  # hipMemcpyHostToDevice
 
     def copy_from_device(self, src_ptr: int, nbytes: int, offset: int = 0):
+        """Device-to-device, complete on return.  (hipMemcpy D2D only ENQUEUES on the null stream, and the library's
+        streams are non-blocking: without the wait a kernel launched next can overtake the copy.)"""
         assert offset + nbytes <= self.nbytes
         assert hip().hipMemcpy(self.ptr + offset, src_ptr, nbytes, 3) == 0          # hipMemcpyDeviceToDevice
+        assert hip().hipDeviceSynchronize() == 0
 
     def fill(self, byte: int = 0):
         assert hip().hipMemset(self.ptr, byte, self.nbytes) == 0
+        assert hip().hipDeviceSynchronize() == 0
 
     def free(self):
         if self.ptr:

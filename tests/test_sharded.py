@@ -217,3 +217,169 @@ def test_gpu_shard_state_errors():
     finally:
         lib.ocean_shard_destroy(h)
         buf.free(); out.free()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Second generation: the fused half-spectrum frame, sharded (ocean_tile_pass1 / ocean_tile_pass2, FusedShardedTile)
+# ----------------------------------------------------------------------------------------------------------------------
+_WORKER2 = _WORKER.replace("sharded.ShardedTile(emu.EmuShardBackend(n, rank, world), dist)", "sharded.FusedShardedTile(emu.EmuTileBackend(n, rank, world), dist)") \
+                  .replace("sharded.exchange_bytes_per_rank(n, world)", "sharded.fused_exchange_bytes_per_rank(n, world)")
+
+
+@pytest.mark.parametrize("world,n", [(2, 512), (4, 256)])
+def test_fused_sharded_tile_matches_the_whole_frame_oracle(tmp_path, world, n):
+    """World 2 and 4 over gloo with the fused kernels in the host emulation: column blocks of the half spectrum, ONE
+    all-to-all of half the volume, row blocks out -- against the fp64 oracle of the whole frame."""
+    assert "FusedShardedTile" in _WORKER2
+    worker = tmp_path / "worker2.py"
+    worker.write_text(_WORKER2)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(29560 + world), str(worker), ROOT, str(n)],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
+    assert r["nmax"] <= 1e-4 and r["rl2"] <= 1e-4 and r["alpha0"], r
+    assert r["nmax"] < 1e-5
+    assert r["bytes"] == 3 * (n // 2 // world) * n * 8 == sharded.exchange_bytes_per_rank(n, world) // 2
+
+
+def test_fused_sharded_single_rank_and_loopback_in_the_emulation():
+    """world = 1 is the fused frame itself; world = 2 with both ranks in one process and the exchange permuted by hand
+    (the shape of the GPU test below)."""
+    import emu
+    n, t = 256, 0.75
+    h0, om = g.synth.make_inputs(n, seed=5)
+    ref = oc.frame_f64(h0, om, t)
+    tile = sharded.FusedShardedTile(emu.EmuTileBackend(n, 0, 1))
+    tile.upload(h0, om)
+    tile.frame(t)
+    nmax, rl2 = oc.parity_errors(tile.gather_tile()[..., :3], ref[..., :3])
+    assert nmax.max() < 1e-5 and rl2.max() < 1e-5
+    world = 2
+    backs = [emu.EmuTileBackend(n, r, world) for r in range(world)]
+    sends = [b.alloc_exchange() for b in backs]
+    recvs = [b.alloc_exchange() for b in backs]
+    outs = [b.alloc_out() for b in backs]
+    for b, s_ in zip(backs, sends):
+        b.upload(h0, om)
+        b.pass1(t, 1000.0, s_)
+    for r in range(world):
+        for src in range(world):
+            recvs[r][src] = sends[src][r]
+    for b, r_, o in zip(backs, recvs, outs):
+        b.pass2(r_, o)
+    full = np.concatenate([o.numpy() for o in outs], axis=0)
+    nmax, rl2 = oc.parity_errors(full[..., :3], ref[..., :3])
+    assert nmax.max() < 1e-5 and rl2.max() < 1e-5 and np.all(full[..., 3] == 0.0)
+    with pytest.raises(g.OceanError):
+        sharded.FusedShardedTile(backs[0])                       # world 2 without a process group
+
+
+def _fused_loopback_frame(n, world, t, h0, om, f16=False):
+    """All ranks of ONE fused sharded tile on device 0, one context (the tile entry points keep no per-rank state); the
+    all-to-all by hand with device-to-device copies.  Returns the assembled tile [y, x, 4]."""
+    import ctypes
+    from hipmem import DeviceBuffer
+    from gfx_ocean_amd._lib import PropagateLocalsC, load_library
+    lib = load_library()
+    d = g.OceanDevice(n)
+    bufs = []
+    try:
+        d.upload_spectrum(h0, om, spectrum_fp16=f16)
+        nbytes = int(lib.ocean_tile_exchange_bytes(d._ctx, world))
+        assert nbytes == sharded.fused_exchange_bytes_per_rank(n, world)
+        slot = nbytes // world
+        rows = n // world
+        sends = [DeviceBuffer(nbytes) for _ in range(world)]
+        recvs = [DeviceBuffer(nbytes) for _ in range(world)]
+        outs = [DeviceBuffer(rows * n * 16) for _ in range(world)]
+        bufs = sends + recvs + outs
+        for b in sends + recvs:
+            b.fill(0xFF)                                          # NaN patterns: an element nobody wrote shows up in the result
+        loc = PropagateLocalsC(float(t), int(n), 1000.0)
+        for r in range(world):
+            d._check(lib.ocean_tile_pass1(d._ctx, ctypes.byref(loc), r, world, sends[r].ptr, None))
+        d.sync()
+        for r in range(world):
+            for src in range(world):
+                recvs[r].copy_from_device(sends[src].ptr + r * slot, slot, offset=src * slot)
+        for r in range(world):
+            d._check(lib.ocean_tile_pass2(d._ctx, r, world, recvs[r].ptr, outs[r].ptr, None))
+        d.sync()
+        return np.concatenate([o.to_host(np.float32).reshape(rows, n, 4) for o in outs], axis=0), (d.read_spectrum() if f16 else None)
+    finally:
+        for b in bufs:
+            b.free()
+        d.destroy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,world,f16", [(256, 2, False), (512, 2, False), (512, 4, False), (1024, 8, False), (2048, 8, False),
+                                         (4096, 1, False), (4096, 2, False), (4096, 8, False), (8192, 2, True), (8192, 4, False)])
+def test_gpu_fused_shard_multi_rank_on_one_device(n, world, f16):
+    """The fused sharded tile with the REAL kernels at world 1 / 2 / 4 / 8 on one GPU (every size the fused frame
+    supports, fp16-stored spectrum included): assembled tile against the oracle -- fp64 closed form at N <= 2048, every
+    texel of the C restatement of the shaders above."""
+    t = 1.5
+    h0, om = g.synth.make_inputs(n, seed=51 + world)
+    got, deq = _fused_loopback_frame(n, world, t, h0, om, f16)
+    src = deq if f16 else h0
+    if n <= 2048:
+        want = oc.frame_f64(src, om, t)
+    else:
+        from oracle import c_oracle as cc
+        cc.build()
+        cc.set_threads(min(32, cc.max_threads()))
+        want = cc.FrameRunner(src, om).frame(t)
+    nmax, rl2 = oc.parity_errors(got[..., :3], want[..., :3])
+    assert nmax.max() <= 1e-4 and rl2.max() <= 1e-4, (nmax, rl2)          # north_star tolerance
+    assert nmax.max() < 2e-5 and np.all(got[..., 3] == 0.0)
+
+
+@pytest.mark.gpu
+def test_gpu_fused_shard_equals_the_fused_frame_bit_for_bit():
+    """Sharding must not change a single bit: the same kernels on the same columns and rows, only the addresses of the
+    intermediate differ."""
+    n, t = 2048, 2.0
+    h0, om = g.synth.make_inputs(n, seed=3)
+    got, _ = _fused_loopback_frame(n, 4, t, h0, om)
+    d = g.OceanDevice(n)
+    try:
+        d.upload_spectrum(h0, om)
+        d.frame(t)
+        assert np.array_equal(got, d.read_displacement())
+    finally:
+        d.destroy()
+
+
+_GPU_FUSED_WORLD1 = r"""
+import sys
+import torch, torch.distributed as dist, os
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import gfx_ocean_amd as g
+from gfx_ocean_amd import sharded
+from oracle import ocean_oracle as oc
+n = int(sys.argv[2])
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))   # RCCL, world 1: the collective call itself
+h0, om = g.synth.make_inputs(n, seed=9)
+tile = sharded.FusedShardedTile(sharded.HipTileBackend(n, 0, 1), dist)
+tile.upload(h0, om)
+tile.frame(2.25)
+got = tile.gather_tile()
+nmax, rl2 = oc.parity_errors(got[..., :3], oc.frame_f64(h0, om, 2.25)[..., :3])
+assert nmax.max() < 2e-5 and rl2.max() < 2e-5 and np.all(got[..., 3] == 0.0), (nmax, rl2)
+tile.b.destroy()
+dist.destroy_process_group()
+print("FUSED_SHARD_GPU_OK")
+"""
+
+
+@pytest.mark.gpu
+def test_gpu_fused_shard_through_torch_and_rccl():
+    """HipTileBackend + FusedShardedTile on torch memory and a torch stream, the all-to-all through RCCL (world 1)."""
+    p = subprocess.run([sys.executable, "-c", _GPU_FUSED_WORLD1, ROOT, "1024"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "FUSED_SHARD_GPU_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]

@@ -21,6 +21,9 @@ def main():
     ap.add_argument("--n", type=int, default=16384)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scheme", choices=("rows", "fused"), default="fused",
+                    help="fused = the half-spectrum frame sharded by column blocks then row blocks (ocean_tile_*, N <= 8192, "
+                         "12 B/texel exchanged); rows = the staged row-block scheme (ocean_shard_*, N <= 16384, 24 B/texel)")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -38,7 +41,11 @@ def main():
     from gfx_ocean_amd import sharded
     n = args.n
     h0, om = g.synth.make_inputs(n, seed=n)
-    tile = sharded.ShardedTile(sharded.HipShardBackend(n, rank, world, local), dist)
+    fused = args.scheme == "fused" and n <= 8192
+    if fused:
+        tile = sharded.FusedShardedTile(sharded.HipTileBackend(n, rank, world, local), dist)
+    else:
+        tile = sharded.ShardedTile(sharded.HipShardBackend(n, rank, world, local), dist)
     tile.upload(h0, om)
 
     frame = tile.frame
@@ -59,11 +66,12 @@ def main():
         ms = float(t.item())
     if rank == 0:
         per = ms / args.steps
-        payload = sharded.exchange_bytes_per_rank(n, world)
-        print(json.dumps({"metric": "frames/s of one sharded N x N tile", "n": n, "world": world, "value": 1000.0 / per,
+        payload = sharded.fused_exchange_bytes_per_rank(n, world) if fused else sharded.exchange_bytes_per_rank(n, world)
+        print(json.dumps({"metric": "frames/s of one sharded N x N tile", "scheme": "fused" if fused else "rows", "n": n, "world": world, "value": 1000.0 / per,
                           "ms_per_frame": per, "all_to_all_bytes_per_rank": payload,
                           "collective": "torch.distributed.all_to_all_single (RCCL)" if dist is not None else "none (one rank)",
-                          "staged_bytes_per_texel": "36 propagate + 3 x (16 rows + 16 transpose + 16 columns) + 40 correction = 220"}),
+                          "hbm_bytes_per_texel": "26 + 28 = 54 (the fused frame's)" if fused else
+                                                 "36 propagate + 3 x (16 rows + 16 transpose + 16 columns) + 40 correction = 220"}),
               flush=True)
     tile.b.destroy()
     if dist is not None:
