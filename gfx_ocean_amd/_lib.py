@@ -133,8 +133,8 @@ def load_library():
         "ocean_shard_sync": (i32, [vp]),
         "ocean_shard_stream": (vp, [vp]),
         "ocean_tile_exchange_bytes": (ctypes.c_int64, [vp, i32]),
-        "ocean_tile_pass1": (i32, [vp, ctypes.POINTER(PropagateLocalsC), i32, i32, vp, vp]),
-        "ocean_tile_pass2": (i32, [vp, i32, i32, vp, vp, vp]),
+        "ocean_tile_pass1": (i32, [vp, ctypes.POINTER(PropagateLocalsC), i32, i32, i32, i32, vp, vp]),
+        "ocean_tile_pass2": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     }
     assert sorted(sig) == sorted(SYMBOLS)
     for name, (res, args) in sig.items():

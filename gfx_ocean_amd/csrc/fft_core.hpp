@@ -25,7 +25,7 @@
 // line FFT, =2 drops every barrier inside it -- an upper bound on what a barrier-free (one wave per line) exchange buys.
 // Every OCEAN_X* switch ("wrong results, timing only") exists in -DOCEAN_AB builds alone: a stray -D on the product
 // build is a compile error, not a silently wrong library.
-#if !defined(OCEAN_AB) && (defined(OCEAN_X_NOBAR) || defined(OCEAN_X_NODUP) || defined(OCEAN_X_NOFFT) || \
+#if !defined(OCEAN_AB) && (defined(OCEAN_X_NOBAR) || defined(OCEAN_X_NODUP) || defined(OCEAN_X_NOFFT) || defined(OCEAN_X_INTER16) || \
                            defined(OCEAN_X2_NOLOAD) || defined(OCEAN_X2_NOSTORE) || defined(OCEAN_X2_NOFFT))
 #error "OCEAN_X* switches produce wrong results on purpose (timing ablations): they require -DOCEAN_AB (tools/ab_variants.sh)"
 #endif

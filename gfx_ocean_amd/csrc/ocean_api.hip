@@ -286,34 +286,35 @@ template <int N> struct Launch {
     // ---- one tile sharded over `world` GPUs (ocean_tile_pass1 / ocean_tile_pass2): the same kernels on this rank's
     // block of half-spectrum columns (pass 1, writing the all-to-all send buffer) and block of rows (pass 2, reading the
     // receive buffer).
-    static bool tile_supported(int world) {
+    static bool tile_supported(int world, int parts) {
         using H = Geo<N, default_psel()>;
-        return H::tile_supported(world);
+        return H::tile_supported(world, parts);
     }
-    static void tile_pass1(OceanContext* c, float time, float domain, int rank, int world, c32* send, hipStream_t s) {
+    static void tile_pass1(OceanContext* c, float time, float domain, int rank, int world, int part, int parts, c32* send, hipStream_t s) {
         using H = Geo<N, default_psel()>;
-        const InterLayout lay = H::tile_layout(world);
-        const int groups = (N / 2 / world) / H::P;
+        const InterLayout lay = H::tile_layout(world, parts);
+        const int groups = (N / 2 / world / parts) / H::P;
+        const int x_group0 = (rank * parts + part) * groups;
         const float descale = c->h0_f16 ? std::ldexp(1.0f, -c->scale_log2) : 1.0f;
         if constexpr (split_built<default_psel()>()) {
             if (c->h0_f16)
                 hipLaunchKernelGGL((k_half_pass1_split<N, H::E1S, H::P, true, H::handover>), dim3(groups), dim3(H::split_threads1), H::split_lds1, s,
-                                   (const void*)c->h0T, descale, (const float*)c->omegaT, send, c->nyq, (const c32*)c->tw, lay, time, domain, rank * groups);
+                                   (const void*)c->h0T, descale, (const float*)c->omegaT, send, c->nyq, (const c32*)c->tw, lay, time, domain, x_group0);
             else
                 hipLaunchKernelGGL((k_half_pass1_split<N, H::E1S, H::P, false, H::handover>), dim3(groups), dim3(H::split_threads1), H::split_lds1, s,
-                                   (const void*)c->h0T, descale, (const float*)c->omegaT, send, c->nyq, (const c32*)c->tw, lay, time, domain, rank * groups);
+                                   (const void*)c->h0T, descale, (const float*)c->omegaT, send, c->nyq, (const c32*)c->tw, lay, time, domain, x_group0);
         } else {
             if (c->h0_f16)
                 hipLaunchKernelGGL((k_half_pass1<N, H::E1, H::P, true, H::handover, H::fpar>), dim3(groups), dim3(H::half_threads1), H::half_lds1, s,
-                                   (const void*)c->h0T, descale, (const float*)c->omegaT, send, c->nyq, (const c32*)c->tw, lay, time, domain, rank * groups);
+                                   (const void*)c->h0T, descale, (const float*)c->omegaT, send, c->nyq, (const c32*)c->tw, lay, time, domain, x_group0);
             else
                 hipLaunchKernelGGL((k_half_pass1<N, H::E1, H::P, false, H::handover, H::fpar>), dim3(groups), dim3(H::half_threads1), H::half_lds1, s,
-                                   (const void*)c->h0T, descale, (const float*)c->omegaT, send, c->nyq, (const c32*)c->tw, lay, time, domain, rank * groups);
+                                   (const void*)c->h0T, descale, (const float*)c->omegaT, send, c->nyq, (const c32*)c->tw, lay, time, domain, x_group0);
         }
     }
-    static void tile_pass2(OceanContext* c, int world, const c32* recv, float4* out_rows, hipStream_t s) {
+    static void tile_pass2(OceanContext* c, int world, int parts, const c32* recv, float4* out_rows, hipStream_t s) {
         using H = Geo<N, default_psel()>;
-        const InterLayout lay = H::tile_layout(world);
+        const InterLayout lay = H::tile_layout(world, parts);
         const int rows = N / world;
         if constexpr (split_built<default_psel()>())
             hipLaunchKernelGGL((k_half_pass2_split<N, H::E, CHUNK_W, H::p2_group, true>), dim3(rows), dim3(H::split_threads2), H::split_lds2, s,
@@ -930,39 +931,41 @@ int32_t ocean_bind_displacement(OceanContext* ctx, void* device_rgba) {
 void* ocean_stream(OceanContext* ctx) { return valid(ctx) ? (void*)ctx->stream : nullptr; }
 
 // ---- one tile over several GPUs, second generation (half-spectrum, fused; include/ocean_hip.h) ------------------------
-static int32_t tile_check(OceanContext* ctx, int32_t rank, int32_t world) {
+static int32_t tile_check(OceanContext* ctx, int32_t rank, int32_t world, int32_t part, int32_t parts) {
     if (!ctx->uploaded) return fail(ctx, OCEAN_E_STATE, "ocean_upload_spectrum has not been called");
     if (ctx->quirks != OCEAN_QUIRKS_REFERENCE) return fail(ctx, OCEAN_E_STATE, "the fused kernels implement the reference quirks only (ocean_set_quirks)");
     bool ok = false;
-    OCEAN_DISPATCH(ctx->n, ok = L::tile_supported(world));
-    if (!ok || rank < 0 || rank >= world)
-        return fail(ctx, OCEAN_E_INVALID_ARG, "sharded tile: world must be a power of two with at least 32 rows per rank, 0 <= rank < world");
+    OCEAN_DISPATCH(ctx->n, ok = L::tile_supported(world, parts));
+    if (!ok || rank < 0 || rank >= world || part < 0 || part >= parts)
+        return fail(ctx, OCEAN_E_INVALID_ARG, "sharded tile: world and parts must be powers of two with at least 32 rows per rank and one "
+                                              "column group per part, 0 <= rank < world, 0 <= part < parts");
     return OCEAN_OK;
 }
 int64_t ocean_tile_exchange_bytes(const OceanContext* ctx, int32_t world) {
     if (!valid(ctx) || world < 1 || (world & (world - 1)) || ctx->n / world < 32) return OCEAN_E_INVALID_ARG;
     return (int64_t)3 * (ctx->n / 2) * (int64_t)(ctx->n / world) * 8;          // per rank: send buffer = receive buffer
 }
-int32_t ocean_tile_pass1(OceanContext* ctx, const OceanPropagateLocals* locals, int32_t rank, int32_t world, void* send_device,
-                         void* stream) {
+int32_t ocean_tile_pass1(OceanContext* ctx, const OceanPropagateLocals* locals, int32_t rank, int32_t world, int32_t part,
+                         int32_t parts, void* send_device, void* stream) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
     if (!locals || !send_device) return fail(ctx, OCEAN_E_INVALID_ARG, "NULL argument");
     if (locals->resolution != ctx->n) return fail(ctx, OCEAN_E_INVALID_ARG, "PropagateLocals.resolution != context resolution");
     if (!(locals->domain_size > 0.0f)) return fail(ctx, OCEAN_E_INVALID_ARG, "domain_size must be > 0");
     if (reinterpret_cast<uintptr_t>(send_device) & 15u) return fail(ctx, OCEAN_E_INVALID_ARG, "send buffer must be 16-byte aligned");
-    { const int32_t st = tile_check(ctx, rank, world); if (st != OCEAN_OK) return st; }
+    { const int32_t st = tile_check(ctx, rank, world, part, parts); if (st != OCEAN_OK) return st; }
     DeviceGuard guard(ctx->device);
-    OCEAN_DISPATCH(ctx->n, L::tile_pass1(ctx, locals->time, locals->domain_size, rank, world, (c32*)send_device, pick(ctx, stream)));
+    OCEAN_DISPATCH(ctx->n, L::tile_pass1(ctx, locals->time, locals->domain_size, rank, world, part, parts, (c32*)send_device, pick(ctx, stream)));
     return check_launch(ctx, "ocean_tile_pass1 launch");
 }
-int32_t ocean_tile_pass2(OceanContext* ctx, int32_t rank, int32_t world, const void* recv_device, void* out_rows_device, void* stream) {
+int32_t ocean_tile_pass2(OceanContext* ctx, int32_t rank, int32_t world, int32_t parts, const void* recv_device, void* out_rows_device,
+                         void* stream) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
     if (!recv_device || !out_rows_device) return fail(ctx, OCEAN_E_INVALID_ARG, "NULL argument");
     if ((reinterpret_cast<uintptr_t>(recv_device) | reinterpret_cast<uintptr_t>(out_rows_device)) & 15u)
         return fail(ctx, OCEAN_E_INVALID_ARG, "buffers must be 16-byte aligned");
-    { const int32_t st = tile_check(ctx, rank, world); if (st != OCEAN_OK) return st; }
+    { const int32_t st = tile_check(ctx, rank, world, 0, parts); if (st != OCEAN_OK) return st; }
     DeviceGuard guard(ctx->device);
-    OCEAN_DISPATCH(ctx->n, L::tile_pass2(ctx, world, (const c32*)recv_device, (float4*)out_rows_device, pick(ctx, stream)));
+    OCEAN_DISPATCH(ctx->n, L::tile_pass2(ctx, world, parts, (const c32*)recv_device, (float4*)out_rows_device, pick(ctx, stream)));
     return check_launch(ctx, "ocean_tile_pass2 launch");
 }
 
@@ -990,7 +993,15 @@ static int32_t profile_common(OceanContext* ctx, float time, int32_t cap, const 
                                       "k_fft_lines<COL> dx", "k_fft_lines<COL> dy", "k_fft_lines<COL> dz", "k_correct"};
     static const char* kChunked[8] = {"k_propagate", "k_stage_rows(fft) dx", "k_stage_rows(fft) dy", "k_stage_rows(fft) dz",
                                       "k_stage_cols(fft) dx", "k_stage_cols(fft) dy", "k_stage_cols(fft) dz", "k_correct_chunked"};
-    const char* const* kStaged = ctx->stage_chunked ? kChunked : kNatural;
+    // N = 8192: two 8192-point lines fill the LDS, so a column workgroup owns 16-byte pieces of the natural rows (or of a
+    // chunk) and the L2 has to merge neighbours: 0.85 ms per field = 1.26 TB/s (round 2) against 3.6-3.9 TB/s of the chunked
+    // hand-off at N <= 4096.  A chunked hand-off with half chunks was estimated at 3.0 ms per frame (today 4.2; the fused
+    // frame: 0.9) and NOT built: the staged calls are the 1:1 compatibility path, ocean_frame is the product
+    // (INTEGRATION.md 2).  The names say so where a profile is read.
+    static const char* kNatural8192[8] = {"k_propagate", "k_fft_lines<ROW> dx", "k_fft_lines<ROW> dy", "k_fft_lines<ROW> dz",
+                                          "k_fft_lines<COL> dx [natural layout, 16-byte pieces: compatibility path, ~1.3 TB/s]",
+                                          "k_fft_lines<COL> dy [compatibility path]", "k_fft_lines<COL> dz [compatibility path]", "k_correct"};
+    const char* const* kStaged = ctx->stage_chunked ? kChunked : (ctx->n >= 8192 ? kNatural8192 : kNatural);
     const char* kFused[2] = {ctx->half ? "k_half_pass1" : "k_frame_pass1",
                              ctx->half ? "k_half_pass2" : (ctx->pass2_thin ? "k_frame_pass2_thin" : "k_frame_pass2")};
     const int count = staged ? 8 : 2;

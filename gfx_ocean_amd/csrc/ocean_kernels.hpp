@@ -246,9 +246,18 @@ struct InterLayout {
     // One tile sharded over several GPUs (ocean_tile_pass1 / ocean_tile_pass2, SHARD kernels only): the receive buffer
     // of the all-to-all holds the chunk columns of source rank s in its own slab, chunk column X = s * 2^xs_shift + Xl at
     //     s * src_stride + (the layout above with X = Xl).   Unsharded: xs_shift = 31 (one slab).
+    // With the exchange cut into 2^part_bits parts per rank (one all-to-all per part, overlapped with the next part's
+    // pass 1), block v = X >> xs_shift of the half spectrum is part v % parts of source rank v / parts and sits in slab
+    // part * world + rank:  slab = ((v & (parts - 1)) << rank_bits) | (v >> part_bits).
     int xs_shift = 31;
     size_t src_stride = 0;
+    int part_bits = 0, rank_bits = 0;
 };
+__device__ __forceinline__ size_t tile_slab_offset(const InterLayout& lay, int Xc) {
+    const int v = Xc >> lay.xs_shift;
+    const int slab = ((v & ((1 << lay.part_bits) - 1)) << lay.rank_bits) | (v >> lay.part_bits);
+    return (size_t)slab * lay.src_stride + (size_t)(Xc & ((1 << lay.xs_shift) - 1)) * lay.sx;
+}
 // Rows of chunks are grouped in blocks of B = 2^bshift: chunk (X, Y) sits at
 //     field * fs + (Y / B) * sy + X * sx + (Y % B) * 16        (elements; 16 = one 128-byte chunk).
 // B = 1 is pass-2-contiguous (the chunks of one chunk row adjacent, sx = 16: pass 2 streams 64 KiB runs while pass 1
@@ -695,7 +704,10 @@ __device__ __forceinline__ void half_load_AB(const void* __restrict__ h0T_, floa
     // load phase also drains every outstanding global load, vmcnt being in-order)
     // (N <= 1024: the frame is latency-bound and a thread has half the elements and no register pressure -- one batch:
     // the four dependent rounds of L2 latency were 1.1 us of a 3.7 us workgroup at N = 512, timeline r03)
-    constexpr int LOAD_BATCHES = (N <= 1024) ? 1 : 4;              // measured: 2 and 8 spill more; issuing a batch ahead: +8 us
+#ifndef OCEAN_ONE_BATCH_MAX_N
+#define OCEAN_ONE_BATCH_MAX_N 1024
+#endif
+    constexpr int LOAD_BATCHES = (N <= OCEAN_ONE_BATCH_MAX_N) ? 1 : 4;   // measured: 2 and 8 spill more; issuing a batch ahead: +8 us
     constexpr int PER = E / LOAD_BATCHES;
     int jj = j;
 #pragma unroll
@@ -1005,6 +1017,14 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
     // One wave of every line sits on each SIMD (T = 4 waves per line, waves dealt to the SIMDs cyclically):
     // the line index is a priority that differs between the waves sharing a SIMD.
     if constexpr (T >= 64) wave_priority((OCEAN_SETPRIO == 2) ? (3 - c) : c);
+#endif
+#ifdef OCEAN_STAGGER_SLOT2   // A/B knob: with two co-resident workgroups per CU (P = 2), the second dispatch slot of every CU
+                             // (blocks 256 .. 511 of the first round) starts late by OCEAN_STAGGER_SLOT2 x 3.4 us, so that the
+                             // two workgroups of a CU are in different phases (one loads while the other transforms)
+    if (blockIdx.x >= 256 && blockIdx.x < 512) {
+#pragma unroll 1
+        for (int s_ = 0; s_ < OCEAN_STAGGER_SLOT2; ++s_) __builtin_amdgcn_s_sleep(127);
+    }
 #endif
     const bool packs_nyquist = (Xg == 0) && (c == 0);              // line 0 of that workgroup: column 0 + i * Nyquist
     const uint32_t x = (uint32_t)(Xg * P + c);                     // kx in [0, N/2)
@@ -1392,6 +1412,17 @@ k_half_pass1_split(const void* __restrict__ h0T, float descale, const float* __r
             const c32 lo0 = u0 + t0, hi0 = u0 - t0, lo1 = u1 + t1, hi1 = u1 - t1;
             float4* olo = reinterpret_cast<float4*>(dst + chunk_row_offset(lay, q * (THREADS / CR)));
             float4* ohi = reinterpret_cast<float4*>(dst + chunk_row_offset(lay, q * (THREADS / CR) + M / CR));
+#ifdef OCEAN_X_INTER16   // timing experiment only (wrong results): the access pattern of a 16-bit intermediate -- every
+                         // element offset halved (4-byte complex numbers), 8 bytes per lane -- without its arithmetic: an
+                         // upper bound on what SURVEY 8d's B_frame16 can buy at N = 8192
+            {
+                float2* qlo = reinterpret_cast<float2*>(reinterpret_cast<float*>(inter) + (reinterpret_cast<c32*>(olo) - inter));
+                float2* qhi = reinterpret_cast<float2*>(reinterpret_cast<float*>(inter) + (reinterpret_cast<c32*>(ohi) - inter));
+                *qlo = make_float2(lo0.x + lo0.y, lo1.x + lo1.y);
+                *qhi = make_float2(hi0.x + hi0.y, hi1.x + hi1.y);
+                continue;
+            }
+#endif
             if constexpr (P == CW) {                               // whole chunk rows (2-column chunks): streamed
                 store_float4_nt(olo, make_float4(lo0.x, lo0.y, lo1.x, lo1.y));
                 store_float4_nt(ohi, make_float4(hi0.x, hi0.y, hi1.x, hi1.y));
@@ -1496,11 +1527,10 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
         if constexpr (SHARD) {
             // chunk column X of the tile sits in the slab of source rank X >> xs_shift
             const size_t offy = chunk_row_offset(lay, ly / CR) + (ly % CR) * P1 + (lk % P1);
-            const int xmask = (1 << lay.xs_shift) - 1;
 #pragma unroll
             for (int e = 0; e < EH; ++e) {
                 const int Xc = lk / P1 + e * (T / P1);
-                const size_t o = offy + (size_t)(Xc >> lay.xs_shift) * lay.src_stride + (size_t)(Xc & xmask) * lay.sx;
+                const size_t o = offy + tile_slab_offset(lay, Xc);
                 if (pass == 0) { a[e] = inter[(size_t)1 * lay.fs + o]; b[e] = mk(0.0f, 0.0f); }
                 else { a[e] = inter[o]; b[e] = inter[(size_t)2 * lay.fs + o]; }
             }
@@ -1630,15 +1660,30 @@ k_half_pass2_split(const c32* __restrict__ inter, float4* __restrict__ out, cons
         c32 a[EH], b[EH];
         if constexpr (SHARD) {                                     // see k_half_pass2
             const size_t offy = chunk_row_offset(lay, y / CR) + (y % CR) * P1 + (tf % P1);
-            const int xmask = (1 << lay.xs_shift) - 1;
 #pragma unroll
             for (int e = 0; e < EH; ++e) {
                 const int Xc = tf / P1 + e * (T / P1);
-                const size_t o = offy + (size_t)(Xc >> lay.xs_shift) * lay.src_stride + (size_t)(Xc & xmask) * lay.sx;
+                const size_t o = offy + tile_slab_offset(lay, Xc);
                 if (pass == 0) a[e] = inter[(size_t)1 * lay.fs + o];
                 else { a[e] = inter[o]; b[e] = inter[(size_t)2 * lay.fs + o]; }
             }
-        } else if (pass == 0) {
+        }
+#ifdef OCEAN_X_INTER16   // timing experiment only (wrong results): 4-byte elements at halved offsets (see k_half_pass1_split)
+        else if (pass == 0) {
+            const float* src = reinterpret_cast<const float*>(inter) + (size_t)1 * lay.fs + off;
+#pragma unroll
+            for (int e = 0; e < EH; ++e) { const float v = src[(size_t)e * (T / P1) * lay.sx]; a[e] = mk(v, -v); }
+        } else {
+            const float* sx_ = reinterpret_cast<const float*>(inter) + off;
+            const float* sz_ = reinterpret_cast<const float*>(inter) + (size_t)2 * lay.fs + off;
+#pragma unroll
+            for (int e = 0; e < EH; ++e) {
+                const float v = sx_[(size_t)e * (T / P1) * lay.sx], w = sz_[(size_t)e * (T / P1) * lay.sx];
+                a[e] = mk(v, -v); b[e] = mk(w, w);
+            }
+        }
+#else
+        else if (pass == 0) {
             const c32* src = inter + (size_t)1 * lay.fs + off;
 #pragma unroll
             for (int e = 0; e < EH; ++e) a[e] = src[(size_t)e * (T / P1) * lay.sx];
@@ -1648,6 +1693,7 @@ k_half_pass2_split(const c32* __restrict__ inter, float4* __restrict__ out, cons
 #pragma unroll
             for (int e = 0; e < EH; ++e) { a[e] = sx_[(size_t)e * (T / P1) * lay.sx]; b[e] = sz_[(size_t)e * (T / P1) * lay.sx]; }
         }
+#endif
         if (pass > 0) __syncthreads();
         // C[kx] goes to sub-line kx & 1 at index kx >> 1; kx = tf + e*T keeps its parity (T is even).  Its mirror
         // C[N - kx] has the same parity and index N/2 - (kx >> 1) - (kx & 1).
@@ -1900,21 +1946,27 @@ template <int N, int PSEL = 0> struct Geo {
     // [r N/(2 world), ..) in pass 1 and the rows [r N/world, ..) in pass 2.  The all-to-all buffers are
     //     [dest or src][block of B chunk rows][field][chunk column][chunk row in block][16 elements]
     // -- the intermediate's layout with the peer outermost, so that every (src, dest) message is contiguous.
-    static constexpr bool tile_supported(int world) {
-        return world >= 1 && (world & (world - 1)) == 0 && (N / world) >= 32 && ((N / 2 / world) % P) == 0 && (N / 8 / world) >= 1;
+    // `parts` (a power of two): the rank's column block is transformed and shipped in that many pieces, one all-to-all
+    // each, so that the exchange of piece k runs under pass 1 of piece k + 1 (the reference's barrier
+    // between its row and column dispatches, src/render.rs:1181-1208, becomes `parts` overlapped collectives).
+    static constexpr bool tile_supported(int world, int parts = 1) {
+        return world >= 1 && (world & (world - 1)) == 0 && parts >= 1 && (parts & (parts - 1)) == 0 && (N / world) >= 32 &&
+               (N / 8 / world / parts) >= 1 && ((N / 2 / world / parts) % P) == 0;
     }
-    static InterLayout tile_layout(int world) {
-        const size_t gxl = (size_t)N / 8 / world, gyl = (size_t)N / 4 / world;   // chunk columns / chunk rows per rank
+    static InterLayout tile_layout(int world, int parts = 1) {
+        const size_t gxp = (size_t)N / 8 / world / parts, gyl = (size_t)N / 4 / world;   // chunk columns per piece / chunk rows per rank
         int bs = inter_bshift;
         while (((size_t)1 << bs) > gyl) --bs;
         const size_t B = (size_t)1 << bs;
         InterLayout l{0, 0, 0, bs};
         l.sx = B * 16;
-        l.fs = gxl * l.sx;                                         // field stride inside a block of chunk rows
+        l.fs = gxp * l.sx;                                         // field stride inside a block of chunk rows
         l.sy = 3 * l.fs;                                           // block of chunk rows
         l.xs_shift = 0;
-        while (((size_t)1 << l.xs_shift) < gxl) ++l.xs_shift;
-        l.src_stride = (gyl / B) * l.sy;                           // one (src, dest) message
+        while (((size_t)1 << l.xs_shift) < gxp) ++l.xs_shift;
+        l.src_stride = (gyl / B) * l.sy;                           // one (src, dest, part) message
+        while ((1 << l.part_bits) < parts) ++l.part_bits;
+        while ((1 << l.rank_bits) < world) ++l.rank_bits;
         return l;
     }
     static_assert(row_threads <= 1024 && col_threads <= 1024 && frame_threads <= 1024, "workgroup too large");

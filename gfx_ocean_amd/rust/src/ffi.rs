@@ -79,6 +79,8 @@ extern "C" {
     pub fn ocean_shard_sync(shard: *mut OceanShard) -> i32;
     pub fn ocean_shard_stream(shard: *mut OceanShard) -> *mut c_void;
     pub fn ocean_tile_exchange_bytes(ctx: *const OceanContext, world: i32) -> i64;
-    pub fn ocean_tile_pass1(ctx: *mut OceanContext, locals: *const OceanPropagateLocals, rank: i32, world: i32, send_device: *mut c_void, stream: *mut c_void) -> i32;
-    pub fn ocean_tile_pass2(ctx: *mut OceanContext, rank: i32, world: i32, recv_device: *const c_void, out_rows_device: *mut c_void, stream: *mut c_void) -> i32;
+    pub fn ocean_tile_pass1(ctx: *mut OceanContext, locals: *const OceanPropagateLocals, rank: i32, world: i32, part: i32, parts: i32,
+                            send_part_device: *mut c_void, stream: *mut c_void) -> i32;
+    pub fn ocean_tile_pass2(ctx: *mut OceanContext, rank: i32, world: i32, parts: i32, recv_device: *const c_void, out_rows_device: *mut c_void,
+                            stream: *mut c_void) -> i32;
 }

@@ -225,10 +225,14 @@ void* ocean_shard_stream(OceanShard* shard);
  * on one GPU (tests) or one context per GPU (gfx_ocean_amd/sharded.py).  N = 256 .. 8192, world a power of two with at
  * least 32 rows per rank.  Same barrier as the reference's between its row and column dispatches (src/render.rs:1181-1208). */
 int64_t ocean_tile_exchange_bytes(const OceanContext* ctx, int32_t world);   /* bytes of a rank's send (= receive) buffer; < 0: error */
-int32_t ocean_tile_pass1(OceanContext* ctx, const OceanPropagateLocals* locals, int32_t rank, int32_t world, void* send_device,
-                         void* stream);
-int32_t ocean_tile_pass2(OceanContext* ctx, int32_t rank, int32_t world, const void* recv_device, void* out_rows_device,
-                         void* stream);
+/* `parts` (a power of two, 1 = no pipelining) cuts the rank's column block -- and the exchange -- into that many pieces:
+ * pass 1 of piece `part` fills send_part_device (ocean_tile_exchange_bytes / parts bytes, [dest][...]), the caller ships
+ * it with its own all-to-all into piece `part` of the receive buffer (recv[part][src][...]) while pass 1 of the next piece
+ * runs, and pass 2 consumes the whole receive buffer. */
+int32_t ocean_tile_pass1(OceanContext* ctx, const OceanPropagateLocals* locals, int32_t rank, int32_t world, int32_t part,
+                         int32_t parts, void* send_part_device, void* stream);
+int32_t ocean_tile_pass2(OceanContext* ctx, int32_t rank, int32_t world, int32_t parts, const void* recv_device,
+                         void* out_rows_device, void* stream);
 
 #ifdef __cplusplus
 }

@@ -282,14 +282,14 @@ class EmuTileBackend:
     """Backend of gfx_ocean_amd.sharded.FusedShardedTile that runs the fused kernels of ocean_tile_pass1 / ocean_tile_pass2
     on the CPU (numpy buffers wrapped as torch CPU tensors for gloo).  Test infrastructure only."""
 
-    def __init__(self, n, rank, world, psel=None):
+    def __init__(self, n, rank, world, psel=None, parts=1):
         import torch
         self.torch = torch
-        self.n, self.rank, self.world, self.rows = n, rank, world, n // world
+        self.n, self.rank, self.world, self.rows, self.parts = n, rank, world, n // world, parts
         self.tw = twiddles(n)
         self.psel = int(psel if psel is not None else {512: 1, 4096: 4}.get(n, 2))      # Launch<N>::default_psel()
         self.nyq = np.full(6 * n, np.nan, np.float32)
-        lib().emu_tile.argtypes = ([ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_float] + [ctypes.c_void_p] * 5 +
+        lib().emu_tile.argtypes = ([ctypes.c_int] * 7 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_float] + [ctypes.c_void_p] * 5 +
                                    [ctypes.c_float] * 2)
         self.exchange_floats = 3 * (n // 2) * (n // world) * 2
 
@@ -298,22 +298,26 @@ class EmuTileBackend:
         self.omT = np.ascontiguousarray(omega.T, np.float32)
 
     def alloc_exchange(self):
-        return self.torch.full((self.world, self.exchange_floats // self.world), float("nan"), dtype=self.torch.float32)
+        return self.torch.full((self.parts, self.world, self.exchange_floats // self.world // self.parts), float("nan"),
+                               dtype=self.torch.float32)
 
     def alloc_out(self):
         return self.torch.full((self.rows, self.n, 4), float("nan"), dtype=self.torch.float32)
 
-    def pass1(self, time, domain_size, send):
-        assert lib().emu_tile(self.n, 1, self.psel, self.rank, self.world, _p(self.h0T), 0, 1.0, _p(self.omT), _p(send.numpy()),
-                              _p(self.nyq), None, _p(self.tw), float(time), float(domain_size)) == 0
+    def pass1(self, time, domain_size, send_part, part=0):
+        assert send_part.is_contiguous()
+        assert lib().emu_tile(self.n, 1, self.psel, self.rank, self.world, int(part), self.parts, _p(self.h0T), 0, 1.0, _p(self.omT),
+                              _p(send_part.numpy()), _p(self.nyq), None, _p(self.tw), float(time), float(domain_size)) == 0
 
     def pass2(self, recv, out):
-        assert lib().emu_tile(self.n, 2, self.psel, self.rank, self.world, None, 0, 1.0, None, _p(recv.numpy()), None,
+        assert lib().emu_tile(self.n, 2, self.psel, self.rank, self.world, 0, self.parts, None, 0, 1.0, None, _p(recv.numpy()), None,
                               _p(out.numpy()), _p(self.tw), 0.0, 0.0) == 0
 
-    def on_stream(self):
-        import contextlib
-        return contextlib.nullcontext()
+    def exchange(self, dist, recv_part, send_part):
+        dist.all_to_all_single(recv_part, send_part)
+
+    def join_exchanges(self):
+        pass
 
     def synchronize(self):
         pass

@@ -108,32 +108,33 @@ template <int N> static int run_half(int psel, const void* h0T, int f16, float d
 
 // one tile sharded over `world` ranks, second generation (ocean_tile_pass1 / ocean_tile_pass2 of csrc/ocean_api.hip: same
 // kernels, same geometry, same layouts)
-template <int N, int PSEL> static int run_tile_pass1(int rank, int world, const void* h0T, int f16, float descale, const float* omT,
+template <int N, int PSEL> static int run_tile_pass1(int rank, int world, int part, int parts, const void* h0T, int f16, float descale, const float* omT,
                                                      c32* send, c32* nyq, const c32* tw, float time, float L) {
     using G = Geo<N, PSEL>;
-    if (!G::tile_supported(world)) return -5;
-    const InterLayout lay = G::tile_layout(world);
-    const int groups = (N / 2 / world) / G::P;
+    if (!G::tile_supported(world, parts)) return -5;
+    const InterLayout lay = G::tile_layout(world, parts);
+    const int groups = (N / 2 / world / parts) / G::P;
+    const int x_group0 = (rank * parts + part) * groups;
     if (f16) emu_launch(groups, G::half_threads1,
-                        [&] { k_half_pass1<N, G::E1, G::P, true, G::handover, G::fpar>(h0T, descale, omT, send, nyq, tw, lay, time, L, rank * groups); });
+                        [&] { k_half_pass1<N, G::E1, G::P, true, G::handover, G::fpar>(h0T, descale, omT, send, nyq, tw, lay, time, L, x_group0); });
     else emu_launch(groups, G::half_threads1,
-                    [&] { k_half_pass1<N, G::E1, G::P, false, G::handover, G::fpar>(h0T, 1.0f, omT, send, nyq, tw, lay, time, L, rank * groups); });
+                    [&] { k_half_pass1<N, G::E1, G::P, false, G::handover, G::fpar>(h0T, 1.0f, omT, send, nyq, tw, lay, time, L, x_group0); });
     return 0;
 }
-template <int N, int PSEL> static int run_tile_pass2(int world, const c32* recv, float4* out, const c32* tw) {
+template <int N, int PSEL> static int run_tile_pass2(int world, int parts, const c32* recv, float4* out, const c32* tw) {
     using G = Geo<N, PSEL>;
-    if (!G::tile_supported(world)) return -5;
-    const InterLayout lay = G::tile_layout(world);
+    if (!G::tile_supported(world, parts)) return -5;
+    const InterLayout lay = G::tile_layout(world, parts);
     emu_launch((N / world) / G::R2h, G::half_threads2,
                [&] { k_half_pass2<N, G::E2, CHUNK_W, G::R2h, G::p2_group, G::ppar, true>(recv, out, tw, lay); });
     return 0;
 }
-template <int N> static int run_tile(int what, int psel, int rank, int world, const void* h0T, int f16, float descale, const float* omT,
+template <int N> static int run_tile(int what, int psel, int rank, int world, int part, int parts, const void* h0T, int f16, float descale, const float* omT,
                                      c32* buf, c32* nyq, float4* out, const c32* tw, float time, float L) {
-    if (psel == 1) return what == 1 ? run_tile_pass1<N, 1>(rank, world, h0T, f16, descale, omT, buf, nyq, tw, time, L) : run_tile_pass2<N, 1>(world, buf, out, tw);
-    if (psel == 2) return what == 1 ? run_tile_pass1<N, 2>(rank, world, h0T, f16, descale, omT, buf, nyq, tw, time, L) : run_tile_pass2<N, 2>(world, buf, out, tw);
+    if (psel == 1) return what == 1 ? run_tile_pass1<N, 1>(rank, world, part, parts, h0T, f16, descale, omT, buf, nyq, tw, time, L) : run_tile_pass2<N, 1>(world, parts, buf, out, tw);
+    if (psel == 2) return what == 1 ? run_tile_pass1<N, 2>(rank, world, part, parts, h0T, f16, descale, omT, buf, nyq, tw, time, L) : run_tile_pass2<N, 2>(world, parts, buf, out, tw);
     if constexpr (CHUNK_W % Geo<N, 0>::P != 0) return -4;
-    else return what == 1 ? run_tile_pass1<N, 0>(rank, world, h0T, f16, descale, omT, buf, nyq, tw, time, L) : run_tile_pass2<N, 0>(world, buf, out, tw);
+    else return what == 1 ? run_tile_pass1<N, 0>(rank, world, part, parts, h0T, f16, descale, omT, buf, nyq, tw, time, L) : run_tile_pass2<N, 0>(world, parts, buf, out, tw);
 }
 
 // staged path with the chunked hand-off: rows (natural -> chunked), cols (in place, chunked), correction / un-chunk
@@ -231,9 +232,9 @@ int emu_frame_half(int n, int psel, const void* h0T, int f16, float descale, con
     DISPATCH(n, C_)
 #undef C_
 }
-int emu_tile(int n, int what, int psel, int rank, int world, const void* h0T, int f16, float descale, const float* omT, float* buf,
+int emu_tile(int n, int what, int psel, int rank, int world, int part, int parts, const void* h0T, int f16, float descale, const float* omT, float* buf,
              float* nyq, float* out, const float* tw, float time, float L) {
-#define C_(N) run_tile<N>(what, psel, rank, world, h0T, f16, descale, omT, (c32*)buf, (c32*)nyq, (float4*)out, (const c32*)tw, time, L)
+#define C_(N) run_tile<N>(what, psel, rank, world, part, parts, h0T, f16, descale, omT, (c32*)buf, (c32*)nyq, (float4*)out, (const c32*)tw, time, L)
     DISPATCH(n, C_)
 #undef C_
 }

@@ -222,12 +222,13 @@ def test_gpu_shard_state_errors():
 # ----------------------------------------------------------------------------------------------------------------------
 # Second generation: the fused half-spectrum frame, sharded (ocean_tile_pass1 / ocean_tile_pass2, FusedShardedTile)
 # ----------------------------------------------------------------------------------------------------------------------
-_WORKER2 = _WORKER.replace("sharded.ShardedTile(emu.EmuShardBackend(n, rank, world), dist)", "sharded.FusedShardedTile(emu.EmuTileBackend(n, rank, world), dist)") \
+_WORKER2 = _WORKER.replace("sharded.ShardedTile(emu.EmuShardBackend(n, rank, world), dist)",
+                          "sharded.FusedShardedTile(emu.EmuTileBackend(n, rank, world, parts=int(sys.argv[3])), dist)") \
                   .replace("sharded.exchange_bytes_per_rank(n, world)", "sharded.fused_exchange_bytes_per_rank(n, world)")
 
 
-@pytest.mark.parametrize("world,n", [(2, 512), (4, 256)])
-def test_fused_sharded_tile_matches_the_whole_frame_oracle(tmp_path, world, n):
+@pytest.mark.parametrize("world,n,parts", [(2, 512, 1), (4, 256, 1), (2, 256, 2)])
+def test_fused_sharded_tile_matches_the_whole_frame_oracle(tmp_path, world, n, parts):
     """World 2 and 4 over gloo with the fused kernels in the host emulation: column blocks of the half spectrum, ONE
     all-to-all of half the volume, row blocks out -- against the fp64 oracle of the whole frame."""
     assert "FusedShardedTile" in _WORKER2
@@ -235,7 +236,7 @@ def test_fused_sharded_tile_matches_the_whole_frame_oracle(tmp_path, world, n):
     worker.write_text(_WORKER2)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-                        "--master-addr", "127.0.0.1", "--master-port", str(29560 + world), str(worker), ROOT, str(n)],
+                        "--master-addr", "127.0.0.1", "--master-port", str(29560 + world + 8 * parts), str(worker), ROOT, str(n), str(parts)],
                        capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     r = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
@@ -257,26 +258,29 @@ def test_fused_sharded_single_rank_and_loopback_in_the_emulation():
     nmax, rl2 = oc.parity_errors(tile.gather_tile()[..., :3], ref[..., :3])
     assert nmax.max() < 1e-5 and rl2.max() < 1e-5
     world = 2
-    backs = [emu.EmuTileBackend(n, r, world) for r in range(world)]
-    sends = [b.alloc_exchange() for b in backs]
-    recvs = [b.alloc_exchange() for b in backs]
-    outs = [b.alloc_out() for b in backs]
-    for b, s_ in zip(backs, sends):
-        b.upload(h0, om)
-        b.pass1(t, 1000.0, s_)
-    for r in range(world):
-        for src in range(world):
-            recvs[r][src] = sends[src][r]
-    for b, r_, o in zip(backs, recvs, outs):
-        b.pass2(r_, o)
-    full = np.concatenate([o.numpy() for o in outs], axis=0)
-    nmax, rl2 = oc.parity_errors(full[..., :3], ref[..., :3])
-    assert nmax.max() < 1e-5 and rl2.max() < 1e-5 and np.all(full[..., 3] == 0.0)
+    for parts in (1, 2, 4):                                       # the exchange in 1, 2, 4 pipelined pieces
+        backs = [emu.EmuTileBackend(n, r, world, parts=parts) for r in range(world)]
+        sends = [b.alloc_exchange() for b in backs]               # [part][dest][message]
+        recvs = [b.alloc_exchange() for b in backs]               # [part][src][message]
+        outs = [b.alloc_out() for b in backs]
+        for b, s_ in zip(backs, sends):
+            b.upload(h0, om)
+            for k in range(parts):
+                b.pass1(t, 1000.0, s_[k], part=k)
+        for r in range(world):
+            for src in range(world):
+                for k in range(parts):
+                    recvs[r][k, src] = sends[src][k, r]
+        for b, r_, o in zip(backs, recvs, outs):
+            b.pass2(r_, o)
+        full = np.concatenate([o.numpy() for o in outs], axis=0)
+        nmax, rl2 = oc.parity_errors(full[..., :3], ref[..., :3])
+        assert nmax.max() < 1e-5 and rl2.max() < 1e-5 and np.all(full[..., 3] == 0.0), parts
     with pytest.raises(g.OceanError):
         sharded.FusedShardedTile(backs[0])                       # world 2 without a process group
 
 
-def _fused_loopback_frame(n, world, t, h0, om, f16=False):
+def _fused_loopback_frame(n, world, t, h0, om, f16=False, parts=1):
     """All ranks of ONE fused sharded tile on device 0, one context (the tile entry points keep no per-rank state); the
     all-to-all by hand with device-to-device copies.  Returns the assembled tile [y, x, 4]."""
     import ctypes
@@ -289,7 +293,7 @@ def _fused_loopback_frame(n, world, t, h0, om, f16=False):
         d.upload_spectrum(h0, om, spectrum_fp16=f16)
         nbytes = int(lib.ocean_tile_exchange_bytes(d._ctx, world))
         assert nbytes == sharded.fused_exchange_bytes_per_rank(n, world)
-        slot = nbytes // world
+        slot = nbytes // world // parts                           # one (src, dest, part) message
         rows = n // world
         sends = [DeviceBuffer(nbytes) for _ in range(world)]
         recvs = [DeviceBuffer(nbytes) for _ in range(world)]
@@ -299,13 +303,15 @@ def _fused_loopback_frame(n, world, t, h0, om, f16=False):
             b.fill(0xFF)                                          # NaN patterns: an element nobody wrote shows up in the result
         loc = PropagateLocalsC(float(t), int(n), 1000.0)
         for r in range(world):
-            d._check(lib.ocean_tile_pass1(d._ctx, ctypes.byref(loc), r, world, sends[r].ptr, None))
+            for k in range(parts):                                # send buffer of rank r: [part][dest][message]
+                d._check(lib.ocean_tile_pass1(d._ctx, ctypes.byref(loc), r, world, k, parts, sends[r].ptr + k * world * slot, None))
         d.sync()
-        for r in range(world):
+        for r in range(world):                                    # receive buffer of rank r: [part][src][message]
             for src in range(world):
-                recvs[r].copy_from_device(sends[src].ptr + r * slot, slot, offset=src * slot)
+                for k in range(parts):
+                    recvs[r].copy_from_device(sends[src].ptr + (k * world + r) * slot, slot, offset=(k * world + src) * slot)
         for r in range(world):
-            d._check(lib.ocean_tile_pass2(d._ctx, r, world, recvs[r].ptr, outs[r].ptr, None))
+            d._check(lib.ocean_tile_pass2(d._ctx, r, world, parts, recvs[r].ptr, outs[r].ptr, None))
         d.sync()
         return np.concatenate([o.to_host(np.float32).reshape(rows, n, 4) for o in outs], axis=0), (d.read_spectrum() if f16 else None)
     finally:
@@ -338,12 +344,13 @@ def test_gpu_fused_shard_multi_rank_on_one_device(n, world, f16):
 
 
 @pytest.mark.gpu
-def test_gpu_fused_shard_equals_the_fused_frame_bit_for_bit():
-    """Sharding must not change a single bit: the same kernels on the same columns and rows, only the addresses of the
-    intermediate differ."""
-    n, t = 2048, 2.0
+@pytest.mark.parametrize("n,world,parts", [(2048, 4, 1), (2048, 2, 4), (4096, 8, 2), (512, 2, 2)])
+def test_gpu_fused_shard_equals_the_fused_frame_bit_for_bit(n, world, parts):
+    """Sharding -- and cutting the exchange into pipelined parts -- must not change a single bit: the same kernels on
+    the same columns and rows, only the addresses of the intermediate differ."""
+    t = 2.0
     h0, om = g.synth.make_inputs(n, seed=3)
-    got, _ = _fused_loopback_frame(n, 4, t, h0, om)
+    got, _ = _fused_loopback_frame(n, world, t, h0, om, parts=parts)
     d = g.OceanDevice(n)
     try:
         d.upload_spectrum(h0, om)
@@ -366,13 +373,15 @@ os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER
 torch.cuda.set_device(0)
 dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))   # RCCL, world 1: the collective call itself
 h0, om = g.synth.make_inputs(n, seed=9)
-tile = sharded.FusedShardedTile(sharded.HipTileBackend(n, 0, 1), dist)
-tile.upload(h0, om)
-tile.frame(2.25)
-got = tile.gather_tile()
-nmax, rl2 = oc.parity_errors(got[..., :3], oc.frame_f64(h0, om, 2.25)[..., :3])
-assert nmax.max() < 2e-5 and rl2.max() < 2e-5 and np.all(got[..., 3] == 0.0), (nmax, rl2)
-tile.b.destroy()
+for parts in (1, 4):                       # 4: the pipelined exchange -- four all-to-alls on the communication stream
+    tile = sharded.FusedShardedTile(sharded.HipTileBackend(n, 0, 1, parts=parts), dist)
+    tile.upload(h0, om)
+    for rep in range(3):                   # consecutive frames reuse the exchange buffers behind the right events
+        tile.frame(2.25)
+    got = tile.gather_tile()
+    nmax, rl2 = oc.parity_errors(got[..., :3], oc.frame_f64(h0, om, 2.25)[..., :3])
+    assert nmax.max() < 2e-5 and rl2.max() < 2e-5 and np.all(got[..., 3] == 0.0), (parts, nmax, rl2)
+    tile.b.destroy()
 dist.destroy_process_group()
 print("FUSED_SHARD_GPU_OK")
 """

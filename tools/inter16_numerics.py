@@ -99,7 +99,11 @@ def main():
         chk = oc.frame_f64(h0, om, t)[..., :3]
         base = oc.parity_errors(ref, chk)
         res["self_check_vs_frame_f64"] = [float(base[0].max()), float(base[1].max())]
-    for mode in ("fp16", "bfp16", "bfp15", "bfp16_r4c4", "bfp16_r32c4", "bfp16_r64c2", "bfp16_r16c2"):
+    modes = ["fp16", "bfp16", "bfp15", "bfp16_r4c4", "bfp16_r32c4", "bfp16_r64c2", "bfp16_r16c2",
+             f"bfp16_r1024c2", f"bfp16_r{n}c2", f"bfp16_r{n}c1", f"bfp16_r{n}c4"]     # one exponent per (field, column [pair]): a whole line
+    if "--modes" in sys.argv:
+        modes = sys.argv[sys.argv.index("--modes") + 1].replace("N", str(n)).split(",")
+    for mode in modes:
         out = np.stack(finish([requantise(c, mode) for c in cols], n), -1)
         nmax, rl2 = oc.parity_errors(out, ref)
         res[mode] = {"normalised_max": [float(x) for x in nmax], "rel_l2": [float(x) for x in rl2]}

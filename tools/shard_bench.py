@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--scheme", choices=("rows", "fused"), default="fused",
                     help="fused = the half-spectrum frame sharded by column blocks then row blocks (ocean_tile_*, N <= 8192, "
                          "12 B/texel exchanged); rows = the staged row-block scheme (ocean_shard_*, N <= 16384, 24 B/texel)")
+    ap.add_argument("--parts", type=int, default=1, help="fused scheme: pieces of the pipelined exchange (one all-to-all each)")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -43,7 +44,7 @@ def main():
     h0, om = g.synth.make_inputs(n, seed=n)
     fused = args.scheme == "fused" and n <= 8192
     if fused:
-        tile = sharded.FusedShardedTile(sharded.HipTileBackend(n, rank, world, local), dist)
+        tile = sharded.FusedShardedTile(sharded.HipTileBackend(n, rank, world, local, parts=args.parts), dist)
     else:
         tile = sharded.ShardedTile(sharded.HipShardBackend(n, rank, world, local), dist)
     tile.upload(h0, om)
@@ -67,7 +68,7 @@ def main():
     if rank == 0:
         per = ms / args.steps
         payload = sharded.fused_exchange_bytes_per_rank(n, world) if fused else sharded.exchange_bytes_per_rank(n, world)
-        print(json.dumps({"metric": "frames/s of one sharded N x N tile", "scheme": "fused" if fused else "rows", "n": n, "world": world, "value": 1000.0 / per,
+        print(json.dumps({"metric": "frames/s of one sharded N x N tile", "scheme": "fused" if fused else "rows", "parts": args.parts if fused else None, "n": n, "world": world, "value": 1000.0 / per,
                           "ms_per_frame": per, "all_to_all_bytes_per_rank": payload,
                           "collective": "torch.distributed.all_to_all_single (RCCL)" if dist is not None else "none (one rank)",
                           "hbm_bytes_per_texel": "26 + 28 = 54 (the fused frame's)" if fused else
