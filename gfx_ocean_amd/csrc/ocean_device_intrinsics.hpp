@@ -5,6 +5,38 @@
 
 namespace ocean {
 
+// Race hunting (A/B builds only, -DOCEAN_RACE_JITTER): every workgroup barrier of the kernels is wrapped in pseudo-random
+// wave-uniform sleeps (0 .. ~2.7 us, from the low bits of the shader clock), before and after.  The arithmetic is
+// untouched, so a frame of this build must be BIT-identical to the product build's; a missing or misplaced barrier --
+// two waves touching the same LDS words with only "they usually arrive in this order" between them -- shows up as a
+// difference within a few hundred frames (tests/test_gpu_race.py::test_barrier_jitter_build_is_bit_identical).
+// AddressSanitizer for the device is not available on this pool (xnack-, no instrumented runtime:
+// profiles/r03_run16_asan_attempt_log.txt).
+#ifdef OCEAN_RACE_JITTER
+#ifndef OCEAN_AB
+#error "OCEAN_RACE_JITTER is a test build: it requires -DOCEAN_AB"
+#endif
+__device__ __forceinline__ void race_jitter() {
+    const unsigned t = (unsigned)__builtin_readcyclecounter();
+    switch ((t >> 2) & 7u) {                                       // wave-uniform (scalar clock)
+        case 0: break;
+        case 1: __builtin_amdgcn_s_sleep(1); break;
+        case 2: __builtin_amdgcn_s_sleep(3); break;
+        case 3: __builtin_amdgcn_s_sleep(7); break;
+        case 4: __builtin_amdgcn_s_sleep(15); break;
+        case 5: __builtin_amdgcn_s_sleep(31); break;
+        case 6: __builtin_amdgcn_s_sleep(63); break;
+        default: __builtin_amdgcn_s_sleep(100); break;
+    }
+}
+__device__ __forceinline__ void jittered_syncthreads() {
+    race_jitter();
+    __syncthreads();
+    race_jitter();
+}
+#define __syncthreads() ::ocean::jittered_syncthreads()
+#endif
+
 // A complex number is a 2-vector of floats living in an even-aligned VGPR pair, so that complex arithmetic
 // maps onto gfx950's packed fp32 instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: two lanes per
 // instruction, swizzles through op_sel): pass 1's phases are VALU-issue-bound (tools/timeline.hip), and the

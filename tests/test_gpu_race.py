@@ -93,3 +93,62 @@ def test_create_destroy_soak():
             with pytest.raises(g.OceanError):
                 d.frame(0.0)
     assert first[(512, False)] != first[(512, True)]
+
+
+_JITTER_WORKER = r"""
+import json, sys
+sys.path.insert(0, sys.argv[1])
+import gfx_ocean_amd as g
+res = {}
+for n in (256, 512, 1024, 2048, 4096, 8192):
+    for f16 in (False, True):
+        h0, om = g.synth.make_inputs(n, seed=n + 1)
+        r = g.OceanRenderer(n)
+        r.upload(h0, om, spectrum_fp16=f16)
+        sums = set()
+        for i in range(int(sys.argv[2])):
+            r.render_fused(2.75)
+            sums.add(r.device.checksum())
+        key = f"{n}:{int(f16)}"
+        res[key + ":fused"] = sorted(sums)
+        if not f16 and n <= 4096:
+            sums = set()
+            for i in range(max(4, int(sys.argv[2]) // 8)):
+                r.render(2.75)
+                sums.add(r.device.checksum())
+            res[key + ":staged"] = sorted(sums)
+        r.dispose()
+print("SUMS " + json.dumps(res))
+"""
+
+
+def test_barrier_jitter_build_is_bit_identical(tmp_path):
+    """Race hunting without a device sanitizer (none on this pool: profiles/r03_run16_asan_attempt_log.txt): the library is
+    rebuilt with every workgroup barrier wrapped in pseudo-random wave-uniform sleeps (-DOCEAN_RACE_JITTER,
+    csrc/ocean_device_intrinsics.hpp).  Same arithmetic, perturbed wave timing: every frame of that build -- all sizes,
+    fp32 and fp16-stored spectrum, fused and staged -- must have the checksum the product build produces."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from gfx_ocean_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "libocean_hip_jitter.so")
+    subprocess.check_call(_lib.hipcc_command(out=so, extra=("-DOCEAN_AB", "-DOCEAN_RACE_JITTER")))
+
+    def sums(lib, reps):
+        env = dict(os.environ)
+        if lib:
+            env["OCEAN_HIP_LIB"] = lib
+        else:
+            env.pop("OCEAN_HIP_LIB", None)
+        p = subprocess.run([sys.executable, "-c", _JITTER_WORKER, root, str(reps)], capture_output=True, text=True, timeout=1500, env=env)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+        return json.loads([l for l in p.stdout.splitlines() if l.startswith("SUMS ")][0][5:])
+
+    want = sums(None, 2)
+    got = sums(so, 64)
+    assert set(want) == set(got)
+    for key, v in want.items():
+        assert len(v) == 1, (key, "the product build itself is not reproducible", v)
+        assert got[key] == v, (key, "jittered barriers changed the result: a race", got[key], v)
