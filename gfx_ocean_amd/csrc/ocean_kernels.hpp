@@ -1847,12 +1847,24 @@ template <int N, int PSEL = 0> struct Geo {
     static constexpr int row_threads = T * ROW_LPW;
     static constexpr int col_threads = T * COL_LPW;
     static constexpr int frame_threads = T * P;
+    // Fused pass 1 hands the intra-workgroup duplicate spectrum streams over through LDS (the split kernels' pair
+    // loader half_load_AB_pairs_handover; half_load_AB_handover for whole lines) instead of asking the memory system
+    // twice.  Shipped at N = 8192, where every 64 KiB line was fetched twice: pass 1 486-490 -> 444-460 us, 1044-1049 ->
+    // 1091-1094 frames/s (run r03_run2, two interleaved repetitions).  NOT at 4096: there the L2 already merges most
+    // twins (269 MB fetched against 235 MB of distinct lines), and the four barriers the hand-over puts into the load
+    // phase cost more than the 30 MB are worth -- 96.0-100.0 us against 91.8-96.6 (runs r03_run2/3; software-pipelining
+    // the batches across the barriers changed nothing).  Below 4096 the working set is cache-resident.
+    // A/B knob: OCEAN_HANDOVER_MIN_N (the CPU emulation builds with 256 to run the hand-over geometry of every size).
+#ifndef OCEAN_HANDOVER_MIN_N
+#define OCEAN_HANDOVER_MIN_N 8192
+#endif
+    static constexpr bool handover = (N >= OCEAN_HANDOVER_MIN_N) && (P >= 2);
     // Field-parallel pass 1 (k_half_pass1<.., FPAR>): three wave groups per workgroup, one per field, at the latency-bound
     // sizes.  A/B knob: OCEAN_FPAR_MAX_N (0 = off).
 #ifndef OCEAN_FPAR_MAX_N
 #define OCEAN_FPAR_MAX_N 512
 #endif
-    static constexpr bool fpar = (N <= OCEAN_FPAR_MAX_N) && (((N / E1) * P) % 64 == 0) && (3 * (N / E1) * P <= 1024);
+    static constexpr bool fpar = (N <= OCEAN_FPAR_MAX_N) && (((N / E1) * P) % 64 == 0) && (3 * (N / E1) * P <= 1024) && !handover;
     static constexpr int half_threads1 = (N / E1) * P * (fpar ? 3 : 1);   // fused pass 1 (half-spectrum path)
     static constexpr int split_threads1 = (N / E1S) * P;
     static constexpr int line_bytes = LinePitch<N>::elems * (int)sizeof(c32);
@@ -1912,18 +1924,6 @@ template <int N, int PSEL = 0> struct Geo {
 #else
     static constexpr int p2_group = (inter_bshift > 0) ? 8 : 1;
 #endif
-    // Fused pass 1 hands the intra-workgroup duplicate spectrum streams over through LDS (the split kernels' pair
-    // loader half_load_AB_pairs_handover; half_load_AB_handover for whole lines) instead of asking the memory system
-    // twice.  Shipped at N = 8192, where every 64 KiB line was fetched twice: pass 1 486-490 -> 444-460 us, 1044-1049 ->
-    // 1091-1094 frames/s (run r03_run2, two interleaved repetitions).  NOT at 4096: there the L2 already merges most
-    // twins (269 MB fetched against 235 MB of distinct lines), and the four barriers the hand-over puts into the load
-    // phase cost more than the 30 MB are worth -- 96.0-100.0 us against 91.8-96.6 (runs r03_run2/3; software-pipelining
-    // the batches across the barriers changed nothing).  Below 4096 the working set is cache-resident.
-    // A/B knob: OCEAN_HANDOVER_MIN_N (the CPU emulation builds with 256 to run the hand-over geometry of every size).
-#ifndef OCEAN_HANDOVER_MIN_N
-#define OCEAN_HANDOVER_MIN_N 8192
-#endif
-    static constexpr bool handover = (N >= OCEAN_HANDOVER_MIN_N) && (P >= 2);
     static constexpr int thin_threads = T * R2;
     static constexpr int thin_lds = R2 * Pitch2<N, R2>::elems * (int)sizeof(c32);
     static constexpr int half_threads2 = T2 * R2h * (ppar ? 2 : 1);  // fused pass 2 (half-spectrum path)

@@ -124,7 +124,7 @@ def test_committed_bench_lines_carry_the_contract_fields():
     """The lines the GPU box produced (profiles/) have every field of the bench contract, with the roofline computed from
     the bytes the kernels move and the three-complex-transform accounting beside it, never as `achieved`."""
     import glob
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_run*_bench*.json")))
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[23]_run*_bench*.json")))
     assert paths
     for path in paths:
         with open(path) as f:
@@ -144,6 +144,9 @@ def test_committed_bench_lines_carry_the_contract_fields():
         assert abs(dom["algorithmic_bytes"] - moved) < 1 and abs(ro["achieved"] - moved / dom["avg_ms"] / 1e6) < 1e-6 * ro["achieved"]
         assert ro["contract_frac"] > ro["frac"]                      # the 76-byte accounting is reported, but not as `achieved`
         assert 0.0 < ro["frac"] < 0.79                               # nothing above the part's measured copy ceiling (6.29 TB/s)
+        if os.path.basename(path).startswith("r03"):                # round 3: where the traffic figure comes from, and the real warm-up
+            assert ro["traffic_source"]["file"].startswith("profiles/hbm_traffic_n") and "NOT measured in this run" in ro["traffic_source"]["method"]
+            assert r["config"]["effective_warmup_frames"] >= r["warmup"]
         if "cpu_baseline" in r:
             for k in ("value", "unit", "cores", "kind", "sample"):
                 assert k in r["cpu_baseline"], (path, k)

@@ -19,18 +19,23 @@ PY
 echo "== bench (driver flags)"; timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 2>$O/bench.err | tee $O/bench.json | cut -c1-300
 echo "== bench config 5"; timeout 900 python bench.py --n 8192 --spectrum f16 --steps 20 --warmup 5 2>$O/bench_f16.err | tee $O/bench_n8192_f16.json | cut -c1-300
 cd /tmp
-run_prof() {   # name, then the command
-  local name=$1; shift
+run_prof() {   # name, N, traffic flag ("-", f16 or staged), then the command
+  local name=$1 n=$2 flag=$3; shift 3
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$name/stats -o run -- "$@" > $O/$name.stats_stdout.txt 2>&1
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/$name/pmc_$c -o run -- "$@" > $O/$name.pmc_${c}_stdout.txt 2>&1
   done
   python $GRAFT_REPO_ROOT/tools/rocprof_summary.py $O/$name > $O/$name.summary.txt 2>&1
-  echo "== $name"; grep -v "^$" $O/$name.summary.txt | cut -c1-160 | head -24
+  python $GRAFT_REPO_ROOT/tools/make_hbm_traffic.py $O/$name $n $TAG $flag > $O/$name.hbm_traffic.txt 2>&1
+  cp $GRAFT_REPO_ROOT/profiles/hbm_traffic_*.json $O/ 2>/dev/null
+  echo "== $name"; grep -v "^$" $O/$name.summary.txt | cut -c1-160 | head -30
 }
-run_prof fused_n4096 python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 20 --warmup 5 --profile-frames 5
-run_prof fused_n8192_f16 python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --n 8192 --spectrum f16 --steps 10 --warmup 2 --profile-frames 2
-run_prof staged_n4096 python $GRAFT_REPO_ROOT/tools/staged_frames.py 4096 10
+run_prof fused_n4096 4096 - python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 200 --warmup 5 --profile-frames 5
+run_prof fused_n8192_f16 8192 f16 python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --n 8192 --spectrum f16 --steps 60 --warmup 2 --profile-frames 2
+run_prof staged_n4096 4096 staged python $GRAFT_REPO_ROOT/tools/staged_frames.py 4096 10
+for N in 512 2048 8192; do
+  run_prof fused_n$N $N - python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --n $N --steps 100 --warmup 5 --profile-frames 3
+done
 cd $GRAFT_REPO_ROOT
 # keep the pulled directory small: the csv traces are summarised above
 find $O -name "*.csv" -size +2M -delete

@@ -37,7 +37,7 @@ def main():
     fetch, write = counters(d, "FETCH_SIZE"), counters(d, "WRITE_SIZE")
     kernels = {}
     for k in sorted(set(fetch) & set(write)):
-        if k.startswith("k_checksum") or k.startswith("k_pack"):
+        if not k.startswith("k_") or k.startswith("k_checksum") or k.startswith("k_pack"):
             continue
         kernels[k] = {"kernel": fetch[k][2], "dispatches": fetch[k][1], "FETCH_SIZE_KB": round(fetch[k][0], 1),
                       "WRITE_SIZE_KB": round(write[k][0], 1), "hbm_bytes": (2.0 * fetch[k][0] + write[k][0]) * 1024.0}
