@@ -40,10 +40,15 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s me
 #          the spectrum is stored as fp16 pairs) + omega 4, write the half-spectrum intermediate 12
 #   pass2: read 12, write RGBA32F 16
 MOVED_BYTES_PER_TEXEL = {"f32": {"pass1": 26.0, "pass2": 28.0}, "f16": {"pass1": 21.0, "pass2": 28.0}}
+# --intermediate bfp16 (opt-in precision mode, N = 8192): the half-spectrum intermediate as int16 pairs, 6 instead of
+# 12 B/texel on each side (+ 3 MB of block scales, not counted)
+INTER16_SAVING = 6.0
 # The contract accounting of SURVEY.md 8d (three complex 2-D transforms per frame, B_frame = 76 N^2; 72 N^2 with
 # an fp16-stored spectrum): reported next to the real bytes as `contract_*`, never as `achieved`.
 #   pass1: read h0 8 (4) + omega 4, write 3 complex fields 24; pass2: read 24, write RGBA32F 16
 CONTRACT_BYTES_PER_TEXEL = {"f32": {"pass1": 36.0, "pass2": 40.0}, "f16": {"pass1": 32.0, "pass2": 40.0}}
+# ... and with a 16-bit intermediate of three complex fields (SURVEY 8d "B_frame16": 4 + 4 | 12 | 12 | 16 with fp16 h0)
+CONTRACT16_BYTES_PER_TEXEL = {"f32": {"pass1": 24.0, "pass2": 28.0}, "f16": {"pass1": 20.0, "pass2": 28.0}}
 
 
 def pass_of(kernel_name):
@@ -57,11 +62,11 @@ def aggregate(values_ms, n_gpus, steps):
     return {"ms_per_step": ms_per_step, "value": n_gpus * 1000.0 / ms_per_step}
 
 
-def measured_traffic(n, kernel_name, spectrum="f32"):
+def measured_traffic(n, kernel_name, spectrum="f32", intermediate="f32"):
     """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and
     WRITE_SIZE are collected in separate runs of this same command, never inside the timed bench;
     gfx950 correction 2*FETCH_SIZE + WRITE_SIZE -- DESIGN.md 7).  None if no pass exists for this N."""
-    suffix = "" if spectrum == "f32" else "_f16"
+    suffix = ("" if spectrum == "f32" else "_f16") + ("" if intermediate == "f32" else "_bfp16")
     path = os.path.join(ROOT, "profiles", f"hbm_traffic_n{n}{suffix}.json")
     try:
         with open(path) as f:
@@ -72,10 +77,10 @@ def measured_traffic(n, kernel_name, spectrum="f32"):
     return v["hbm_bytes"] if v else None
 
 
-def traffic_source(n, spectrum="f32"):
+def traffic_source(n, spectrum="f32", intermediate="f32"):
     """Where `roofline.traffic` comes from: never from the timed run (counters perturb timing and need rocprofv3
     around the process) but from a committed PMC pass of this same command."""
-    suffix = "" if spectrum == "f32" else "_f16"
+    suffix = ("" if spectrum == "f32" else "_f16") + ("" if intermediate == "f32" else "_bfp16")
     rel = os.path.join("profiles", f"hbm_traffic_n{n}{suffix}.json")
     try:
         with open(os.path.join(ROOT, rel)) as f:
@@ -359,6 +364,9 @@ def main():
     ap.add_argument("--n", type=int, default=4096, help="tile edge (power of two, 256..8192)")
     ap.add_argument("--spectrum", choices=("f32", "f16"), default="f32",
                     help="storage of the initial spectrum in HBM (f16 = BASELINE config 5: scaled fp16 pairs, fp32 arithmetic)")
+    ap.add_argument("--intermediate", choices=("f32", "bfp16"), default="f32",
+                    help="precision of the intermediate between the two launches: f32 (default, what every parity figure refers to) or "
+                         "bfp16 (opt-in, N = 8192: int16 mantissas + one power-of-two scale per 64 x 2 block; ~3e-5 normalised max)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", dest="gather", action="store_true", default=None,
                     help="time frames followed by an RCCL gather of every tile's RGBA map to rank 0 (BASELINE config 4; "
@@ -438,6 +446,8 @@ def main():
     h0, omega = g.synth.make_inputs(n, seed=seed)
     dev = g.OceanDevice(n, device_ordinal=local_rank)
     dev.upload_spectrum(h0, omega, spectrum_fp16=(args.spectrum == "f16"))
+    if args.intermediate == "bfp16":
+        dev.set_intermediate(g.INTER_BFP16)
 
     def barrier():
         dev.sync()
@@ -472,7 +482,10 @@ def main():
         all_ms = [wall_ms]
     agg = aggregate(all_ms, n_gpus, args.steps)
 
-    moved, contract = MOVED_BYTES_PER_TEXEL[args.spectrum], CONTRACT_BYTES_PER_TEXEL[args.spectrum]
+    moved, contract = dict(MOVED_BYTES_PER_TEXEL[args.spectrum]), CONTRACT_BYTES_PER_TEXEL[args.spectrum]
+    if args.intermediate == "bfp16":
+        moved = {k: v - INTER16_SAVING for k, v in moved.items()}
+        contract = CONTRACT16_BYTES_PER_TEXEL[args.spectrum]
     kernels = []
     for name, total in acc.items():
         avg_ms = total / args.profile_frames
@@ -480,12 +493,12 @@ def main():
         cb = contract[pass_of(name)] * n * n
         kernels.append({"name": name, "avg_ms": avg_ms, "algorithmic_bytes": b, "GBps": b / avg_ms / 1e6,
                         "frac": b / avg_ms / 1e6 / HBM_PEAK_GBS, "contract_bytes": cb, "contract_GBps": cb / avg_ms / 1e6,
-                        "contract_frac": cb / avg_ms / 1e6 / HBM_PEAK_GBS, "traffic": measured_traffic(n, name, args.spectrum)})
+                        "contract_frac": cb / avg_ms / 1e6 / HBM_PEAK_GBS, "traffic": measured_traffic(n, name, args.spectrum, args.intermediate)})
     dom = max(kernels, key=lambda k: k["avg_ms"])
     frame_ms = event_ms / args.steps
     fb, fcb = sum(moved.values()) * n * n, sum(contract.values()) * n * n
     roofline = {"bound": "hbm", "kernel": dom["name"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": dom["frac"], "traffic": dom["traffic"], "traffic_source": traffic_source(n, args.spectrum),
+                "frac": dom["frac"], "traffic": dom["traffic"], "traffic_source": traffic_source(n, args.spectrum, args.intermediate),
                 "algorithmic_bytes_per_launch": dom["algorithmic_bytes"], "avg_launch_ms": dom["avg_ms"],
                 "accounting": f"achieved = bytes the shipped half-spectrum algorithm must move ({moved['pass1']:.0f} + "
                               f"{moved['pass2']:.0f} B/texel) / kernel time; contract_* = SURVEY 8d's three-complex-"
@@ -498,6 +511,9 @@ def main():
 
     if rank == 0:
         spec_txt = "fp32 spectrum" if args.spectrum == "f32" else "fp16-stored spectrum (scaled pairs), fp32 arithmetic and intermediate"
+        if args.intermediate == "bfp16":
+            spec_txt = spec_txt.replace(" and intermediate", "") + ("; OPT-IN PRECISION MODE: 16-bit block-floating intermediate (int16 mantissas, "
+                                                                    "one power-of-two scale per 64 x 2 block; ~3e-5 normalised max against the fp32 intermediate)")
         line = {
             "metric": "ocean frames/sec (propagate + 3x 2-D iFFT + correction, one NxN tile per GPU)",
             "value": agg["value"], "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -507,7 +523,7 @@ def main():
                                    f"row pass + correction), height+disp_x+disp_z; half-spectrum real-output algorithm: "
                                    f"{sum(moved.values()):.0f} B/texel moved ({sum(contract.values()):.0f} B/texel on the "
                                    f"three-complex-transform accounting of SURVEY 8d); seed N+rank",
-                       "n": n, "spectrum": args.spectrum, "tiles": n_gpus,
+                       "n": n, "spectrum": args.spectrum, "intermediate": args.intermediate, "tiles": n_gpus,
                        "parallelism": f"tile-parallel x{n_gpus}, no data-path collective",
                        "gpu_event_ms_per_step": frame_ms,
                        "effective_warmup_frames": args.ramp_frames + 3 * args.profile_frames + args.warmup,

@@ -22,7 +22,7 @@ SYMBOLS = [
     "ocean_fft_init", "ocean_fft_destroy", "ocean_propagation_init",
     "ocean_propagation_destroy", "ocean_correction_init", "ocean_correction_destroy", "ocean_propagate",
     "ocean_fft_rows", "ocean_fft_cols", "ocean_correct", "ocean_frame", "ocean_frame_ex", "ocean_sync",
-    "ocean_set_quirks", "ocean_quirks",
+    "ocean_set_quirks", "ocean_quirks", "ocean_set_intermediate", "ocean_intermediate",
     "ocean_normals", "ocean_read_normals", "ocean_positions", "ocean_read_positions",
     "ocean_checksum_displacement", "ocean_packed_bytes", "ocean_pack_displacement",
     "ocean_read_displacement", "ocean_read_field", "ocean_write_field", "ocean_displacement_device_ptr",
@@ -106,6 +106,8 @@ def load_library():
         "ocean_sync": (i32, [vp]),
         "ocean_set_quirks": (i32, [vp, ctypes.c_uint32]),
         "ocean_quirks": (ctypes.c_uint32, [vp]),
+        "ocean_set_intermediate": (i32, [vp, i32]),
+        "ocean_intermediate": (i32, [vp]),
         "ocean_normals": (i32, [vp, i32, vp]),
         "ocean_read_normals": (i32, [vp, vp]),
         "ocean_positions": (i32, [vp, i32, f32, f32, vp]),

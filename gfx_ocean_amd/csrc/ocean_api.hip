@@ -77,6 +77,8 @@ struct OceanContext {
     InterLayout lay{0, 0, 0, 0};     // three complex fields, all N columns, B = 1   (staged hand-off; OCEAN_ALGO=c2c)
     InterLayout lay_h{0, 0, 0, 0};   // three complex fields, columns 0..N/2-1       (half-spectrum path)
     c32* nyq = nullptr;           // scratch of the half-spectrum path: the Nyquist column's 3 spectra, 3 x N complex
+    bool inter16 = false;         // ocean_set_intermediate(OCEAN_INTER_BFP16): int16 intermediate + block scales (N = 8192)
+    float* inter_scale = nullptr; // [3][N/64][N/4] block scales of that mode (allocated on first use)
     bool half = true;             // OCEAN_ALGO=c2c selects the three-complex-transform frame (A/B)
     bool split = false;           // lines as two interleaved N/2 transforms (N = 8192; OCEAN_SPLIT=0/1 for A/B)
     int P = 0;                    // chunk width of the c2c path (fixed per N)
@@ -226,6 +228,15 @@ template <int N> struct Launch {
             if (e != hipSuccess) return e;
             e = hipFuncSetAttribute((const void*)k_half_pass2_split<N, H::E, CHUNK_W, H::p2_group, true>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, H::split_lds2);
+            if (e != hipSuccess) return e;
+            e = hipFuncSetAttribute((const void*)k_half_pass2_split<N, H::E, CHUNK_W, H::p2_group, false, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, H::split_lds2);
+            if (e != hipSuccess) return e;
+            e = hipFuncSetAttribute((const void*)k_half_pass1_split<N, H::E1S, H::P, false, H::handover, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, H::split_lds1);
+            if (e != hipSuccess) return e;
+            e = hipFuncSetAttribute((const void*)k_half_pass1_split<N, H::E1S, H::P, true, H::handover, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, H::split_lds1);
         }
         return e;
     }
@@ -234,14 +245,25 @@ template <int N> struct Launch {
         const float descale = std::ldexp(1.0f, -c->scale_log2);
         if constexpr (split_built<PSEL>()) {
             if (c->split) {
+                if (c->inter16) {                                  // opt-in precision mode (ocean_set_intermediate)
+                    if (c->h0_f16)
+                        launch(k_half_pass1_split<N, H::E1S, H::P, true, H::handover, true>, dim3(H::half_grid1), dim3(H::split_threads1),
+                               H::split_lds1, s, t, (const void*)c->h0T, descale, (const float*)c->omegaT, c->inter, c->nyq,
+                               (const c32*)c->tw, c->lay_h, time, domain, 0, c->inter_scale);
+                    else
+                        launch(k_half_pass1_split<N, H::E1S, H::P, false, H::handover, true>, dim3(H::half_grid1), dim3(H::split_threads1),
+                               H::split_lds1, s, t, (const void*)c->h0T, 1.0f, (const float*)c->omegaT, c->inter, c->nyq,
+                               (const c32*)c->tw, c->lay_h, time, domain, 0, c->inter_scale);
+                    return;
+                }
                 if (c->h0_f16)
                     launch(k_half_pass1_split<N, H::E1S, H::P, true, H::handover>, dim3(H::half_grid1), dim3(H::split_threads1),
                            H::split_lds1, s, t, (const void*)c->h0T, descale, (const float*)c->omegaT, c->inter, c->nyq,
-                           (const c32*)c->tw, c->lay_h, time, domain, 0);
+                           (const c32*)c->tw, c->lay_h, time, domain, 0, (float*)nullptr);
                 else
                     launch(k_half_pass1_split<N, H::E1S, H::P, false, H::handover>, dim3(H::half_grid1), dim3(H::split_threads1),
                            H::split_lds1, s, t, (const void*)c->h0T, 1.0f, (const float*)c->omegaT, c->inter, c->nyq,
-                           (const c32*)c->tw, c->lay_h, time, domain, 0);
+                           (const c32*)c->tw, c->lay_h, time, domain, 0, (float*)nullptr);
                 return;
             }
         }
@@ -274,8 +296,12 @@ template <int N> struct Launch {
 #endif
         if constexpr (split_built<PSEL>()) {
             if (c->split) {
-                launch(k_half_pass2_split<N, H::E, CHUNK_W, H::p2_group>, dim3(N), dim3(H::split_threads2), H::split_lds2, s, t,
-                       (const c32*)c->inter, c->out, (const c32*)c->tw, c->lay_h);
+                if (c->inter16)
+                    launch(k_half_pass2_split<N, H::E, CHUNK_W, H::p2_group, false, true>, dim3(N), dim3(H::split_threads2), H::split_lds2, s, t,
+                           (const c32*)c->inter, c->out, (const c32*)c->tw, c->lay_h, (const float*)c->inter_scale);
+                else
+                    launch(k_half_pass2_split<N, H::E, CHUNK_W, H::p2_group>, dim3(N), dim3(H::split_threads2), H::split_lds2, s, t,
+                           (const c32*)c->inter, c->out, (const c32*)c->tw, c->lay_h, (const float*)nullptr);
                 return;
             }
         }
@@ -299,10 +325,10 @@ template <int N> struct Launch {
         if constexpr (split_built<default_psel()>()) {
             if (c->h0_f16)
                 hipLaunchKernelGGL((k_half_pass1_split<N, H::E1S, H::P, true, H::handover>), dim3(groups), dim3(H::split_threads1), H::split_lds1, s,
-                                   (const void*)c->h0T, descale, (const float*)c->omegaT, send, c->nyq, (const c32*)c->tw, lay, time, domain, x_group0);
+                                   (const void*)c->h0T, descale, (const float*)c->omegaT, send, c->nyq, (const c32*)c->tw, lay, time, domain, x_group0, (float*)nullptr);
             else
                 hipLaunchKernelGGL((k_half_pass1_split<N, H::E1S, H::P, false, H::handover>), dim3(groups), dim3(H::split_threads1), H::split_lds1, s,
-                                   (const void*)c->h0T, descale, (const float*)c->omegaT, send, c->nyq, (const c32*)c->tw, lay, time, domain, x_group0);
+                                   (const void*)c->h0T, descale, (const float*)c->omegaT, send, c->nyq, (const c32*)c->tw, lay, time, domain, x_group0, (float*)nullptr);
         } else {
             if (c->h0_f16)
                 hipLaunchKernelGGL((k_half_pass1<N, H::E1, H::P, true, H::handover, H::fpar>), dim3(groups), dim3(H::half_threads1), H::half_lds1, s,
@@ -318,7 +344,7 @@ template <int N> struct Launch {
         const int rows = N / world;
         if constexpr (split_built<default_psel()>())
             hipLaunchKernelGGL((k_half_pass2_split<N, H::E, CHUNK_W, H::p2_group, true>), dim3(rows), dim3(H::split_threads2), H::split_lds2, s,
-                               recv, out_rows, (const c32*)c->tw, lay);
+                               recv, out_rows, (const c32*)c->tw, lay, (const float*)nullptr);
         else
             hipLaunchKernelGGL((k_half_pass2<N, H::E2, CHUNK_W, H::R2h, H::p2_group, H::ppar, true>), dim3(rows / H::R2h), dim3(H::half_threads2),
                                H::half_lds2, s, recv, out_rows, (const c32*)c->tw, lay);
@@ -472,7 +498,7 @@ void free_all(OceanContext* c) {
     auto f = [](void* p) { if (p) (void)hipFree(p); };
     f(c->h0); f(c->omega); f(c->field[0]); f(c->field[1]); f(c->field[2]);
     f(c->cfield[0]); f(c->cfield[1]); f(c->cfield[2]);
-    f(c->h0T); f(c->omegaT); f(c->inter); f(c->nyq); f(c->tw); f(c->out_own); f(c->normals); f(c->positions); f(c->checksum_acc);
+    f(c->h0T); f(c->omegaT); f(c->inter); f(c->nyq); f(c->tw); f(c->out_own); f(c->normals); f(c->positions); f(c->checksum_acc); f(c->inter_scale);
     if (c->ev_a) (void)hipEventDestroy(c->ev_a);
     if (c->ev_b) (void)hipEventDestroy(c->ev_b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -777,6 +803,23 @@ int32_t ocean_set_quirks(OceanContext* ctx, uint32_t quirks) {
     return OCEAN_OK;
 }
 uint32_t ocean_quirks(const OceanContext* ctx) { return valid(ctx) ? ctx->quirks : 0u; }
+
+int32_t ocean_set_intermediate(OceanContext* ctx, int32_t mode) {
+    if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    if (mode != OCEAN_INTER_F32 && mode != OCEAN_INTER_BFP16) return fail(ctx, OCEAN_E_INVALID_ARG, "unknown intermediate mode");
+    if (mode == OCEAN_INTER_BFP16) {
+        bool ok = false;
+        OCEAN_DISPATCH(ctx->n, ok = L::template split_built<L::default_psel()>() && ctx->split);
+        if (!ok) return fail(ctx, OCEAN_E_UNSUPPORTED_N, "the 16-bit intermediate exists for the split-line kernels only (N = 8192, BASELINE config 5)");
+        if (!ctx->inter_scale) {
+            DeviceGuard guard(ctx->device);
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->inter_scale, (size_t)3 * (ctx->n / 64) * (ctx->n / 4) * sizeof(float)));
+        }
+    }
+    ctx->inter16 = (mode == OCEAN_INTER_BFP16);
+    return OCEAN_OK;
+}
+int32_t ocean_intermediate(const OceanContext* ctx) { return valid(ctx) ? (ctx->inter16 ? OCEAN_INTER_BFP16 : OCEAN_INTER_F32) : OCEAN_E_INVALID_ARG; }
 
 int32_t ocean_frame(OceanContext* ctx, float time, void* stream) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;

@@ -160,6 +160,37 @@ __device__ __forceinline__ c32 unpack_half2(uint32_t bits, float descale) {
     return mk((float)h.x * descale, (float)h.y * descale);
 }
 
+// ---- 16-bit block-floating intermediate (opt-in precision mode, SURVEY 8d "B_frame16") ---------------------------------
+// Maximum of a NON-NEGATIVE value over the 64 lanes of the wave, returned in every lane: four DPP steps inside the
+// rows of 16 lanes (quad permutes, half-row and row mirrors: one v_max with a DPP operand each), then the four rows
+// through readlane.  (North_star's "wavefront shuffle reduction": this is the one reduction the path has.)
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+    int b = __builtin_bit_cast(int, v);                            // non-negative floats order like their bit patterns
+    b = max(b, __builtin_amdgcn_update_dpp(0, b, 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+    b = max(b, __builtin_amdgcn_update_dpp(0, b, 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+    b = max(b, __builtin_amdgcn_update_dpp(0, b, 0x141, 0xF, 0xF, false));   // row_half_mirror
+    b = max(b, __builtin_amdgcn_update_dpp(0, b, 0x140, 0xF, 0xF, false));   // row_mirror
+    const int m = max(max(__builtin_amdgcn_readlane(b, 0), __builtin_amdgcn_readlane(b, 16)),
+                      max(__builtin_amdgcn_readlane(b, 32), __builtin_amdgcn_readlane(b, 48)));
+    return __builtin_bit_cast(float, m);
+}
+// Block scale for int16 mantissas: the power of two 2^(e-15) with |v| < 2^e for every v of the block (maximum m), and
+// its reciprocal; q = rint(v * inv) lies in [-32768, 32768] and the pack saturates.  m = 0 or denormal: scale 2^-126.
+__device__ __forceinline__ void block_scale_i16(float m, float& scale, float& inv) {
+    int E = (__builtin_bit_cast(int, m) >> 23) & 255;              // m in [2^(E-127), 2^(E-126))
+    E = (E < 15) ? 15 : E;
+    scale = __builtin_bit_cast(float, (E - 14) << 23);             // 2^(E - 141)
+    inv = __builtin_bit_cast(float, (268 - E) << 23);              // 2^(141 - E)
+}
+typedef short ocean_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_i16x2(c32 v, float inv) {
+    const ocean_s2 p = __builtin_amdgcn_cvt_pk_i16((int)rintf(v.x * inv), (int)rintf(v.y * inv));   // saturating
+    return __builtin_bit_cast(uint32_t, p);
+}
+__device__ __forceinline__ c32 unpack_i16x2(uint32_t bits, float scale) {
+    return mk((float)(short)(bits & 0xFFFFu), (float)((int)bits >> 16)) * scale;
+}
+
 // Static issue priority of this wave (s_setprio, 0..3; wave-uniform argument).  The waves of a workgroup that share
 // a SIMD otherwise move through every barrier-separated phase together (all in VALU, then all in their LDS stores);
 // distinct priorities serialise their VALU phases so that one wave's LDS traffic runs under the others' arithmetic.

@@ -1341,10 +1341,18 @@ __device__ __forceinline__ void half_load_AB_pairs_handover(const void* __restri
 // threads that read the lines out of LDS for the chunk stores.  Replaces a leading radix-2 pass with its own
 // LDS exchange and barriers (run 16: FFT phases 14 / 10 / 13 us per field at 8192 against 6 / 6 / 7.5 for the
 // same amount of data at 4096).
-template <int N, int E, int P, bool H16, bool HAND = false>
+// I16 (opt-in precision mode, SURVEY 8d "B_frame16"; ocean_set_intermediate): the intermediate is stored as int16 (re, im)
+// pairs -- 4 bytes per element at the SAME element offsets -- with one power-of-two scale per wave store, i.e. per block
+// of 64 rows x 2 columns (rows k .. k+63 and their partners k+N/2 ..), kept in a side array
+//     inter_scale[(field * N/64 + row block) * N/4 + column pair].
+// The scale is the wave maximum of |re|, |im| (DPP reduction) rounded up to a power of two: values are exact multiples of
+// 2^(e-15).  Numerics (tools/inter16_numerics.py, N = 8192, fp16-quantised spectrum): 2.7-3.1e-5 normalised max against
+// the unquantised result, tolerance 1e-4.
+template <int N, int E, int P, bool H16, bool HAND = false, bool I16 = false>
 __global__ void __launch_bounds__((N / E) * P, pass1_waves_per_simd<E>((N / E) * P))
 k_half_pass1_split(const void* __restrict__ h0T, float descale, const float* __restrict__ omegaT, c32* __restrict__ inter,
-                   c32* nyq_spec, const c32* __restrict__ tw, InterLayout lay, float time, float domain_size, int x_group0) {
+                   c32* nyq_spec, const c32* __restrict__ tw, InterLayout lay, float time, float domain_size, int x_group0,
+                   float* __restrict__ inter_scale) {
     constexpr int M = N / 2;                                       // sub-transform length
     constexpr int TS = M / E;                                      // threads per sub-line
     constexpr int THREADS = 2 * P * TS;
@@ -1412,6 +1420,26 @@ k_half_pass1_split(const void* __restrict__ h0T, float descale, const float* __r
             const c32 lo0 = u0 + t0, hi0 = u0 - t0, lo1 = u1 + t1, hi1 = u1 - t1;
             float4* olo = reinterpret_cast<float4*>(dst + chunk_row_offset(lay, q * (THREADS / CR)));
             float4* ohi = reinterpret_cast<float4*>(dst + chunk_row_offset(lay, q * (THREADS / CR) + M / CR));
+            if constexpr (I16) {
+                // one scale for this wave's two store blocks (rows k .. k+63 and k+M ..: the same columns, the same
+                // magnitudes); the 8-byte row pieces go to the element offsets of the fp32 layout, 4 bytes per element
+                const c32 a0 = mk(fabsf(lo0.x), fabsf(lo0.y)), a1 = mk(fabsf(lo1.x), fabsf(lo1.y));
+                const c32 b0 = mk(fabsf(hi0.x), fabsf(hi0.y)), b1 = mk(fabsf(hi1.x), fabsf(hi1.y));
+                const float m = wave_max_nonneg(fmaxf(fmaxf(fmaxf(a0.x, a0.y), fmaxf(a1.x, a1.y)), fmaxf(fmaxf(b0.x, b0.y), fmaxf(b1.x, b1.y))));
+                float scale, inv;
+                block_scale_i16(m, scale, inv);
+                uint32_t* base32 = reinterpret_cast<uint32_t*>(inter);
+                uint2* qlo = reinterpret_cast<uint2*>(base32 + (reinterpret_cast<c32*>(olo) - inter));
+                uint2* qhi = reinterpret_cast<uint2*>(base32 + (reinterpret_cast<c32*>(ohi) - inter));
+                *qlo = make_uint2(pack_i16x2(lo0, inv), pack_i16x2(lo1, inv));
+                *qhi = make_uint2(pack_i16x2(hi0, inv), pack_i16x2(hi1, inv));
+                if ((tf & 63) == 0) {                              // one lane per wave: the two blocks' entries
+                    float* sc = inter_scale + ((size_t)f * (N / 64) + (size_t)(k >> 6)) * (N / 4) + Xg;
+                    sc[0] = scale;
+                    sc[(size_t)(M / 64) * (N / 4)] = scale;
+                }
+                continue;
+            }
 #ifdef OCEAN_X_INTER16   // timing experiment only (wrong results): the access pattern of a 16-bit intermediate -- every
                          // element offset halved (4-byte complex numbers), 8 bytes per lane -- without its arithmetic: an
                          // upper bound on what SURVEY 8d's B_frame16 can buy at N = 8192
@@ -1626,9 +1654,11 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
 // Pass 2 for the split geometry (N = 8192): the row is rebuilt in LDS as two interleaved half-length lines
 // (C[2m] and C[2m+1]), each transformed by N/(2E) threads in three passes, and the final radix-2 step is done by
 // the thread that owns outputs n and n + N/2 in the epilogue (see k_half_pass1_split).  One row per workgroup.
-template <int N, int E, int P1, int GRP = 1, bool SHARD = false>
+template <int N, int E, int P1, int GRP = 1, bool SHARD = false, bool I16 = false>
 __global__ void __launch_bounds__(N / E, ((N / E) >= 512) ? 2 : 1)
-k_half_pass2_split(const c32* __restrict__ inter, float4* __restrict__ out, const c32* __restrict__ tw, InterLayout lay) {
+k_half_pass2_split(const c32* __restrict__ inter, float4* __restrict__ out, const c32* __restrict__ tw, InterLayout lay,
+                   const float* __restrict__ inter_scale) {
+    static_assert(!(SHARD && I16), "the 16-bit intermediate is not combined with the sharded tile");
     constexpr int M = N / 2;
     constexpr int T = N / E;                                       // threads per row
     constexpr int TS = M / E;                                      // threads per sub-line
@@ -1666,6 +1696,20 @@ k_half_pass2_split(const c32* __restrict__ inter, float4* __restrict__ out, cons
                 const size_t o = offy + tile_slab_offset(lay, Xc);
                 if (pass == 0) a[e] = inter[(size_t)1 * lay.fs + o];
                 else { a[e] = inter[o]; b[e] = inter[(size_t)2 * lay.fs + o]; }
+            }
+        } else if constexpr (I16) {
+            // int16 pairs at the fp32 layout's element offsets; the scale of (row block y / 64, column pair kx / 2)
+            const uint32_t* b32 = reinterpret_cast<const uint32_t*>(inter) + off;
+            const float* sc = inter_scale + (size_t)(y >> 6) * (N / 4) + (tf >> 1);
+            constexpr size_t SF = (size_t)(N / 64) * (N / 4);      // one field's scales
+#pragma unroll
+            for (int e = 0; e < EH; ++e) {
+                const size_t o = (size_t)e * (T / P1) * lay.sx;
+                if (pass == 0) a[e] = unpack_i16x2(b32[(size_t)1 * lay.fs + o], sc[SF + e * (T / 2)]);
+                else {
+                    a[e] = unpack_i16x2(b32[o], sc[e * (T / 2)]);
+                    b[e] = unpack_i16x2(b32[(size_t)2 * lay.fs + o], sc[2 * SF + e * (T / 2)]);
+                }
             }
         }
 #ifdef OCEAN_X_INTER16   // timing experiment only (wrong results): 4-byte elements at halved offsets (see k_half_pass1_split)

@@ -10,6 +10,7 @@ from ._lib import OCEAN_OK, OceanError, load_library
 from .fft import FIELD_ALL, FIELD_DX, FIELD_DY, FIELD_DZ, Fft
 
 QUIRK_Q1, QUIRK_Q2, QUIRKS_REFERENCE = 1, 2, 3      # include/ocean_hip.h OCEAN_QUIRK_*
+INTER_F32, INTER_BFP16 = 0, 1                         # include/ocean_hip.h OCEAN_INTER_*
 PACK_RGBA32F, PACK_RGB32F, PACK_HEIGHT32F = 0, 1, 2   # include/ocean_hip.h OCEAN_PACK_*
 PACK_BYTES_PER_TEXEL = {PACK_RGBA32F: 16, PACK_RGB32F: 12, PACK_HEIGHT32F: 4}
 from .ocean import DOMAIN_SIZE, Correction, CorrectionLocals, Propagation, PropagateLocals
@@ -89,6 +90,15 @@ class OceanDevice:
         """QUIRKS_REFERENCE (default) = the shipped shaders; clear QUIRK_Q1 for a signed wave index,
         QUIRK_Q2 for the conjugated (N+1-g) % N partner.  Non-reference settings run the staged kernels."""
         self._check(load_library().ocean_set_quirks(self._ctx, int(quirks)))
+
+    # -- precision of the intermediate (include/ocean_hip.h OCEAN_INTER_*) ------------------------------
+    def set_intermediate(self, mode: int):
+        """INTER_F32 (default) or INTER_BFP16: int16 intermediate with block scales, opt-in, N = 8192 (config 5)."""
+        self._check(load_library().ocean_set_intermediate(self._ctx, int(mode)))
+
+    @property
+    def intermediate(self) -> int:
+        return int(load_library().ocean_intermediate(self._ctx))
 
     # -- fused frame ---------------------------------------------------------------------------------
     def frame(self, time: float, domain_size: float = DOMAIN_SIZE, stream=None):

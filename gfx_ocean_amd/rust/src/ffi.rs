@@ -54,6 +54,8 @@ extern "C" {
     pub fn ocean_pack_displacement(ctx: *mut OceanContext, format: i32, device_out: *mut c_void, stream: *mut c_void) -> i32;
     pub fn ocean_set_quirks(ctx: *mut OceanContext, quirks: u32) -> i32;
     pub fn ocean_quirks(ctx: *const OceanContext) -> u32;
+    pub fn ocean_set_intermediate(ctx: *mut OceanContext, mode: i32) -> i32;
+    pub fn ocean_intermediate(ctx: *const OceanContext) -> i32;
     pub fn ocean_read_displacement(ctx: *mut OceanContext, host_rgba: *mut f32) -> i32;
     pub fn ocean_read_field(ctx: *mut OceanContext, field: i32, host_re_im: *mut f32) -> i32;
     pub fn ocean_write_field(ctx: *mut OceanContext, field: i32, host_re_im: *const f32) -> i32;

@@ -133,6 +133,16 @@ int32_t ocean_frame_ex(OceanContext* ctx, const OceanPropagateLocals* locals, vo
 int32_t ocean_set_quirks(OceanContext* ctx, uint32_t quirks);
 uint32_t ocean_quirks(const OceanContext* ctx);
 
+/* Precision of the intermediate between the two fused launches.  Default OCEAN_INTER_F32 (complex fp32, what every
+ * parity figure of this library refers to).  OCEAN_INTER_BFP16 is SURVEY 8d's "B_frame16" for BASELINE config 5: int16
+ * (re, im) mantissas with one power-of-two scale per block of 64 rows x 2 columns in a side array -- 12 instead of
+ * 24 B/texel through the intermediate; 2.7-3.1e-5 normalised max against the fp32 intermediate at N = 8192 (tolerance
+ * 1e-4; tools/inter16_numerics.py).  Opt-in, never the default; N = 8192 only (OCEAN_E_UNSUPPORTED_N otherwise). */
+#define OCEAN_INTER_F32 0
+#define OCEAN_INTER_BFP16 1
+int32_t ocean_set_intermediate(OceanContext* ctx, int32_t mode);
+int32_t ocean_intermediate(const OceanContext* ctx);
+
 /* the reference's normal field (shader/ocean.frag:50-66: finite differences of the
  * displacement map with Tile wrap, height_scale 180) as a compute pass over the current
  * displacement map.  source_channel 0 = disp_x (what the reference differentiates, quirk Q5),

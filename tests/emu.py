@@ -36,7 +36,7 @@ def lib():
         _LIB.emu_frame_pass2.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_size_t] * 3
         _LIB.emu_frame_pass2_thin.argtypes = _LIB.emu_frame_pass2.argtypes
         _LIB.emu_frame_half.argtypes = ([ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_float] + [ctypes.c_void_p] * 5 +
-                                        [ctypes.c_size_t] * 3 + [ctypes.c_int] + [ctypes.c_float] * 2)
+                                        [ctypes.c_size_t] * 3 + [ctypes.c_int] + [ctypes.c_float] * 2 + [ctypes.c_void_p])
         _LIB.emu_fft_lines.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         _LIB.emu_propagate.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_float] * 2 + [ctypes.c_uint32]
         _LIB.emu_correct.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4
@@ -164,8 +164,10 @@ def quantize_f16(h0):
     return (bits[..., 0] | (bits[..., 1] << 16)).astype(np.uint32), deq, s
 
 
-def frame_half(h0, omega, time, L=1000.0, layout="p2", return_inter=False, spectrum_fp16=False, P=None, split=False, bshift=None):
-    """split=True: every line as two interleaved N/2 transforms (the N = 8192 geometry, P = 2)."""
+def frame_half(h0, omega, time, L=1000.0, layout="p2", return_inter=False, spectrum_fp16=False, P=None, split=False, bshift=None,
+               inter16=False):
+    """split=True: every line as two interleaved N/2 transforms (the N = 8192 geometry, P = 2); inter16=True (split only):
+    the 16-bit block-floating intermediate (OCEAN_INTER_BFP16)."""
     n = h0.shape[0]
     P = 2 if split else (P or lib().emu_frame_p(n))
     descale = 1.0
@@ -181,8 +183,10 @@ def frame_half(h0, omega, time, L=1000.0, layout="p2", return_inter=False, spect
     nyq = np.full(6 * n, np.nan, np.float32)           # scratch: the Nyquist column's three spectra
     out = np.full((n, n, 4), np.nan, np.float32)
     tw = twiddles(n)
-    assert lib().emu_frame_half(n, 22 if split else int(P), _p(h0T), int(spectrum_fp16), descale, _p(omT), _p(inter), _p(nyq), _p(out), _p(tw),
-                                sx, sy, fs, bshift, time, L) == 0
+    assert split or not inter16
+    scales = np.full(3 * (n // 64) * (n // 4), np.nan, np.float32) if inter16 else None
+    assert lib().emu_frame_half(n, (23 if inter16 else 22) if split else int(P), _p(h0T), int(spectrum_fp16), descale, _p(omT), _p(inter),
+                                _p(nyq), _p(out), _p(tw), sx, sy, fs, bshift, time, L, _p(scales) if inter16 else None) == 0
     if return_inter:
         return out, inter, nyq, (P, (sx, sy, fs, bshift))
     return out

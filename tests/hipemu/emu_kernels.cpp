@@ -16,7 +16,7 @@ emu_dim3 gridDim;
 static std::barrier<>* g_barrier = nullptr;
 void __syncthreads() { g_barrier->arrive_and_wait(); }
 
-namespace ocean { alignas(16) unsigned char smem[160 * 1024]; }
+namespace ocean { alignas(16) unsigned char smem[160 * 1024]; float g_emu_wave_scratch[16][64]; }
 
 #include "ocean_kernels.hpp"
 
@@ -83,22 +83,24 @@ template <int N, int PSEL> static int run_half_p(const void* h0T, int f16, float
                [&] { k_half_pass2<N, G::E2, CHUNK_W, G::R2h, G::p2_group, G::ppar>(inter, out, tw, lay); });
     return 0;
 }
-template <int N> static int run_half_split(const void* h0T, int f16, float descale, const float* omT, c32* inter, c32* nyq,
-                                           float4* out, const c32* tw, InterLayout lay, float time, float L) {
+template <int N, bool I16> static int run_half_split(const void* h0T, int f16, float descale, const float* omT, c32* inter, c32* nyq,
+                                                     float4* out, const c32* tw, InterLayout lay, float time, float L, float* scales) {
     using G = Geo<N, 2>;
     static_assert(G::can_split, "split geometry");
     if (f16) emu_launch(G::half_grid1, G::split_threads1,
-                        [&] { k_half_pass1_split<N, G::E1S, G::P, true, G::handover>(h0T, descale, omT, inter, nyq, tw, lay, time, L, 0); });
+                        [&] { k_half_pass1_split<N, G::E1S, G::P, true, G::handover, I16>(h0T, descale, omT, inter, nyq, tw, lay, time, L, 0, scales); });
     else emu_launch(G::half_grid1, G::split_threads1,
-                    [&] { k_half_pass1_split<N, G::E1S, G::P, false, G::handover>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L, 0); });
-    emu_launch(N, G::split_threads2, [&] { k_half_pass2_split<N, G::E, CHUNK_W, G::p2_group>(inter, out, tw, lay); });
+                    [&] { k_half_pass1_split<N, G::E1S, G::P, false, G::handover, I16>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L, 0, scales); });
+    emu_launch(N, G::split_threads2, [&] { k_half_pass2_split<N, G::E, CHUNK_W, G::p2_group, false, I16>(inter, out, tw, lay, scales); });
     return 0;
 }
 template <int N> static int run_half(int psel, const void* h0T, int f16, float descale, const float* omT, c32* inter, c32* nyq,
-                                     float4* out, const c32* tw, InterLayout lay, float time, float L) {
-    if (psel == 22) {                                   // P = 2 with the split geometry
-        if constexpr (N >= 512) return run_half_split<N>(h0T, f16, descale, omT, inter, nyq, out, tw, lay, time, L);
-        else return -3;
+                                     float4* out, const c32* tw, InterLayout lay, float time, float L, float* scales) {
+    if (psel == 22 || psel == 23) {                     // P = 2 with the split geometry; 23: + the 16-bit intermediate
+        if constexpr (N >= 512) {
+            if (psel == 23) return scales ? run_half_split<N, true>(h0T, f16, descale, omT, inter, nyq, out, tw, lay, time, L, scales) : -6;
+            return run_half_split<N, false>(h0T, f16, descale, omT, inter, nyq, out, tw, lay, time, L, nullptr);
+        } else return -3;
     }
     if (psel == 2) return run_half_p<N, 2>(h0T, f16, descale, omT, inter, nyq, out, tw, lay, time, L);
     if (psel == 1) return run_half_p<N, 1>(h0T, f16, descale, omT, inter, nyq, out, tw, lay, time, L);
@@ -227,8 +229,8 @@ int emu_frame_pass2_thin(int n, const float* inter, float* out, const float* tw,
 #undef C_
 }
 int emu_frame_half(int n, int psel, const void* h0T, int f16, float descale, const float* omT, float* inter, c32* nyq, float* out,
-                   const float* tw, size_t sx, size_t sy, size_t fs, int bshift, float time, float L) {
-#define C_(N) run_half<N>(psel, h0T, f16, descale, omT, (c32*)inter, (c32*)nyq, (float4*)out, (const c32*)tw, InterLayout{sx, sy, fs, bshift}, time, L)
+                   const float* tw, size_t sx, size_t sy, size_t fs, int bshift, float time, float L, float* scales) {
+#define C_(N) run_half<N>(psel, h0T, f16, descale, omT, (c32*)inter, (c32*)nyq, (float4*)out, (const c32*)tw, InterLayout{sx, sy, fs, bshift}, time, L, scales)
     DISPATCH(n, C_)
 #undef C_
 }

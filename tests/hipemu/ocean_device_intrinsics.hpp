@@ -42,5 +42,33 @@ static inline float load_float_nt(const float* p) { return *p; }
 static inline int opaque_after(int x, float) { return x; }
 template <int T> static inline void line_sync() { __syncthreads(); }   // host threads are not a wave: always the full barrier
 static inline void workgroup_publish() { __syncthreads(); }       // the emulation's barrier is a full fence
+// 16-bit block-floating intermediate: the wave reduction through a scratch array and two barriers (every thread of the
+// workgroup calls it, uniformly); pack / unpack as the device's (round to nearest even, saturate).
+extern float g_emu_wave_scratch[16][64];
+static inline float wave_max_nonneg(float v) {
+    const unsigned w = threadIdx.x / 64, lane = threadIdx.x % 64;
+    g_emu_wave_scratch[w][lane] = v;
+    __syncthreads();
+    float m = 0.0f;
+    const unsigned live = (blockDim.x - w * 64 < 64) ? (blockDim.x - w * 64) : 64;
+    for (unsigned i = 0; i < live; ++i) m = std::fmax(m, g_emu_wave_scratch[w][i]);
+    __syncthreads();
+    return m;
+}
+static inline void block_scale_i16(float m, float& scale, float& inv) {
+    int e;
+    std::frexp(m, &e);                                            // m = f * 2^e, f in [0.5, 1): m < 2^e
+    int E = (m > 0.0f) ? e + 126 : 0;
+    E = (E < 15) ? 15 : E;
+    scale = std::ldexp(1.0f, E - 141);
+    inv = std::ldexp(1.0f, 141 - E);
+}
+static inline uint32_t pack_i16x2(c32 v, float inv) {
+    auto q = [](float x) { const float r = std::nearbyint(x); return (int)(r > 32767.0f ? 32767.0f : (r < -32768.0f ? -32768.0f : r)); };
+    return ((uint32_t)(uint16_t)(int16_t)q(v.x * inv)) | ((uint32_t)(uint16_t)(int16_t)q(v.y * inv) << 16);
+}
+static inline c32 unpack_i16x2(uint32_t bits, float scale) {
+    return mk((float)(int16_t)(bits & 0xFFFFu), (float)(int16_t)(bits >> 16)) * scale;
+}
 }  // namespace ocean
 #define OCEAN_TL(k)

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 import emu
+import gfx_ocean_amd as g
 from conftest import assert_parity
 from oracle import ocean_oracle as oc
 
@@ -269,3 +270,18 @@ print("HANDOVER_EMU_OK")
     env = dict(os.environ, OCEAN_EMU_FLAGS="-DOCEAN_HANDOVER_MIN_N=256")
     p = subprocess.run([sys.executable, "-c", code, root], capture_output=True, text=True, timeout=1500, env=env)
     assert p.returncode == 0 and "HANDOVER_EMU_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
+@pytest.mark.parametrize("n", [512, 1024])
+def test_emu_bfp16_intermediate(n, ref_inputs):
+    """The opt-in 16-bit block-floating intermediate (OCEAN_INTER_BFP16; split kernels): int16 mantissas, one power-of-two
+    scale per wave store.  Against the fp32-intermediate frame the error is the quantisation's (a few 1e-5 normalised max,
+    tolerance 1e-4), and it is really different from it (not silently the fp32 path)."""
+    h0, om = ref_inputs if n == 512 else g.synth.make_inputs(n, seed=8)
+    ref = oc.frame_f64(h0, om, 2.5)[..., :3]
+    out32 = emu.frame_half(h0, om, 2.5, split=True)[..., :3]
+    out16 = emu.frame_half(h0, om, 2.5, split=True, inter16=True)[..., :3]
+    assert not np.isnan(out16).any()
+    nmax, rl2 = assert_parity(out16, ref, 1e-4, f"bfp16 intermediate n={n}")
+    assert nmax.max() < 6e-5
+    assert oc.parity_errors(out16, out32)[0].max() > 2e-6             # quantised: not the fp32 intermediate

@@ -524,3 +524,51 @@ def test_stale_stage_handle_of_a_reused_context_address_is_rejected():
             g.load_library().ocean_propagation_destroy(raw)
             p._h = None
     # (address reuse is up to the allocator; the call is rejected either way)
+
+
+@pytest.mark.parametrize("f16", [True, False])
+def test_config5_bfp16_intermediate_8192(f16):
+    """SURVEY 8d "B_frame16" as an opt-in precision mode (ocean_set_intermediate(OCEAN_INTER_BFP16), N = 8192): int16
+    intermediate with one power-of-two scale per 64 x 2 block.  EVERY texel against the C restatement of the shaders fed
+    the spectrum the kernels use: within the 1e-4 tolerance (expected 3-4e-5: tools/inter16_numerics.py), really
+    different from the fp32 intermediate, and switchable back bit for bit."""
+    n, t = 8192, 1.25
+    h0, om = g.synth.make_inputs(n)
+    d = g.OceanDevice(n)
+    try:
+        d.upload_spectrum(h0, om, spectrum_fp16=f16)
+        src = d.read_spectrum() if f16 else h0
+        d.frame(t)
+        c32 = d.checksum()
+        ref32 = d.read_displacement()
+        assert d.intermediate == g.INTER_F32
+        d.set_intermediate(g.INTER_BFP16)
+        assert d.intermediate == g.INTER_BFP16
+        d.frame(t)
+        out = d.read_displacement()
+        cc.set_threads(min(32, cc.max_threads()))
+        refc = cc.FrameRunner(src, om).frame(t)
+        nmax, rl2 = assert_parity(out[..., :3], refc[..., :3], TOL, "bfp16 intermediate vs C oracle")
+        assert nmax.max() < 6e-5 and np.all(out[..., 3] == 0.0)
+        q = oc.parity_errors(out[..., :3], ref32[..., :3])[0].max()
+        assert 5e-6 < q < 6e-5                                       # the quantisation is real, and small
+        d.frame(t)
+        assert np.array_equal(out, d.read_displacement())             # reproducible
+        d.set_intermediate(g.INTER_F32)
+        d.frame(t)
+        assert d.checksum() == c32                                     # and the default comes back bit for bit
+    finally:
+        d.destroy()
+
+
+def test_bfp16_intermediate_is_8192_only():
+    d = g.OceanDevice(4096)
+    try:
+        with pytest.raises(g.OceanError) as e:
+            d.set_intermediate(g.INTER_BFP16)
+        assert e.value.status == -2                                   # OCEAN_E_UNSUPPORTED_N
+        with pytest.raises(g.OceanError):
+            d.set_intermediate(7)
+        assert d.intermediate == g.INTER_F32
+    finally:
+        d.destroy()

@@ -34,6 +34,7 @@ def main():
     d, n, run = sys.argv[1], int(sys.argv[2]), sys.argv[3]
     f16 = "f16" in sys.argv[4:]
     staged = "staged" in sys.argv[4:]
+    bfp16 = "bfp16" in sys.argv[4:]
     fetch, write = counters(d, "FETCH_SIZE"), counters(d, "WRITE_SIZE")
     kernels = {}
     for k in sorted(set(fetch) & set(write)):
@@ -43,8 +44,8 @@ def main():
                       "WRITE_SIZE_KB": round(write[k][0], 1), "hbm_bytes": (2.0 * fetch[k][0] + write[k][0]) * 1024.0}
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of the bench command, average per dispatch; "
                      "gfx950 correction hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (tools/make_hbm_traffic.py)",
-           "run": run, "n": n, "spectrum": "f16" if f16 else "f32", "kernels": kernels}
-    name = f"hbm_traffic_{'staged_' if staged else ''}n{n}{'_f16' if f16 else ''}.json"
+           "run": run, "n": n, "spectrum": "f16" if f16 else "f32", "intermediate": "bfp16" if bfp16 else "f32", "kernels": kernels}
+    name = f"hbm_traffic_{'staged_' if staged else ''}n{n}{'_f16' if f16 else ''}{'_bfp16' if bfp16 else ''}.json"
     with open(os.path.join(ROOT, "profiles", name), "w") as f:
         json.dump(out, f, indent=1)
     print(name, {k: round(v["hbm_bytes"] / 1e6, 1) for k, v in kernels.items()})
