@@ -141,6 +141,9 @@ def test_committed_bench_lines_carry_the_contract_fields():
         n, spec = r["config"]["n"], r["config"].get("spectrum", "f32")
         dom = [k for k in ro["kernels"] if k["name"] == ro["kernel"]][0]
         moved = bench.MOVED_BYTES_PER_TEXEL[spec][bench.pass_of(dom["name"])] * n * n
+        if r["config"].get("intermediate", "f32") == "bfp16":        # the opt-in 16-bit intermediate: 6 B/texel less per side
+            moved -= bench.INTER16_SAVING * n * n
+            assert "OPT-IN PRECISION MODE" in r["config"]["workload"]
         assert abs(dom["algorithmic_bytes"] - moved) < 1 and abs(ro["achieved"] - moved / dom["avg_ms"] / 1e6) < 1e-6 * ro["achieved"]
         assert ro["contract_frac"] > ro["frac"]                      # the 76-byte accounting is reported, but not as `achieved`
         assert 0.0 < ro["frac"] < 0.79                               # nothing above the part's measured copy ceiling (6.29 TB/s)
