@@ -148,7 +148,8 @@ def test_committed_bench_lines_carry_the_contract_fields():
         assert ro["contract_frac"] > ro["frac"]                      # the 76-byte accounting is reported, but not as `achieved`
         assert 0.0 < ro["frac"] < 0.79                               # nothing above the part's measured copy ceiling (6.29 TB/s)
         if os.path.basename(path).startswith("r03"):                # round 3: where the traffic figure comes from, and the real warm-up
-            assert ro["traffic_source"]["file"].startswith("profiles/hbm_traffic_n") and "NOT measured in this run" in ro["traffic_source"]["method"]
+            if ro["traffic"] is not None:                             # (null = no committed PMC pass for this variant yet)
+                assert ro["traffic_source"]["file"].startswith("profiles/hbm_traffic_n") and "NOT measured in this run" in ro["traffic_source"]["method"]
             assert r["config"]["effective_warmup_frames"] >= r["warmup"]
         if "cpu_baseline" in r:
             for k in ("value", "unit", "cores", "kind", "sample"):
