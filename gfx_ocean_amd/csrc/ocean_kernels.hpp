@@ -1683,6 +1683,38 @@ k_half_pass2_split(const c32* __restrict__ inter, float4* __restrict__ out, cons
 
     float keep_lo[EH], keep_hi[EH];
     OCEAN_TL(0);
+    // The (disp_x, disp_z) loads are issued before the height transform (all three fields in flight at once): with two
+    // 512-thread workgroups per CU the gather is short of requests in flight, not of L2 -- pass 2 462-470 -> 426-429 us,
+    // 1084-1098 -> 1148-1149 frames/s at N = 8192 (r03_run21; the same idea costs 2-3 us at 4096, where four workgroups
+    // per CU already fill the queues: k_half_pass2).  A/B knob: -DOCEAN_P2S_PREFETCH=0.
+#ifdef OCEAN_P2S_PREFETCH
+    constexpr bool PREFETCH = (OCEAN_P2S_PREFETCH != 0);
+#else
+    constexpr bool PREFETCH = true;
+#endif
+    c32 pre_x[EH], pre_z[EH];                                      // (I16: the raw int16 pairs in .x, their scales in .y)
+    if constexpr (PREFETCH) {
+        const size_t offy0 = chunk_row_offset(lay, y / CR) + (y % CR) * P1 + (tid % P1);
+#pragma unroll
+        for (int e = 0; e < EH; ++e) {
+            const int Xc = tid / P1 + e * (T / P1);
+            if constexpr (SHARD) {
+                const size_t o = offy0 + tile_slab_offset(lay, Xc);
+                pre_x[e] = inter[o];
+                pre_z[e] = inter[(size_t)2 * lay.fs + o];
+            } else if constexpr (I16) {
+                const uint32_t* b32 = reinterpret_cast<const uint32_t*>(inter) + offy0 + (size_t)Xc * lay.sx;
+                const float* sc = inter_scale + (size_t)(y >> 6) * (N / 4) + (tid >> 1) + e * (T / 2);
+                constexpr size_t SF = (size_t)(N / 64) * (N / 4);
+                pre_x[e] = mk(__builtin_bit_cast(float, b32[0]), sc[0]);
+                pre_z[e] = mk(__builtin_bit_cast(float, b32[(size_t)2 * lay.fs]), sc[2 * SF]);
+            } else {
+                const size_t o = offy0 + (size_t)Xc * lay.sx;
+                pre_x[e] = inter[o];
+                pre_z[e] = inter[(size_t)2 * lay.fs + o];
+            }
+        }
+    }
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {                         // 0: height, 1: (disp_x, disp_z)
         const int tf = opaque_lane(tid);                           // loads: kx = tf + e*T, e < E/2
@@ -1695,6 +1727,7 @@ k_half_pass2_split(const c32* __restrict__ inter, float4* __restrict__ out, cons
                 const int Xc = tf / P1 + e * (T / P1);
                 const size_t o = offy + tile_slab_offset(lay, Xc);
                 if (pass == 0) a[e] = inter[(size_t)1 * lay.fs + o];
+                else if constexpr (PREFETCH) { a[e] = pre_x[e]; b[e] = pre_z[e]; }
                 else { a[e] = inter[o]; b[e] = inter[(size_t)2 * lay.fs + o]; }
             }
         } else if constexpr (I16) {
@@ -1706,7 +1739,10 @@ k_half_pass2_split(const c32* __restrict__ inter, float4* __restrict__ out, cons
             for (int e = 0; e < EH; ++e) {
                 const size_t o = (size_t)e * (T / P1) * lay.sx;
                 if (pass == 0) a[e] = unpack_i16x2(b32[(size_t)1 * lay.fs + o], sc[SF + e * (T / 2)]);
-                else {
+                else if constexpr (PREFETCH) {
+                    a[e] = unpack_i16x2(__builtin_bit_cast(uint32_t, pre_x[e].x), pre_x[e].y);
+                    b[e] = unpack_i16x2(__builtin_bit_cast(uint32_t, pre_z[e].x), pre_z[e].y);
+                } else {
                     a[e] = unpack_i16x2(b32[o], sc[e * (T / 2)]);
                     b[e] = unpack_i16x2(b32[(size_t)2 * lay.fs + o], sc[2 * SF + e * (T / 2)]);
                 }
@@ -1731,6 +1767,9 @@ k_half_pass2_split(const c32* __restrict__ inter, float4* __restrict__ out, cons
             const c32* src = inter + (size_t)1 * lay.fs + off;
 #pragma unroll
             for (int e = 0; e < EH; ++e) a[e] = src[(size_t)e * (T / P1) * lay.sx];
+        } else if constexpr (PREFETCH) {
+#pragma unroll
+            for (int e = 0; e < EH; ++e) { a[e] = pre_x[e]; b[e] = pre_z[e]; }
         } else {
             const c32* sx_ = inter + off;
             const c32* sz_ = inter + (size_t)2 * lay.fs + off;
