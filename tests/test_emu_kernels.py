@@ -272,7 +272,7 @@ print("HANDOVER_EMU_OK")
     assert p.returncode == 0 and "HANDOVER_EMU_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
-@pytest.mark.parametrize("n", [512, 1024])
+@pytest.mark.parametrize("n", [512])
 def test_emu_bfp16_intermediate(n, ref_inputs):
     """The opt-in 16-bit block-floating intermediate (OCEAN_INTER_BFP16; split kernels): int16 mantissas, one power-of-two
     scale per wave store.  Against the fp32-intermediate frame the error is the quantisation's (a few 1e-5 normalised max,

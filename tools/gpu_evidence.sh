@@ -18,6 +18,8 @@ for l in open("$O/sweep.jsonl"):
 PY
 echo "== bench (driver flags)"; timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 2>$O/bench.err | tee $O/bench.json | cut -c1-300
 echo "== bench config 5"; timeout 900 python bench.py --n 8192 --spectrum f16 --steps 20 --warmup 5 2>$O/bench_f16.err | tee $O/bench_n8192_f16.json | cut -c1-300
+echo "== bench config 5, opt-in 16-bit intermediate"; timeout 900 python bench.py --no-cpu-baseline --n 8192 --spectrum f16 --intermediate bfp16 --steps 20 --warmup 5 2>/dev/null | tee $O/bench_n8192_f16_bfp16.json | cut -c1-300
+echo "== bench config 2 (N = 512) and 3 (N = 2048)"; for n in 512 2048; do timeout 600 python bench.py --no-cpu-baseline --n $n --steps 200 --warmup 20 2>/dev/null | tee $O/bench_n$n.json | cut -c1-200; done
 cd /tmp
 run_prof() {   # name, N, traffic flag ("-", f16 or staged), then the command
   local name=$1 n=$2 flag=$3; shift 3
@@ -32,6 +34,7 @@ run_prof() {   # name, N, traffic flag ("-", f16 or staged), then the command
 }
 run_prof fused_n4096 4096 - python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 200 --warmup 5 --profile-frames 5
 run_prof fused_n8192_f16 8192 f16 python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --n 8192 --spectrum f16 --steps 60 --warmup 2 --profile-frames 2
+run_prof fused_n8192_f16_bfp16 8192 "f16 bfp16" python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --n 8192 --spectrum f16 --intermediate bfp16 --steps 60 --warmup 2 --profile-frames 2
 run_prof staged_n4096 4096 staged python $GRAFT_REPO_ROOT/tools/staged_frames.py 4096 10
 for N in 512 2048 8192; do
   run_prof fused_n$N $N - python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --n $N --steps 100 --warmup 5 --profile-frames 3
