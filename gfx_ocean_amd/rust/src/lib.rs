@@ -27,6 +27,9 @@ use std::ptr;
 pub const QUIRK_Q1_UINT_WAVE_INDEX: u32 = 1;
 pub const QUIRK_Q2_MIRROR_NO_CONJ: u32 = 2;
 pub const QUIRKS_REFERENCE: u32 = 3;
+/// Precision of the intermediate (include/ocean_hip.h `OCEAN_INTER_*`).
+pub const INTER_F32: i32 = 0;
+pub const INTER_BFP16: i32 = 1;
 
 #[derive(Debug)]
 pub struct OceanError { pub status: i32, pub message: String }
@@ -81,6 +84,28 @@ impl Device {
                 "read_displacement: expected a slice of {} floats, got {}", want, rgba.len()) }));
         }
         self.check(unsafe { ffi::ocean_read_displacement(self.ctx, rgba.as_mut_ptr()) })
+    }
+    /// Opt-in precision of the intermediate between the two fused launches: `INTER_F32` (default) or `INTER_BFP16`
+    /// (int16 mantissas + block scales, N = 8192; include/ocean_hip.h `OCEAN_INTER_*`).
+    pub fn set_intermediate(&self, mode: i32) -> Result<(), Box<dyn Error>> {
+        self.check(unsafe { ffi::ocean_set_intermediate(self.ctx, mode) })
+    }
+    /// Order-independent 64-bit checksum of the current displacement map, computed on the device.
+    pub fn checksum(&self) -> Result<u64, Box<dyn Error>> {
+        let mut sum = 0u64;
+        self.check(unsafe { ffi::ocean_checksum_displacement(self.ctx, ptr::null_mut(), &mut sum) })?;
+        Ok(sum)
+    }
+    /// One tile over several GPUs (fused scheme): pass 1 of piece `part` of `parts` of rank `rank`'s half-spectrum columns
+    /// into the caller's device send buffer, and pass 2 of its rows from the receive buffer (see include/ocean_hip.h).
+    /// The pointers are device addresses owned by the caller (e.g. RCCL buffers): hence `unsafe`.
+    pub unsafe fn tile_pass1(&self, locals: &ocean::PropagateLocals, rank: i32, world: i32, part: i32, parts: i32,
+                             send_part_device: *mut std::ffi::c_void, stream: *mut std::ffi::c_void) -> Result<(), Box<dyn Error>> {
+        self.check(ffi::ocean_tile_pass1(self.ctx, locals, rank, world, part, parts, send_part_device, stream))
+    }
+    pub unsafe fn tile_pass2(&self, rank: i32, world: i32, parts: i32, recv_device: *const std::ffi::c_void,
+                             out_rows_device: *mut std::ffi::c_void, stream: *mut std::ffi::c_void) -> Result<(), Box<dyn Error>> {
+        self.check(ffi::ocean_tile_pass2(self.ctx, rank, world, parts, recv_device, out_rows_device, stream))
     }
     pub fn raw(&self) -> *mut ffi::OceanContext { self.ctx }
 }

@@ -72,6 +72,17 @@ int main(int argc, char** argv) {
     if (ocean_frame((OceanContext*)0, 0.0f, (void*)0) != OCEAN_E_INVALID_ARG) return 15;
     if (ocean_set_quirks((OceanContext*)0, OCEAN_QUIRKS_REFERENCE) != OCEAN_E_INVALID_ARG) return 16;
     if (ocean_quirks((const OceanContext*)0) != 0u) return 17;
+    {   /* round 3's entry points: NULL handles are rejected, never dereferenced */
+        uint64_t sum = 0;
+        if (ocean_checksum_displacement((OceanContext*)0, (void*)0, &sum) != OCEAN_E_INVALID_ARG) return 30;
+        if (ocean_pack_displacement((OceanContext*)0, OCEAN_PACK_RGB32F, (void*)16, (void*)0) != OCEAN_E_INVALID_ARG) return 31;
+        if (ocean_packed_bytes((const OceanContext*)0, OCEAN_PACK_HEIGHT32F) != OCEAN_E_INVALID_ARG) return 32;
+        if (ocean_set_intermediate((OceanContext*)0, OCEAN_INTER_BFP16) != OCEAN_E_INVALID_ARG) return 33;
+        if (ocean_intermediate((const OceanContext*)0) != OCEAN_E_INVALID_ARG) return 34;
+        if (ocean_tile_exchange_bytes((const OceanContext*)0, 2) != OCEAN_E_INVALID_ARG) return 35;
+        if (ocean_tile_pass1((OceanContext*)0, &pl, 0, 2, 0, 1, (void*)16, (void*)0) != OCEAN_E_INVALID_ARG) return 36;
+        if (ocean_tile_pass2((OceanContext*)0, 0, 2, 1, (const void*)16, (void*)16, (void*)0) != OCEAN_E_INVALID_ARG) return 37;
+    }
     ocean_context_destroy((OceanContext*)0);
     if (argc >= 4) return gpu_frame(argv[1], argv[2], argv[3]);
     st = ocean_context_create(0, 512, &ctx);               /* no GPU in the CPU tier: must fail, not crash */
