@@ -186,6 +186,8 @@ template <int N> struct Launch {
     static constexpr int default_psel() { return (N <= 1024) ? OCEAN_P_SMALL : ((N == 2048 || N > 4096 || CHUNK_W < 4) ? 2 : 4); }
 #elif defined(OCEAN_P_2048)                                            // A/B knob: lines per pass-1 workgroup at N = 2048
     static constexpr int default_psel() { return (N == 2048) ? OCEAN_P_2048 : ((N == 512 || N > 4096 || CHUNK_W < 4) ? 2 : 4); }
+#elif defined(OCEAN_P_1024)                                            // A/B knob: lines per pass-1 workgroup at N = 1024
+    static constexpr int default_psel() { return (N == 512) ? 1 : ((N == 1024) ? OCEAN_P_1024 : ((N <= 2048 || N > 4096 || CHUNK_W < 4) ? 2 : 4)); }
 #else
     static constexpr int default_psel() { return (N == 512) ? 1 : ((N <= 2048 || N > 4096 || CHUNK_W < 4) ? 2 : 4); }
 #endif
