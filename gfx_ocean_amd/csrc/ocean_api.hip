@@ -270,12 +270,17 @@ template <int N> struct Launch {
             }
         }
         if constexpr (plain_built<PSEL>()) {
+#ifdef OCEAN_PASS1_ITERS
+            constexpr int GRID1 = (N == 4096 && !H::fpar && !H::handover) ? H::half_grid1 / OCEAN_PASS1_ITERS : H::half_grid1;
+#else
+            constexpr int GRID1 = H::half_grid1;
+#endif
             if (c->h0_f16)
-                launch(k_half_pass1<N, H::E1, H::P, true, H::handover, H::fpar>, dim3(H::half_grid1), dim3(H::half_threads1), H::half_lds1, s, t,
+                launch(k_half_pass1<N, H::E1, H::P, true, H::handover, H::fpar>, dim3(GRID1), dim3(H::half_threads1), H::half_lds1, s, t,
                        (const void*)c->h0T, descale, (const float*)c->omegaT, c->inter, c->nyq, (const c32*)c->tw,
                        c->lay_h, time, domain, 0);
             else
-                launch(k_half_pass1<N, H::E1, H::P, false, H::handover, H::fpar>, dim3(H::half_grid1), dim3(H::half_threads1), H::half_lds1, s, t,
+                launch(k_half_pass1<N, H::E1, H::P, false, H::handover, H::fpar>, dim3(GRID1), dim3(H::half_threads1), H::half_lds1, s, t,
                        (const void*)c->h0T, 1.0f, (const float*)c->omegaT, c->inter, c->nyq, (const c32*)c->tw,
                        c->lay_h, time, domain, 0);
         }

@@ -1007,10 +1007,20 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
     c32* lds_line = lds_grp + c * LinePitch<N>::elems;
     const float kscale = OCEAN_PI_F / domain_size;
 
+    // A/B knob OCEAN_PASS1_ITERS (N = 4096 only): a persistent workgroup transforms that many column groups one after the
+    // other (grid / ITERS workgroups) instead of leaving the second dispatch round to the hardware.
+#ifdef OCEAN_PASS1_ITERS
+    constexpr int ITERS = (N == 4096 && !FPAR && !HAND) ? OCEAN_PASS1_ITERS : 1;
+#pragma unroll 1
+    for (int it = 0; it < ITERS; ++it) {
+#else
+    constexpr int ITERS = 1, it = 0;                               // (no loop in the product build: its mere presence moves the register allocation)
+    {
+#endif
     // X: the workgroup's column group within this launch (= within the intermediate it writes); Xg: within the tile.
     // They differ only when the tile is sharded over several GPUs and this rank transforms the column groups
     // [x_group0, x_group0 + gridDim.x) (ocean_tile_pass1).
-    const int X = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+    const int X = xcd_contiguous((int)blockIdx.x + it * (int)gridDim.x, (int)gridDim.x * ITERS);
     const int Xg = X + x_group0;
     if (Xg == 0) nyquist_spectra<N, H16, GT * (FPAR ? 3 : 1)>(h0T, descale, omegaT, nyq_spec, tid, time, kscale);   // uniform branch
 #ifdef OCEAN_SETPRIO
@@ -1116,6 +1126,8 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
             else *o = make_float4(v0.x, v0.y, v1.x, v1.y);        // half a chunk row: must meet its other half in L2
         }
         OCEAN_TL(3 + 2 * (FPAR ? f : ff));
+    }
+    if (ITERS > 1) __syncthreads();                               // the next group's transforms reuse the line buffers
     }
 }
 
