@@ -1,20 +1,30 @@
-"""ONE N x N tile whose 2-D transform is sharded over the GPUs of a node (include/ocean_hip.h
-"sharded tile").  Independent tiles need no exchange (bench.py); this module is for a single tile that is
-too large or too slow for one GPU (N up to 16384).
+"""ONE N x N tile whose 2-D transform is sharded over the GPUs of a node (include/ocean_hip.h).
+Independent tiles need no exchange (bench.py); this module is for a single tile that is too large or too slow
+for one GPU.  Two schemes, both with ONE all-to-all where the reference has its barrier between the row and the column
+dispatches (src/render.rs:1181-1208):
 
-Decomposition = the reference's own dispatch order (src/render.rs:1122-1310): propagate and all row passes, a
-barrier, all column passes, correction -- with the barrier replaced by ONE all-to-all over xGMI:
+`FusedShardedTile` (N <= 8192, the one to use) -- the fused half-spectrum frame of `ocean_frame`, sharded:
+
+    rank r owns half-spectrum columns [r N/2R, ..)   fused pass 1 on them                  (ocean_tile_pass1)
+    all_to_all_single(recv, send)                     3 (N/2) (N/R) 8 bytes per rank: 12 B/texel in total; optionally cut
+                                                      into `parts` all-to-alls overlapped with pass 1 of the next part
+    rank r owns rows [r N/R, (r+1) N/R)               fused pass 2 on them                  (ocean_tile_pass2)
+
+  Result: the rank's ROW block in the natural orientation, ``out[y - r N/R, x] = (disp_x, height, disp_z, 0)``; 54 B/texel
+  of HBM traffic, bit-identical to `ocean_frame`.
+
+`ShardedTile` (N <= 16384; the only scheme for 16384) -- the reference's own dispatch order (src/render.rs:1122-1310):
 
     rank r owns rows [r N/R, (r+1) N/R)           propagate + row pass on them        (ocean_shard_rows)
     all_to_all_single(recv, send)                 3 N^2 8 / R bytes per rank and frame, (R-1)/R of it over xGMI
     rank r owns columns [r N/R, (r+1) N/R)        column pass + correction on them    (ocean_shard_cols)
 
-The result is distributed by COLUMN blocks and stored transposed: ``out[x - r N/R, y] = (disp_x, height, disp_z, 0)``.
+  Result: the rank's COLUMN block, transposed: ``out[x - r N/R, y]``; staged kernels, 220 B/texel of HBM traffic.
 
-`ShardedTile` drives a backend with three calls (upload / rows / cols).  The product backend is `HipShardBackend`
-(the C ABI on device memory, RCCL through torch.distributed); the tests plug in a backend that executes the same
-kernels on the CPU (tests/emu.py) under gloo.  There is no CPU fallback in the product: `HipShardBackend` raises
-OceanError without the HIP library or a GPU.
+The drivers work on a backend with a handful of calls.  The product backends are `HipTileBackend` / `HipShardBackend` (the
+C ABI on device memory, RCCL through torch.distributed); the tests plug in backends that execute the same kernels on the
+CPU (tests/emu.py) under gloo.  There is no CPU fallback in the product: the Hip backends raise OceanError without the
+HIP library or a GPU.
 """
 from __future__ import annotations
 
