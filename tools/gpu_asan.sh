@@ -13,17 +13,14 @@ echo "# xnack: $(/opt/rocm/bin/rocminfo 2>/dev/null | grep -i -m2 'xnack' | tr '
 HSA_XNACK=1 ASAN_OPTIONS=detect_leaks=0:halt_on_error=0:abort_on_error=0 LD_PRELOAD=$RT \
 OCEAN_HIP_LIB=$PWD/gfx_ocean_amd/variants/libocean_hip_asan.so timeout 420 python - <<'PY'
 import numpy as np, gfx_ocean_amd as g
-from oracle import ocean_oracle as oc
 print("library:", g.load_library()._name)
-for n in (256, 512, 1024, 2048):
+for n in (256, 512, 1024, 2048):                 # (a sanitizer run checks memory accesses, not values: fused against staged is enough)
     h0, om = g.synth.make_inputs(n, seed=n)
     r = g.OceanRenderer(n)
     r.upload(h0, om)
-    ref = oc.frame_f64(h0, om, 1.5)
-    for name, fn in (("fused", r.render_fused), ("staged", r.render)):
-        fn(1.5)
-        nmax, rl2 = oc.parity_errors(r.displacement()[..., :3], ref[..., :3])
-        print(f"N={n} {name}: normalised-max {nmax.max():.2e} rel-L2 {rl2.max():.2e}", flush=True)
+    r.render_fused(1.5); a = r.displacement()
+    r.render(1.5); b = r.displacement()
+    print(f"N={n}: fused vs staged max abs {np.abs(a - b).max():.2e}", flush=True)
     r.dispose()
 print("ASAN_RUN_COMPLETE")
 PY

@@ -4,7 +4,6 @@ a 20000-frame loop at N = 4096.  python tools/soak.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, gfx_ocean_amd as g
-from oracle import ocean_oracle as oc
 # create/destroy loop at several sizes (leaks, handle registry), long frame loop, result stability
 for rep in range(3):
     for n in (256, 512, 1024, 2048, 4096):
