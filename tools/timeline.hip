@@ -58,6 +58,24 @@ int main(int argc, char** argv) {
         const auto h1 = std::chrono::steady_clock::now();
         ocean_sync(ctx);
         const auto h2 = std::chrono::steady_clock::now();
+        {   // the same frame as a captured hipGraph (fixed time: a timing experiment): does a graph launch shorten the
+            // two launch boundaries of a frame?
+            hipGraph_t graph; hipGraphExec_t exec;
+            hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeGlobal);
+            ocean_frame(ctx, 0.5f, nullptr);
+            hipStreamEndCapture(ctx->stream, &graph);
+            hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            for (int i = 0; i < 50; ++i) hipGraphLaunch(exec, ctx->stream);
+            ocean_sync(ctx);
+            const auto g0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < K; ++i) hipGraphLaunch(exec, ctx->stream);
+            const auto g1 = std::chrono::steady_clock::now();
+            ocean_sync(ctx);
+            const auto g2 = std::chrono::steady_clock::now();
+            printf("the frame as a hipGraph (%d launches): host submit %.2f us/frame, until the GPU is idle %.2f us/frame\n", K,
+                   std::chrono::duration<double, std::micro>(g1 - g0).count() / K, std::chrono::duration<double, std::micro>(g2 - g0).count() / K);
+            hipGraphExecDestroy(exec); hipGraphDestroy(graph);
+        }
         printf("frame loop of %d frames: host submit %.2f us/frame, until the GPU is idle %.2f us/frame\n", K,
                std::chrono::duration<double, std::micro>(h1 - h0).count() / K, std::chrono::duration<double, std::micro>(h2 - h0).count() / K);
     }
