@@ -635,62 +635,35 @@ int32_t ocean_resolution(const OceanContext* ctx) { return valid(ctx) ? ctx->n :
 
 namespace {
 
-// fp32 -> fp16 bits, round to nearest even (host side of the config-5 upload)
-uint16_t float_to_half_bits(float f) {
-    const _Float16 h = (_Float16)f;
-    uint16_t b;
-    std::memcpy(&b, &h, sizeof b);
-    return b;
-}
-float half_bits_to_float(uint16_t b) {
-    _Float16 h;
-    std::memcpy(&h, &b, sizeof h);
-    return (float)h;
-}
-
 int32_t upload_common(OceanContext* ctx, const float* h0_re_im, const float* omega, bool f16) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
     if (!h0_re_im || !omega) return fail(ctx, OCEAN_E_INVALID_ARG, "NULL input");
     DeviceGuard guard(ctx->device);
     const size_t n = (size_t)ctx->n, n2 = n * n;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    std::vector<c32> nat, tT;
-    std::vector<float> oT;
-    std::vector<uint32_t> packedT;
-    try { nat.resize(n2); tT.resize(n2); oT.resize(n2); if (f16) packedT.resize(n2); }
-    catch (...) { return fail(ctx, OCEAN_E_OOM, "host staging allocation failed"); }
-    const c32* src = reinterpret_cast<const c32*>(h0_re_im);
+    HIP_TRY(ctx, sync_for_readback(ctx));                         // frames in flight still read the old inputs
     int scale_log2 = 0;
-    if (f16) {
+    if (f16) {                                                     // max |component| * 2^s lands in [2^14, 2^15)
         float mx = 0.0f;
         for (size_t i = 0; i < 2 * n2; ++i) { const float a = std::fabs(h0_re_im[i]); if (a > mx) mx = a; }
         if (!(mx > 0.0f) || !std::isfinite(mx)) scale_log2 = 0;
-        else scale_log2 = 14 - (int)std::floor(std::log2(mx));       // max * 2^s in [2^14, 2^15)
-        const float up = std::ldexp(1.0f, scale_log2), down = std::ldexp(1.0f, -scale_log2);
-        for (size_t i = 0; i < n2; ++i) {                              // the values every kernel will use
-            nat[i] = mk(half_bits_to_float(float_to_half_bits(src[i].x * up)) * down,
-                                 half_bits_to_float(float_to_half_bits(src[i].y * up)) * down);
-        }
-    } else {
-        std::memcpy(nat.data(), src, n2 * sizeof(c32));
+        else scale_log2 = 14 - (int)std::floor(std::log2(mx));
     }
-    // one-time re-layout for the fused path: h0T[x][y] = h0[y][x] (blocked host transpose)
-    constexpr size_t B = 32;
-    const float up = std::ldexp(1.0f, scale_log2);
-    for (size_t y0 = 0; y0 < n; y0 += B)
-        for (size_t x0 = 0; x0 < n; x0 += B)
-            for (size_t y = y0; y < y0 + B; ++y)
-                for (size_t x = x0; x < x0 + B; ++x) {
-                    tT[x * n + y] = nat[y * n + x];
-                    oT[x * n + y] = omega[y * n + x];
-                    if (f16) packedT[x * n + y] = (uint32_t)float_to_half_bits(nat[y * n + x].x * up) |
-                                                  ((uint32_t)float_to_half_bits(nat[y * n + x].y * up) << 16);
-                }
-    HIP_TRY(ctx, hipMemcpy(ctx->h0, nat.data(), n2 * sizeof(c32), hipMemcpyHostToDevice));
+    // natural layout (the staged path; = the reference's initial_spec / omega_buffer), then the one-time re-layout for the
+    // fused path on the device: h0T[x][y] = h0[y][x], omegaT likewise (k_transpose; round 2 did this on one host core:
+    // 0.9 s at N = 8192, 2.2 s with the fp16 packing)
+    HIP_TRY(ctx, hipMemcpy(ctx->h0, h0_re_im, n2 * sizeof(c32), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->omega, omega, n2 * sizeof(float), hipMemcpyHostToDevice));
-    if (f16) HIP_TRY(ctx, hipMemcpy(ctx->h0T, packedT.data(), n2 * sizeof(uint32_t), hipMemcpyHostToDevice));
-    else HIP_TRY(ctx, hipMemcpy(ctx->h0T, tT.data(), n2 * sizeof(c32), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(ctx->omegaT, oT.data(), n2 * sizeof(float), hipMemcpyHostToDevice));
+    const unsigned tiles = (unsigned)((n / 32) * (n / 32));
+    hipStream_t s = ctx->stream;
+    if (f16)
+        hipLaunchKernelGGL(k_quantise_f16_transpose, dim3(tiles), dim3(256), 0, s, reinterpret_cast<float2*>(ctx->h0),
+                           reinterpret_cast<uint32_t*>(ctx->h0T), (int)n, std::ldexp(1.0f, scale_log2), std::ldexp(1.0f, -scale_log2));
+    else
+        hipLaunchKernelGGL(k_transpose<float2>, dim3(tiles), dim3(256), 0, s, reinterpret_cast<const float2*>(ctx->h0),
+                           reinterpret_cast<float2*>(ctx->h0T), (int)n);
+    hipLaunchKernelGGL(k_transpose<float>, dim3(tiles), dim3(256), 0, s, (const float*)ctx->omega, ctx->omegaT, (int)n);
+    { const int32_t st = check_launch(ctx, "upload re-layout launch"); if (st != OCEAN_OK) return st; }
+    HIP_TRY(ctx, hipStreamSynchronize(s));
     ctx->h0_f16 = f16;
     ctx->scale_log2 = scale_log2;
     ctx->uploaded = true;

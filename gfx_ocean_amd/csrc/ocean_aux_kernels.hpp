@@ -52,4 +52,42 @@ k_pack_height32f(const float4* __restrict__ rgba, float4* __restrict__ height, s
     height[q] = make_float4(rgba[4 * q].y, rgba[4 * q + 1].y, rgba[4 * q + 2].y, rgba[4 * q + 3].y);
 }
 
+// ---- upload-time re-layout (once per ocean_upload_spectrum; the reference's staging copy, src/render.rs:872-924) --------
+// The fused path reads the static inputs transposed (h0T[x][y] = h0[y][x], omegaT likewise): 32 x 32 tiles through LDS,
+// both sides in contiguous pieces.  grid = (n / 32)^2, 256 threads.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_transpose(const T* __restrict__ src, T* __restrict__ dst, int n) {
+    __shared__ T tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int tiles = n / 32;
+    const int x0 = ((int)blockIdx.x % tiles) * 32, y0 = ((int)blockIdx.x / tiles) * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tile[ty + 8 * k][tx] = src[(size_t)(y0 + ty + 8 * k) * n + x0 + tx];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dst[(size_t)(x0 + ty + 8 * k) * n + y0 + tx] = tile[tx][ty + 8 * k];
+}
+// BASELINE config 5: h0 * 2^scale_log2 rounded to fp16 (nearest even) -> packed (re, im) pairs, transposed, for the fused
+// path; and the natural-layout fp32 copy is REPLACED by the dequantised values, so that every kernel (and
+// ocean_read_spectrum) uses exactly the numbers the fp16 storage holds.
+__global__ void __launch_bounds__(256)
+k_quantise_f16_transpose(float2* __restrict__ h0, uint32_t* __restrict__ packedT, int n, float up, float down) {
+    __shared__ uint32_t tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int tiles = n / 32;
+    const int x0 = ((int)blockIdx.x % tiles) * 32, y0 = ((int)blockIdx.x / tiles) * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const size_t i = (size_t)(y0 + ty + 8 * k) * n + x0 + tx;
+        const float2 v = h0[i];
+        const _Float16 re = (_Float16)(v.x * up), im = (_Float16)(v.y * up);       // round to nearest even
+        h0[i] = make_float2((float)re * down, (float)im * down);
+        tile[ty + 8 * k][tx] = (uint32_t)__builtin_bit_cast(unsigned short, re) | ((uint32_t)__builtin_bit_cast(unsigned short, im) << 16);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) packedT[(size_t)(x0 + ty + 8 * k) * n + y0 + tx] = tile[tx][ty + 8 * k];
+}
+
 }  // namespace ocean
