@@ -437,6 +437,13 @@ hipStream_t pick(OceanContext* c, void* stream) {
 hipError_t sync_for_readback(OceanContext* c) { return c->foreign_stream ? hipDeviceSynchronize() : hipStreamSynchronize(c->stream); }
 
 void launch_propagate(OceanContext* c, float time, float domain, hipStream_t s) {
+    if (c->quirks == OCEAN_QUIRKS_REFERENCE) {     // the whole tile, reference arithmetic: each spectrum texel is read once
+        const unsigned gridp = (unsigned)(((size_t)c->n * c->n / 4 + 255) / 256);
+        hipLaunchKernelGGL(k_propagate_paired, dim3(gridp), dim3(256), 0, s, (const c32*)c->h0, (const float*)c->omega,
+                           c->field[OCEAN_FIELD_DY], c->field[OCEAN_FIELD_DX], c->field[OCEAN_FIELD_DZ], c->n, time, domain);
+        for (int f = 0; f < 3; ++f) { c->nat_valid[f] = true; c->chk_valid[f] = false; }
+        return;
+    }
     const unsigned grid = (unsigned)(((size_t)c->n * c->n / 2 + 255) / 256);
     hipLaunchKernelGGL(k_propagate, dim3(grid), dim3(256), 0, s, (const c32*)c->h0, (const c32*)c->h0, (const float*)c->omega,
                        c->field[OCEAN_FIELD_DY], c->field[OCEAN_FIELD_DX], c->field[OCEAN_FIELD_DZ], c->n, 0, c->n, time,

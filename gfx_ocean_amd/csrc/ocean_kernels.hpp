@@ -126,6 +126,44 @@ k_propagate(const c32* __restrict__ h0, const c32* __restrict__ h0_partner, cons
     *reinterpret_cast<float4*>(disp_z + index) = make_float4(dz0.x, dz0.y, dz1.x, dz1.y);
 }
 
+// The whole tile with the reference quirks: texel i and its "-k" partner N*N-1-i (propagate.comp:48) use the SAME two
+// spectrum values with the roles swapped, so one thread does two adjacent texels AND their two partners from one pair of
+// 16-byte loads: 12 instead of 20 bytes read per texel (k_propagate re-reads every h0 texel as somebody's partner:
+// 738 MB counted at N = 4096 where 604 are the algorithm's).  Same arithmetic per texel as
+// k_propagate: bit-identical fields.  grid = N*N/4/256.
+__global__ void __launch_bounds__(256)
+k_propagate_paired(const c32* __restrict__ h0, const float* __restrict__ omega, c32* __restrict__ height, c32* __restrict__ disp_x,
+                   c32* __restrict__ disp_z, int n, float time, float domain_size) {
+    const uint32_t un = (uint32_t)n;
+    const uint32_t total = un * un;
+    const uint32_t index = (blockIdx.x * 256u + threadIdx.x) * 2u;     // texels index, index + 1 of the first half ...
+    if (index >= total / 2u) return;
+    const uint32_t mindex = total - 2u - index;                        // ... and mindex, mindex + 1 = the partners of index + 1, index
+    const float4 lo = *reinterpret_cast<const float4*>(h0 + index);
+    const float4 hi = *reinterpret_cast<const float4*>(h0 + mindex);
+    const c32 om_lo = *reinterpret_cast<const c32*>(omega + index);
+    const c32 om_hi = *reinterpret_cast<const c32*>(omega + mindex);
+    const uint32_t quirks = OCEAN_QUIRK_Q1 | OCEAN_QUIRK_Q2;
+    auto texels = [&](uint32_t base, float4 own, float4 neg, c32 om) {  // the body of k_propagate for texels base, base + 1
+        const uint32_t gx = base % un, gy = base / un;
+        const float ky = OCEAN_PI_F * wave_index(gy, un, quirks) / domain_size;
+        const float kx0 = OCEAN_PI_F * wave_index(gx, un, quirks) / domain_size;
+        const float kx1 = OCEAN_PI_F * wave_index(gx + 1u, un, quirks) / domain_size;
+        const c32 h0v = propagate_height(mk(own.x, own.y), mk(neg.z, neg.w), om.x, time);
+        const c32 h1v = propagate_height(mk(own.z, own.w), mk(neg.x, neg.y), om.y, time);
+        float knx0, kny0, knx1, kny1;
+        k_normalised(kx0, ky, knx0, kny0);
+        k_normalised(kx1, ky, knx1, kny1);
+        const c32 dx0 = mul_minus_i_kn(knx0, h0v), dx1 = mul_minus_i_kn(knx1, h1v);
+        const c32 dz0 = mul_minus_i_kn(kny0, h0v), dz1 = mul_minus_i_kn(kny1, h1v);
+        *reinterpret_cast<float4*>(height + base) = make_float4(h0v.x, h0v.y, h1v.x, h1v.y);
+        *reinterpret_cast<float4*>(disp_x + base) = make_float4(dx0.x, dx0.y, dx1.x, dx1.y);
+        *reinterpret_cast<float4*>(disp_z + base) = make_float4(dz0.x, dz0.y, dz1.x, dz1.y);
+    };
+    texels(index, lo, hi, om_lo);
+    texels(mindex, hi, lo, om_hi);
+}
+
 // One thread per 2 texels of a block of `lines` lines of N texels starting at line `line0` (whole tile: 0, N).
 // The sign depends on the parity of x + y only, so the same kernel serves a block of rows (line = y) and, in the
 // sharded transform, a block of columns stored as lines (line = x, position = y).

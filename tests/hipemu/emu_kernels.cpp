@@ -275,6 +275,11 @@ int emu_normals(int n, const float* rgba, float* normals, int channel) {
     return 0;
 }
 int emu_propagate(int n, const float* h0, const float* omega, float* h, float* dx, float* dz, float time, float L, unsigned quirks) {
+    if (quirks == 3u) {                                 // as launch_propagate of csrc/ocean_api.hip: the paired kernel for the reference quirks
+        const int gridp = (n * n / 4 + 255) / 256;
+        emu_launch(gridp, 256, [&] { k_propagate_paired((const c32*)h0, omega, (c32*)h, (c32*)dx, (c32*)dz, n, time, L); });
+        return 0;
+    }
     const int grid = (n * n / 2 + 255) / 256;
     emu_launch(grid, 256, [&] { k_propagate((const c32*)h0, (const c32*)h0, omega, (c32*)h, (c32*)dx, (c32*)dz, n, 0, n, time, L, quirks); });
     return 0;
