@@ -1578,10 +1578,12 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
     // N <= 2048: all three fields' loads are issued before the first transform (a workgroup has 8, then 16, 8-byte loads
     // per thread in flight otherwise).  Run 34: N = 2048 20.07-20.24k frames/s against 19.84-19.94k; at N = 4096 the same
     // costs 2-3 us (pass 2 91-94 us against 88-91): more lines in flight than the L2 keeps for the four sharers.
-#ifdef OCEAN_P2_PREFETCH
+#ifdef OCEAN_P2_PREFETCH   // A/B knob: 0 = none, 1 = disp_x and disp_z, 2 = disp_x only
     constexpr bool PREFETCH = (OCEAN_P2_PREFETCH != 0) && !PPAR && !SHARD;
+    constexpr bool PREFETCH_Z = (OCEAN_P2_PREFETCH == 1);
 #else
     constexpr bool PREFETCH = (N <= 2048) && !PPAR && !SHARD;
+    constexpr bool PREFETCH_Z = true;
 #endif
     c32 pre_x[EH], pre_z[EH];
     if constexpr (PREFETCH) {
@@ -1589,7 +1591,7 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
         const c32* sx_ = inter + off0;
         const c32* sz_ = inter + (size_t)2 * lay.fs + off0;
 #pragma unroll
-        for (int e = 0; e < EH; ++e) { pre_x[e] = sx_[(size_t)e * (T / P1) * lay.sx]; pre_z[e] = sz_[(size_t)e * (T / P1) * lay.sx]; }
+        for (int e = 0; e < EH; ++e) { pre_x[e] = sx_[(size_t)e * (T / P1) * lay.sx]; if constexpr (PREFETCH_Z) pre_z[e] = sz_[(size_t)e * (T / P1) * lay.sx]; }
     }
 #pragma unroll
     for (int it = 0; it < (PPAR ? 1 : 2); ++it) {                  // pass 0: height, 1: (disp_x, disp_z)
@@ -1617,8 +1619,9 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
 #pragma unroll
             for (int e = 0; e < EH; ++e) { a[e] = src[(size_t)e * (T / P1) * lay.sx]; b[e] = mk(0.0f, 0.0f); }
         } else if constexpr (PREFETCH) {
+            const c32* sz_ = inter + (size_t)2 * lay.fs + off;
 #pragma unroll
-            for (int e = 0; e < EH; ++e) { a[e] = pre_x[e]; b[e] = pre_z[e]; }
+            for (int e = 0; e < EH; ++e) { a[e] = pre_x[e]; b[e] = PREFETCH_Z ? pre_z[e] : sz_[(size_t)e * (T / P1) * lay.sx]; }
         } else {
             const c32* sx_ = inter + off;
             const c32* sz_ = inter + (size_t)2 * lay.fs + off;
