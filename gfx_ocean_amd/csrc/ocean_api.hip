@@ -205,10 +205,10 @@ template <int N> struct Launch {
         using H = Geo<N, PSEL>;
         hipError_t e = hipSuccess;
         if constexpr (plain_built<PSEL>()) {
-            e = hipFuncSetAttribute((const void*)k_half_pass1<N, H::E1, H::P, false, H::handover, H::fpar>,
+            e = hipFuncSetAttribute((const void*)k_half_pass1<N, H::E1, H::P, false, H::loader, H::fpar>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, H::half_lds1);
             if (e != hipSuccess) return e;
-            e = hipFuncSetAttribute((const void*)k_half_pass1<N, H::E1, H::P, true, H::handover, H::fpar>,
+            e = hipFuncSetAttribute((const void*)k_half_pass1<N, H::E1, H::P, true, H::loader, H::fpar>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, H::half_lds1);
             if (e != hipSuccess) return e;
             e = hipFuncSetAttribute((const void*)k_half_pass2<N, H::E2, CHUNK_W, H::R2h, H::p2_group, H::ppar>,
@@ -219,10 +219,10 @@ template <int N> struct Launch {
             if (e != hipSuccess) return e;
         }
         if constexpr (split_built<PSEL>()) {
-            e = hipFuncSetAttribute((const void*)k_half_pass1_split<N, H::E1S, H::P, false, H::handover>,
+            e = hipFuncSetAttribute((const void*)k_half_pass1_split<N, H::E1S, H::P, false, H::loader>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, H::split_lds1);
             if (e != hipSuccess) return e;
-            e = hipFuncSetAttribute((const void*)k_half_pass1_split<N, H::E1S, H::P, true, H::handover>,
+            e = hipFuncSetAttribute((const void*)k_half_pass1_split<N, H::E1S, H::P, true, H::loader>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, H::split_lds1);
             if (e != hipSuccess) return e;
             e = hipFuncSetAttribute((const void*)k_half_pass2_split<N, H::E, CHUNK_W, H::p2_group>,
@@ -234,10 +234,10 @@ template <int N> struct Launch {
             e = hipFuncSetAttribute((const void*)k_half_pass2_split<N, H::E, CHUNK_W, H::p2_group, false, true>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, H::split_lds2);
             if (e != hipSuccess) return e;
-            e = hipFuncSetAttribute((const void*)k_half_pass1_split<N, H::E1S, H::P, false, H::handover, true>,
+            e = hipFuncSetAttribute((const void*)k_half_pass1_split<N, H::E1S, H::P, false, H::loader, true>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, H::split_lds1);
             if (e != hipSuccess) return e;
-            e = hipFuncSetAttribute((const void*)k_half_pass1_split<N, H::E1S, H::P, true, H::handover, true>,
+            e = hipFuncSetAttribute((const void*)k_half_pass1_split<N, H::E1S, H::P, true, H::loader, true>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, H::split_lds1);
         }
         return e;
@@ -249,21 +249,21 @@ template <int N> struct Launch {
             if (c->split) {
                 if (c->inter16) {                                  // opt-in precision mode (ocean_set_intermediate)
                     if (c->h0_f16)
-                        launch(k_half_pass1_split<N, H::E1S, H::P, true, H::handover, true>, dim3(H::half_grid1), dim3(H::split_threads1),
+                        launch(k_half_pass1_split<N, H::E1S, H::P, true, H::loader, true>, dim3(H::half_grid1), dim3(H::split_threads1),
                                H::split_lds1, s, t, (const void*)c->h0T, descale, (const float*)c->omegaT, c->inter, c->nyq,
                                (const c32*)c->tw, c->lay_h, time, domain, 0, c->inter_scale);
                     else
-                        launch(k_half_pass1_split<N, H::E1S, H::P, false, H::handover, true>, dim3(H::half_grid1), dim3(H::split_threads1),
+                        launch(k_half_pass1_split<N, H::E1S, H::P, false, H::loader, true>, dim3(H::half_grid1), dim3(H::split_threads1),
                                H::split_lds1, s, t, (const void*)c->h0T, 1.0f, (const float*)c->omegaT, c->inter, c->nyq,
                                (const c32*)c->tw, c->lay_h, time, domain, 0, c->inter_scale);
                     return;
                 }
                 if (c->h0_f16)
-                    launch(k_half_pass1_split<N, H::E1S, H::P, true, H::handover>, dim3(H::half_grid1), dim3(H::split_threads1),
+                    launch(k_half_pass1_split<N, H::E1S, H::P, true, H::loader>, dim3(H::half_grid1), dim3(H::split_threads1),
                            H::split_lds1, s, t, (const void*)c->h0T, descale, (const float*)c->omegaT, c->inter, c->nyq,
                            (const c32*)c->tw, c->lay_h, time, domain, 0, (float*)nullptr);
                 else
-                    launch(k_half_pass1_split<N, H::E1S, H::P, false, H::handover>, dim3(H::half_grid1), dim3(H::split_threads1),
+                    launch(k_half_pass1_split<N, H::E1S, H::P, false, H::loader>, dim3(H::half_grid1), dim3(H::split_threads1),
                            H::split_lds1, s, t, (const void*)c->h0T, 1.0f, (const float*)c->omegaT, c->inter, c->nyq,
                            (const c32*)c->tw, c->lay_h, time, domain, 0, (float*)nullptr);
                 return;
@@ -271,16 +271,16 @@ template <int N> struct Launch {
         }
         if constexpr (plain_built<PSEL>()) {
 #ifdef OCEAN_PASS1_ITERS
-            constexpr int GRID1 = (N == 4096 && !H::fpar && !H::handover) ? H::half_grid1 / OCEAN_PASS1_ITERS : H::half_grid1;
+            constexpr int GRID1 = (N == 4096 && !H::fpar && !H::loader) ? H::half_grid1 / OCEAN_PASS1_ITERS : H::half_grid1;
 #else
             constexpr int GRID1 = H::half_grid1;
 #endif
             if (c->h0_f16)
-                launch(k_half_pass1<N, H::E1, H::P, true, H::handover, H::fpar>, dim3(GRID1), dim3(H::half_threads1), H::half_lds1, s, t,
+                launch(k_half_pass1<N, H::E1, H::P, true, H::loader, H::fpar>, dim3(GRID1), dim3(H::half_threads1), H::half_lds1, s, t,
                        (const void*)c->h0T, descale, (const float*)c->omegaT, c->inter, c->nyq, (const c32*)c->tw,
                        c->lay_h, time, domain, 0);
             else
-                launch(k_half_pass1<N, H::E1, H::P, false, H::handover, H::fpar>, dim3(GRID1), dim3(H::half_threads1), H::half_lds1, s, t,
+                launch(k_half_pass1<N, H::E1, H::P, false, H::loader, H::fpar>, dim3(GRID1), dim3(H::half_threads1), H::half_lds1, s, t,
                        (const void*)c->h0T, 1.0f, (const float*)c->omegaT, c->inter, c->nyq, (const c32*)c->tw,
                        c->lay_h, time, domain, 0);
         }
@@ -331,17 +331,17 @@ template <int N> struct Launch {
         const float descale = c->h0_f16 ? std::ldexp(1.0f, -c->scale_log2) : 1.0f;
         if constexpr (split_built<default_psel()>()) {
             if (c->h0_f16)
-                hipLaunchKernelGGL((k_half_pass1_split<N, H::E1S, H::P, true, H::handover>), dim3(groups), dim3(H::split_threads1), H::split_lds1, s,
+                hipLaunchKernelGGL((k_half_pass1_split<N, H::E1S, H::P, true, H::loader>), dim3(groups), dim3(H::split_threads1), H::split_lds1, s,
                                    (const void*)c->h0T, descale, (const float*)c->omegaT, send, c->nyq, (const c32*)c->tw, lay, time, domain, x_group0, (float*)nullptr);
             else
-                hipLaunchKernelGGL((k_half_pass1_split<N, H::E1S, H::P, false, H::handover>), dim3(groups), dim3(H::split_threads1), H::split_lds1, s,
+                hipLaunchKernelGGL((k_half_pass1_split<N, H::E1S, H::P, false, H::loader>), dim3(groups), dim3(H::split_threads1), H::split_lds1, s,
                                    (const void*)c->h0T, descale, (const float*)c->omegaT, send, c->nyq, (const c32*)c->tw, lay, time, domain, x_group0, (float*)nullptr);
         } else {
             if (c->h0_f16)
-                hipLaunchKernelGGL((k_half_pass1<N, H::E1, H::P, true, H::handover, H::fpar>), dim3(groups), dim3(H::half_threads1), H::half_lds1, s,
+                hipLaunchKernelGGL((k_half_pass1<N, H::E1, H::P, true, H::loader, H::fpar>), dim3(groups), dim3(H::half_threads1), H::half_lds1, s,
                                    (const void*)c->h0T, descale, (const float*)c->omegaT, send, c->nyq, (const c32*)c->tw, lay, time, domain, x_group0);
             else
-                hipLaunchKernelGGL((k_half_pass1<N, H::E1, H::P, false, H::handover, H::fpar>), dim3(groups), dim3(H::half_threads1), H::half_lds1, s,
+                hipLaunchKernelGGL((k_half_pass1<N, H::E1, H::P, false, H::loader, H::fpar>), dim3(groups), dim3(H::half_threads1), H::half_lds1, s,
                                    (const void*)c->h0T, descale, (const float*)c->omegaT, send, c->nyq, (const c32*)c->tw, lay, time, domain, x_group0);
         }
     }

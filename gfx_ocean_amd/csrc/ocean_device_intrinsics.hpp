@@ -65,6 +65,10 @@ __device__ __forceinline__ int opaque_lane(int x) {
     return x;
 }
 
+// The two values are computed HERE: an opaque use that keeps the compiler from sinking their arithmetic to a later
+// block (and their inputs alive until then).
+__device__ __forceinline__ void pin_here(c32& a, c32& b) { asm volatile("" : "+v"(a), "+v"(b)); }
+
 // Returns x, but only after `dep` has been computed: orders the loads whose addresses derive from
 // the result behind the arithmetic that produced `dep` (splits a long load phase in two so that
 // the first half's input registers are free before the second half's loads are issued).
@@ -201,6 +205,48 @@ __device__ __forceinline__ void wave_priority(int p) {
         case 2: __builtin_amdgcn_s_setprio(2); break;
         default: __builtin_amdgcn_s_setprio(3); break;
     }
+}
+
+// ---- LDS-DMA (global -> LDS without VGPRs): the loader of fused pass 1 at N >= 2048 (half_load_AB_dma) ------------------
+// One wave instruction moves 64 x 16 bytes: lane l reads 16 bytes at (wave-uniform base + its 32-bit offset) and the data
+// lands in LDS at (wave-uniform lds_dst + 16 l) -- lane-linear, so the LDS image of a contiguous kilobyte is the kilobyte.
+// Issued through inline asm on purpose: hipcc counts the builtin (__builtin_amdgcn_global_load_lds) as a pending LDS
+// write and waits vmcnt(0) in front of every ds_read that may alias it (measured on ROCm 7.2), which drains a ring of
+// pieces in flight; an asm statement is outside its bookkeeping, the waits below are ours.  M0 (the LDS destination)
+// is saved and restored inside the statement; `s_nop 1` + the two s_mov + `s_nop 0` are the five wait states between a
+// readfirstlane-written SGPR and the memory instruction that reads it.
+__device__ __forceinline__ uint32_t lds_address(const void* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+template <bool NT>
+__device__ __forceinline__ void glds16(const void* base_uniform, uint32_t lane_offset, uint32_t lds_dst_uniform) {
+    const uint64_t b = (uint64_t)base_uniform;
+    const uint64_t sb = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst_uniform);
+    unsigned keep;
+    if constexpr (NT)
+        asm volatile("s_nop 1\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(lane_offset), "s"(sb), "s"(dst) : "memory");
+    else
+        asm volatile("s_nop 1\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(lane_offset), "s"(sb), "s"(dst) : "memory");
+}
+// "At most K of this wave's DMA instructions are still in flight, and its LDS reads have returned."  The data of the
+// others is in LDS for THIS wave; for the rest of the workgroup after the barrier that follows (dma_barrier).
+template <int K> __device__ __forceinline__ void dma_wait() {
+    static_assert(K >= 0 && K < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(K) : "memory");
+}
+// Workgroup barrier that does NOT wait for DMA in flight (__syncthreads() carries a fence that would).
+__device__ __forceinline__ void dma_barrier() {
+#ifdef OCEAN_RACE_JITTER
+    race_jitter();
+#endif
+    asm volatile("s_barrier" : : : "memory");
+#ifdef OCEAN_RACE_JITTER
+    race_jitter();
+#endif
 }
 
 // x is known to be identical in every lane of the wave: move it to an SGPR so that addresses

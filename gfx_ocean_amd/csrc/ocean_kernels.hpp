@@ -969,6 +969,198 @@ __device__ __forceinline__ void half_load_AB_skewed(const void* __restrict__ h0T
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pass-1 loader through LDS-DMA (half_load_AB_dma)
+// ---------------------------------------------------------------------------------------------
+// half_load_AB stages its inputs in VGPRs: four dependent batches of 6 streams x 4 elements, at the 128-register budget
+// of a 1024-thread workgroup, while the 136 KiB of line buffers sit idle until the first transform.  Here the workgroup
+// streams its inputs through that idle LDS instead, in E / Q pieces of L = S * TS * Q positions of every line, with
+// global_load_lds_dwordx4 (glds16: no VGPR destination, 1 KiB per wave instruction), a ring of D pieces so that
+// D - 2 .. D - 1 pieces are in flight while one is propagated out of LDS:
+//   * P + 1 "own-type" lines  OWN[k] = h0T[(x0 - 1 + k) % N][y0 .. y0 + L)            k = 0 is the left neighbour's column
+//   * P + 1 "mirror-type"     MIR[k] = h0T[(N - x0 - k) % N][N - y0 - L .. N - y0)
+//   * P dispersion lines      OM[c]  = omegaT[x0 + c][y0 .. y0 + L),   OM2[c] = omegaT[(N - x0 - c) % N][N - y0 - L .. N - y0)
+// Column c of the workgroup (x = x0 + c) at position y = y0 + o reads (half_load_AB's six streams):
+//     own[y] = OWN[c+1][o]      mirror[N-1-y] = MIR[c+1][L-1-o]     omega  = OM[c][o]
+//     mirror2[y-1] = OWN[c][o-1]   own2[N-y]  = MIR[c][L-o]          omega2 = OM2[c][L-o]
+// -- the duplicate streams (own2 / mirror2 of column c are mirror / own of column c - 1) come out of the SAME staged
+// lines instead of a second request, so a workgroup asks the memory system for each of its P + 1 + P + 1 lines once
+// (half_load_AB: 4 P requests, of which the L2 merged most but not all: 267 MB fetched at N = 4096 where 235 MB are
+// the workgroups' distinct lines).  Position o = 0 needs index -1 / L of the second row: the previous
+// piece's last (first) element -- every thread keeps those three values of its column from the piece before
+// (broadcast reads); for the first piece they are the line's other end, which arrives with the LAST piece: that one
+// element of B is computed after the loop.
+// Synchronisation per piece: every wave waits for ITS instructions of piece b (counted vmcnt, the younger pieces stay in
+// flight), one barrier -- which also says that everybody has finished reading piece b - 1 -- then piece b + D - 1 is
+// issued into the slot of piece b - 1 and piece b is consumed.  No register staging, no compiler-visible global load
+// in the whole load phase.
+template <int N, int E, int P, bool H16, int S>
+struct DmaRing {
+    static constexpr int TS = N / (S * E);                         // threads per (sub-)line
+#ifndef OCEAN_DMA_Q
+#define OCEAN_DMA_Q 1
+#endif
+    static constexpr int QMIN = (S * TS >= 256) ? 1 : 256 / (S * TS);   // a dispersion segment is at least one 1 KiB instruction
+    static constexpr int Q = (OCEAN_DMA_Q > QMIN) ? OCEAN_DMA_Q : QMIN;   // elements per thread and piece
+    static constexpr int L = S * TS * Q;                           // positions of a line per piece
+    static constexpr int NP = E / Q;                               // pieces
+    static constexpr int SPB = H16 ? 4 : 8;                        // bytes per spectrum texel
+    static constexpr int SEG_H = L * SPB, SEG_W = L * 4;           // one line segment: spectrum, dispersion
+    static constexpr int OFF_MIR = 0;
+    static constexpr int OFF_OWN = (P + 1) * SEG_H;
+    static constexpr int OFF_OM2 = 2 * (P + 1) * SEG_H;
+    static constexpr int OFF_OM = OFF_OM2 + P * SEG_W;
+    static constexpr int PIECE = OFF_OM + P * SEG_W;               // bytes of one piece
+    static constexpr int SLOTS = PIECE / 1024;                     // wave instructions per piece
+    static constexpr int WAVES = P * S * TS / 64;
+    static constexpr int SPW = (SLOTS + WAVES - 1) / WAVES;        // ... per wave (the first SLOTS % WAVES waves when uneven)
+    static constexpr int REM = SLOTS % WAVES;
+    static constexpr int BASE = SLOTS / WAVES;
+#ifndef OCEAN_DMA_DEPTH
+#define OCEAN_DMA_DEPTH 4
+#endif
+    static constexpr int D = (NP < OCEAN_DMA_DEPTH) ? (NP < 2 ? 2 : NP) : OCEAN_DMA_DEPTH;   // ring slots (>= 2: the protocol below)
+    static_assert(OCEAN_DMA_DEPTH >= 2, "the ring needs two slots");
+    static constexpr int bytes = D * PIECE;
+    static_assert(E % Q == 0 && SEG_H % 1024 == 0 && SEG_W % 1024 == 0 && (P * S * TS) % 64 == 0, "DMA ring geometry");
+};
+
+// LDS bytes of the ring (fp32 spectrum: the larger one), 0 when the loader is not used for this geometry.
+template <bool ON, int N, int E, int P, int S> struct DmaRingBytes { static constexpr int value = 0; };
+template <int N, int E, int P, int S> struct DmaRingBytes<true, N, E, P, S> { static constexpr int value = DmaRing<N, E, P, false, S>::bytes; };
+
+template <int N, int E, int P, bool H16, int S>
+__device__ __forceinline__ void half_load_AB_dma(const void* __restrict__ h0T_, float descale, const float* __restrict__ omegaT_,
+                                                 uint32_t x0, int c, int par, int j, int tid, float time, unsigned char* ring,
+                                                 c32 (&A)[E], c32 (&B)[E]) {
+    typedef DmaRing<N, E, P, H16, S> R;
+    typedef typename Spec<H16>::elem Sp;
+    constexpr int TS = R::TS, Q = R::Q, L = R::L, NP = R::NP, D = R::D;
+    const char* h0T = reinterpret_cast<const char*>(h0T_);
+    const char* omT = reinterpret_cast<const char*>(omegaT_);
+    const int wave = wave_uniform(tid >> 6);
+    const uint32_t lane16 = (uint32_t)(tid & 63) * 16u;
+    const uint32_t ring_lds = lds_address(ring);
+
+    // This wave's slots (wave + k * WAVES): source of piece 0 and the step from piece to piece (scalar registers).
+    const char* src0[R::SPW];
+    int step[R::SPW];
+    bool stream_once[R::SPW];
+#pragma unroll
+    for (int k = 0; k < R::SPW; ++k) {
+        const int byte = (wave + k * R::WAVES) * 1024;             // offset within the piece = offset within its LDS image
+#ifdef OCEAN_X_NODUP   // timing experiment only (wrong results): the left neighbour's two lines (k = 0) are not asked for -- an
+                       // upper bound on what keeping the inter-workgroup duplicates out of the memory system can buy
+#define OCEAN_DMA_LINE_K(k) (((k) == 0) ? 1 : (k))
+#else
+#define OCEAN_DMA_LINE_K(k) (k)
+#endif
+        if (byte < R::OFF_OWN) {
+            const uint32_t line = (uint32_t)(N - (int)x0 - OCEAN_DMA_LINE_K(byte / R::SEG_H)) & (uint32_t)(N - 1);
+            src0[k] = h0T + ((size_t)line * N + (N - L)) * R::SPB + (byte % R::SEG_H);
+            step[k] = -R::SEG_H; stream_once[k] = false;
+        } else if (byte < R::OFF_OM2) {
+            const int bb = byte - R::OFF_OWN;
+            const uint32_t line = (uint32_t)((int)x0 - 1 + OCEAN_DMA_LINE_K(bb / R::SEG_H)) & (uint32_t)(N - 1);
+            src0[k] = h0T + (size_t)line * N * R::SPB + (bb % R::SEG_H);
+            step[k] = R::SEG_H; stream_once[k] = false;
+        } else if (byte < R::OFF_OM) {
+            const int bb = byte - R::OFF_OM2;
+            const uint32_t line = (uint32_t)(N - (int)x0 - bb / R::SEG_W) & (uint32_t)(N - 1);
+            src0[k] = omT + ((size_t)line * N + (N - L)) * 4 + (bb % R::SEG_W);
+            step[k] = -R::SEG_W; stream_once[k] = true;
+        } else {
+            const int bb = byte - R::OFF_OM;
+            src0[k] = omT + (size_t)(x0 + (uint32_t)(bb / R::SEG_W)) * N * 4 + (bb % R::SEG_W);
+            step[k] = R::SEG_W; stream_once[k] = true;
+        }
+    }
+    auto issue = [&](int b) {
+#pragma unroll
+        for (int k = 0; k < R::SPW; ++k) {
+            if ((k + 1) * R::WAVES <= R::SLOTS || wave + k * R::WAVES < R::SLOTS) {   // wave-uniform
+                const char* src = src0[k] + (ptrdiff_t)b * step[k];
+                const uint32_t dst = ring_lds + (uint32_t)((b % D) * R::PIECE + (wave + k * R::WAVES) * 1024);
+                // the dispersion lines are read once per frame by one workgroup: non-temporal where the working set exceeds the caches
+#ifndef OCEAN_DMA_NT
+#define OCEAN_DMA_NT 1                                              // A/B knob: 0 = no hint, 1 = the dispersion lines, 2 = everything
+#endif
+                if constexpr (OCEAN_DMA_NT == 2) glds16<true>(src, lane16, dst);
+                else if constexpr (OCEAN_DMA_NT == 0) glds16<false>(src, lane16, dst);
+                else if (N >= 4096 && stream_once[k]) glds16<true>(src, lane16, dst);
+                else glds16<false>(src, lane16, dst);
+            }
+        }
+    };
+    // "my instructions of piece b have landed": the pieces issued after it may stay in flight
+    auto wait_piece = [&](int b, int issued_upto) {
+        const int after = issued_upto - b;                         // compile-time after unrolling: 0 .. D - 2
+        if constexpr (R::REM == 0) {
+            if (after <= 0) dma_wait<0>(); else if (after == 1) dma_wait<R::BASE>(); else if (after == 2) dma_wait<2 * R::BASE>(); else dma_wait<3 * R::BASE>();
+        } else if (wave < R::REM) {
+            if (after <= 0) dma_wait<0>(); else if (after == 1) dma_wait<R::BASE + 1>(); else if (after == 2) dma_wait<2 * (R::BASE + 1)>(); else dma_wait<3 * (R::BASE + 1)>();
+        } else {
+            if (after <= 0) dma_wait<0>(); else if (after == 1) dma_wait<R::BASE>(); else if (after == 2) dma_wait<2 * R::BASE>(); else dma_wait<3 * R::BASE>();
+        }
+    };
+    static_assert(D <= 5, "wait_piece covers rings of up to five pieces");
+
+#pragma unroll
+    for (int b = 0; b < D - 1 && b < NP; ++b) issue(b);
+
+    const int o0 = S * j + par;                                    // this thread's offset within a piece (element q: + q S TS)
+    const bool first = (o0 == 0);
+    const Sp* own1 = reinterpret_cast<const Sp*>(ring + R::OFF_OWN + (c + 1) * R::SEG_H) + o0;        // OWN[c+1][o]
+    const Sp* own0 = reinterpret_cast<const Sp*>(ring + R::OFF_OWN + c * R::SEG_H) + o0 - 1;          // OWN[c][o-1]
+    const Sp* mir1 = reinterpret_cast<const Sp*>(ring + R::OFF_MIR + (c + 1) * R::SEG_H) + (L - 1 - o0);   // MIR[c+1][L-1-o]
+    const Sp* mir0 = reinterpret_cast<const Sp*>(ring + R::OFF_MIR + c * R::SEG_H) + (L - o0);        // MIR[c][L-o]
+    const float* om1 = reinterpret_cast<const float*>(ring + R::OFF_OM + c * R::SEG_W) + o0;          // OM[c][o]
+    const float* om0 = reinterpret_cast<const float*>(ring + R::OFF_OM2 + c * R::SEG_W) + (L - o0);   // OM2[c][L-o]
+    // the piece's last / first elements of the second rows: position o = 0 of the NEXT piece (wave-uniform addresses)
+    const Sp* own0_last = reinterpret_cast<const Sp*>(ring + R::OFF_OWN + c * R::SEG_H) + (L - 1);
+    const Sp* mir0_first = reinterpret_cast<const Sp*>(ring + R::OFF_MIR + c * R::SEG_H);
+    const float* om0_first = reinterpret_cast<const float*>(ring + R::OFF_OM2 + c * R::SEG_W);
+    c32 edge_m2 = mk(0.0f, 0.0f), edge_a2 = mk(0.0f, 0.0f);
+    float edge_w2 = 0.0f;
+#pragma unroll
+    for (int b = 0; b < NP; ++b) {
+        constexpr int PE = R::PIECE / (int)sizeof(Sp), PF = R::PIECE / 4;
+        const int issued = (b + D - 2 < NP - 1) ? (b + D - 2) : (NP - 1);
+        wait_piece(b, issued);
+        dma_barrier();
+        if (b + D - 1 < NP) issue(b + D - 1);                      // into the slot of piece b - 1: everybody is past it
+        const int slot = b % D;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int e = b * Q + q;
+            const int oq = q * S * TS;
+            const c32 a = Spec<H16>::load(own1 + slot * PE + oq, descale);
+            const c32 m = Spec<H16>::load(mir1 + slot * PE - oq, descale);
+            const float w = om1[slot * PF + oq];
+            c32 m2 = Spec<H16>::load(own0 + slot * PE + oq, descale);
+            c32 a2 = Spec<H16>::load(mir0 + slot * PE - oq, descale);
+            float w2 = om0[slot * PF - oq];
+            if (q == 0) {                                          // o == 0: the previous piece's values (b == 0: fixed below)
+                m2 = first ? edge_m2 : m2;
+                a2 = first ? edge_a2 : a2;
+                w2 = first ? edge_w2 : w2;
+            }
+            A[e] = propagate_height(a, m, w, time);
+            B[e] = cconj(propagate_height(a2, m2, w2, time));
+            pin_here(A[e], B[e]);                                  // (else the arithmetic sinks to the first use, behind the whole
+                                                                   //  load phase, and the raw inputs of every piece stay live: 117 spills)
+        }
+        edge_m2 = Spec<H16>::load(own0_last + slot * PE, descale);
+        edge_a2 = Spec<H16>::load(mir0_first + slot * PE, descale);
+        edge_w2 = om0_first[slot * PF];
+    }
+    // position y = 0 (piece 0, o = 0) pairs with the lines' other ends, which came with the last piece
+    {
+        const c32 b0 = cconj(propagate_height(edge_a2, edge_m2, edge_w2, time));
+        B[0] = first ? b0 : B[0];
+    }
+}
+
 // The same for ONE position (the Nyquist column is done element-wise by a whole workgroup).
 template <int N, bool H16>
 __device__ __forceinline__ void half_AB_at(const void* __restrict__ h0T_, float descale, const float* __restrict__ omegaT,
@@ -1023,7 +1215,10 @@ template <int E> constexpr int pass1_waves_per_simd(int threads) {
 // other.  At N = 512 a workgroup is two waves on a CU with four SIMDs and every instruction's latency is exposed
 // (timeline r03_run4: load 1.0 us, then 1.45 + 1.0 + 1.3 us of transforms, 3 x 0.2 us of stores): the three
 // transforms now run side by side.
-template <int N, int E, int P, bool H16, bool HAND = false, bool FPAR = false>
+// LD: how the inputs arrive -- LOAD_REGS (half_load_AB), LOAD_HANDOVER (+ the duplicate streams through LDS), LOAD_DMA
+// (half_load_AB_dma: streamed through the idle line buffers by LDS-DMA).
+constexpr int LOAD_REGS = 0, LOAD_HANDOVER = 1, LOAD_DMA = 2;
+template <int N, int E, int P, bool H16, int LD = LOAD_REGS, bool FPAR = false>
 __global__ void __launch_bounds__((N / E) * P * (FPAR ? 3 : 1), pass1_waves_per_simd<E>((N / E) * P * (FPAR ? 3 : 1)))
 k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restrict__ omegaT, c32* __restrict__ inter,
              c32* nyq_spec, const c32* __restrict__ tw, InterLayout lay, float time, float domain_size, int x_group0) {
@@ -1032,7 +1227,8 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
     constexpr int H2 = P / 2;
     constexpr int CR = CHUNK_R, CW = CHUNK_W;                    // row y of a chunk is y % CR, column x % CW
     static_assert((2 * T) % CR == 0 && CW % P == 0, "chunk geometry");
-    static_assert(!FPAR || (GT % 64 == 0 && !HAND), "a field group is whole waves");
+    constexpr bool HAND = (LD == LOAD_HANDOVER);
+    static_assert(!FPAR || (GT % 64 == 0 && LD == LOAD_REGS), "a field group is whole waves");
     static_assert(P > 1 || !HAND, "the hand-over needs a left neighbour inside the workgroup");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     c32* lds = reinterpret_cast<c32*>(smem);
@@ -1082,7 +1278,10 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
 #ifdef OCEAN_SKEW_DUP
     half_load_AB_skewed<N, E, H16>(h0T, descale, omegaT, x, j, time, A, B);
 #else
-    if constexpr (HAND) half_load_AB_handover<N, E, P, H16>(h0T, descale, omegaT, x, c, j, tid, time, reinterpret_cast<float4*>(smem), A, B);
+    if constexpr (LD == LOAD_DMA) {
+        static_assert(DmaRing<N, E, P, H16, 1>::bytes <= 160 * 1024, "the DMA ring fits the LDS");
+        half_load_AB_dma<N, E, P, H16, 1>(h0T, descale, omegaT, (uint32_t)(Xg * P), c, 0, j, tid, time, smem, A, B);
+    } else if constexpr (HAND) half_load_AB_handover<N, E, P, H16>(h0T, descale, omegaT, x, c, j, tid, time, reinterpret_cast<float4*>(smem), A, B);
     else half_load_AB<N, E, H16>(h0T, descale, omegaT, x, j, time, A, B);
 #endif
     OCEAN_TL(1);
@@ -1113,7 +1312,7 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
                 reg[e] = cadd_i(reg[e], z[e * T]);                 // + i * Sn
             }
         }
-        if (HAND || ff > 0) __syncthreads();                      // the line buffers' previous readers (hand-over / chunk stores) are done
+        if (LD != LOAD_REGS || ff > 0) __syncthreads();           // the line buffers' previous readers (loader ring / hand-over / chunk stores) are done
 #ifdef OCEAN_X_NOFFT   // timing experiment only (wrong results): the transform replaced by its final LDS scatter
         {
             c32* g = lds_line + lds_pad(jf);
@@ -1398,7 +1597,7 @@ __device__ __forceinline__ void half_load_AB_pairs_handover(const void* __restri
 // The scale is the wave maximum of |re|, |im| (DPP reduction) rounded up to a power of two: values are exact multiples of
 // 2^(e-15).  Numerics (tools/inter16_numerics.py, N = 8192, fp16-quantised spectrum): 2.7-3.1e-5 normalised max against
 // the unquantised result, tolerance 1e-4.
-template <int N, int E, int P, bool H16, bool HAND = false, bool I16 = false>
+template <int N, int E, int P, bool H16, int LD = LOAD_REGS, bool I16 = false>
 __global__ void __launch_bounds__((N / E) * P, pass1_waves_per_simd<E>((N / E) * P))
 k_half_pass1_split(const void* __restrict__ h0T, float descale, const float* __restrict__ omegaT, c32* __restrict__ inter,
                    c32* nyq_spec, const c32* __restrict__ tw, InterLayout lay, float time, float domain_size, int x_group0,
@@ -1429,7 +1628,11 @@ k_half_pass1_split(const void* __restrict__ h0T, float descale, const float* __r
     c32 A[E], B[E];
     OCEAN_TL(0);
     static_assert(E / 2 * THREADS * (int)sizeof(float4) <= 2 * P * LinePitch<M>::elems * (int)sizeof(c32), "exchange fits the line buffers");
-    if constexpr (HAND) half_load_AB_pairs_handover<N, E, H16, THREADS>(h0T, descale, omegaT, x, j, par, c, tid, time, reinterpret_cast<float4*>(smem), A, B);
+    if constexpr (LD == LOAD_DMA) {
+        static_assert(DmaRing<N, E, P, H16, 2>::bytes <= 160 * 1024, "the DMA ring fits the LDS");
+        half_load_AB_dma<N, E, P, H16, 2>(h0T, descale, omegaT, (uint32_t)(Xg * P), c, par, j, tid, time, smem, A, B);
+        __syncthreads();                                           // the ring is the transforms' line buffers next
+    } else if constexpr (LD == LOAD_HANDOVER) half_load_AB_pairs_handover<N, E, H16, THREADS>(h0T, descale, omegaT, x, j, par, c, tid, time, reinterpret_cast<float4*>(smem), A, B);
     else half_load_AB_pairs<N, E, H16, THREADS>(h0T, descale, omegaT, x, j, par, tid, time, reinterpret_cast<float4*>(smem), A, B);
     OCEAN_TL(1);
     const c32 kxv = mk(wave_index_q1(x, N), wave_index_q1(x2, N)) * kscale;
@@ -1995,19 +2198,28 @@ template <int N, int PSEL = 0> struct Geo {
 #define OCEAN_HANDOVER_MIN_N 8192
 #endif
     static constexpr bool handover = (N >= OCEAN_HANDOVER_MIN_N) && (P >= 2);
+    // LDS-DMA loader of fused pass 1 (half_load_AB_dma): the inputs streamed through the idle line buffers, no register
+    // staging, every line of the workgroup requested once.  A/B knob: OCEAN_DMA_MIN_N (0 = off).
+#ifndef OCEAN_DMA_MIN_N
+#define OCEAN_DMA_MIN_N 4096
+#endif
+    static constexpr bool dma = (OCEAN_DMA_MIN_N > 0) && (N >= OCEAN_DMA_MIN_N) && (((N / E1) * P) % 64 == 0);
+    static constexpr int loader = dma ? LOAD_DMA : (handover ? LOAD_HANDOVER : LOAD_REGS);
     // Field-parallel pass 1 (k_half_pass1<.., FPAR>): three wave groups per workgroup, one per field, at the latency-bound
     // sizes.  A/B knob: OCEAN_FPAR_MAX_N (0 = off).
 #ifndef OCEAN_FPAR_MAX_N
 #define OCEAN_FPAR_MAX_N 512
 #endif
-    static constexpr bool fpar = (N <= OCEAN_FPAR_MAX_N) && (((N / E1) * P) % 64 == 0) && (3 * (N / E1) * P <= 1024) && !handover;
+    static constexpr bool fpar = (N <= OCEAN_FPAR_MAX_N) && (((N / E1) * P) % 64 == 0) && (3 * (N / E1) * P <= 1024) && !handover && !dma;
     static constexpr int half_threads1 = (N / E1) * P * (fpar ? 3 : 1);   // fused pass 1 (half-spectrum path)
     static constexpr int split_threads1 = (N / E1S) * P;
     static constexpr int line_bytes = LinePitch<N>::elems * (int)sizeof(c32);
     static constexpr int row_lds = ROW_LPW * line_bytes;
     static constexpr int col_lds = COL_LPW * line_bytes;
     static constexpr int frame_lds = P * line_bytes;
-    static constexpr int half_lds1 = P * line_bytes * (fpar ? 3 : 1);
+    static constexpr int max_i(int a, int b) { return a > b ? a : b; }
+    static constexpr int dma_lds1 = DmaRingBytes<dma, N, E1, P, 1>::value;
+    static constexpr int half_lds1 = max_i(P * line_bytes * (fpar ? 3 : 1), dma_lds1);
     static constexpr int row_grid = N / ROW_LPW;
     static constexpr int col_grid = N / COL_LPW;
     static constexpr int frame_grid = N / P;
@@ -2075,7 +2287,7 @@ template <int N, int PSEL = 0> struct Geo {
     static constexpr int stage_grid = N / 4;
     // split geometry (lines as two interleaved N/2 transforms; k_half_pass1_split / k_half_pass2_split)
     static constexpr bool can_split = (P == 2) && (N >= 512);
-    static constexpr int split_lds1 = 2 * P * LinePitch<N / 2>::elems * (int)sizeof(c32);
+    static constexpr int split_lds1 = max_i(2 * P * LinePitch<N / 2>::elems * (int)sizeof(c32), DmaRingBytes<(dma && can_split), N, E1S, P, 2>::value);
     static constexpr int split_lds2 = 2 * LinePitch<N / 2>::elems * (int)sizeof(c32);
     static constexpr int split_threads2 = T;
     // One tile sharded over `world` GPUs (ocean_tile_pass1 / ocean_tile_pass2): rank r owns the half-spectrum columns

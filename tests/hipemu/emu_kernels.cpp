@@ -76,9 +76,9 @@ template <int N, int PSEL> static int run_half_p(const void* h0T, int f16, float
                                                  float4* out, const c32* tw, InterLayout lay, float time, float L) {
     using G = Geo<N, PSEL>;
     if (f16) emu_launch(G::half_grid1, G::half_threads1,
-                        [&] { k_half_pass1<N, G::E1, G::P, true, G::handover, G::fpar>(h0T, descale, omT, inter, nyq, tw, lay, time, L, 0); });
+                        [&] { k_half_pass1<N, G::E1, G::P, true, G::loader, G::fpar>(h0T, descale, omT, inter, nyq, tw, lay, time, L, 0); });
     else emu_launch(G::half_grid1, G::half_threads1,
-                    [&] { k_half_pass1<N, G::E1, G::P, false, G::handover, G::fpar>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L, 0); });
+                    [&] { k_half_pass1<N, G::E1, G::P, false, G::loader, G::fpar>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L, 0); });
     emu_launch(G::half_grid2, G::half_threads2,
                [&] { k_half_pass2<N, G::E2, CHUNK_W, G::R2h, G::p2_group, G::ppar>(inter, out, tw, lay); });
     return 0;
@@ -88,9 +88,9 @@ template <int N, bool I16> static int run_half_split(const void* h0T, int f16, f
     using G = Geo<N, 2>;
     static_assert(G::can_split, "split geometry");
     if (f16) emu_launch(G::half_grid1, G::split_threads1,
-                        [&] { k_half_pass1_split<N, G::E1S, G::P, true, G::handover, I16>(h0T, descale, omT, inter, nyq, tw, lay, time, L, 0, scales); });
+                        [&] { k_half_pass1_split<N, G::E1S, G::P, true, G::loader, I16>(h0T, descale, omT, inter, nyq, tw, lay, time, L, 0, scales); });
     else emu_launch(G::half_grid1, G::split_threads1,
-                    [&] { k_half_pass1_split<N, G::E1S, G::P, false, G::handover, I16>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L, 0, scales); });
+                    [&] { k_half_pass1_split<N, G::E1S, G::P, false, G::loader, I16>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L, 0, scales); });
     emu_launch(N, G::split_threads2, [&] { k_half_pass2_split<N, G::E, CHUNK_W, G::p2_group, false, I16>(inter, out, tw, lay, scales); });
     return 0;
 }
@@ -118,9 +118,9 @@ template <int N, int PSEL> static int run_tile_pass1(int rank, int world, int pa
     const int groups = (N / 2 / world / parts) / G::P;
     const int x_group0 = (rank * parts + part) * groups;
     if (f16) emu_launch(groups, G::half_threads1,
-                        [&] { k_half_pass1<N, G::E1, G::P, true, G::handover, G::fpar>(h0T, descale, omT, send, nyq, tw, lay, time, L, x_group0); });
+                        [&] { k_half_pass1<N, G::E1, G::P, true, G::loader, G::fpar>(h0T, descale, omT, send, nyq, tw, lay, time, L, x_group0); });
     else emu_launch(groups, G::half_threads1,
-                    [&] { k_half_pass1<N, G::E1, G::P, false, G::handover, G::fpar>(h0T, 1.0f, omT, send, nyq, tw, lay, time, L, x_group0); });
+                    [&] { k_half_pass1<N, G::E1, G::P, false, G::loader, G::fpar>(h0T, 1.0f, omT, send, nyq, tw, lay, time, L, x_group0); });
     return 0;
 }
 template <int N, int PSEL> static int run_tile_pass2(int world, int parts, const c32* recv, float4* out, const c32* tw) {

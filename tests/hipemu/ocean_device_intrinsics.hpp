@@ -2,6 +2,7 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 namespace ocean {
 // scalar twin of the device's packed 2-vector complex type and its primitives
 struct c32 { float x, y; };
@@ -40,8 +41,18 @@ static inline float cos_rev(float x) { return (float)std::cos(6.283185307179586 
 static inline void store_float4_nt(float4* p, float4 v) { *p = v; }
 static inline float load_float_nt(const float* p) { return *p; }
 static inline int opaque_after(int x, float) { return x; }
+static inline void pin_here(c32&, c32&) {}
 template <int T> static inline void line_sync() { __syncthreads(); }   // host threads are not a wave: always the full barrier
 static inline void workgroup_publish() { __syncthreads(); }       // the emulation's barrier is a full fence
+// LDS-DMA (half_load_AB_dma): the copy happens at issue, lane by lane; the waits are no-ops and the barrier is the
+// emulation's full barrier, so what is checked here is the ring's index algebra and the barrier protocol's ordering.
+extern unsigned char smem[];
+static inline uint32_t lds_address(const void* p) { return (uint32_t)(reinterpret_cast<const unsigned char*>(p) - smem); }
+template <bool NT> static inline void glds16(const void* base_uniform, uint32_t lane_offset, uint32_t lds_dst_uniform) {
+    std::memcpy(smem + lds_dst_uniform + (threadIdx.x % 64) * 16, reinterpret_cast<const unsigned char*>(base_uniform) + lane_offset, 16);
+}
+template <int K> static inline void dma_wait() {}
+static inline void dma_barrier() { __syncthreads(); }
 // 16-bit block-floating intermediate: the wave reduction through a scratch array and two barriers (every thread of the
 // workgroup calls it, uniformly); pack / unpack as the device's (round to nearest even, saturate).
 extern float g_emu_wave_scratch[16][64];
