@@ -21,27 +21,9 @@
 
 #include <ocean_device_intrinsics.hpp>
 
-// Timing experiments only (results are wrong, never shipped): OCEAN_X_NOBAR=1 drops the write-after-read barriers of the
-// line FFT, =2 drops every barrier inside it -- an upper bound on what a barrier-free (one wave per line) exchange buys.
-// Every OCEAN_X* switch ("wrong results, timing only") exists in -DOCEAN_AB builds alone: a stray -D on the product
-// build is a compile error, not a silently wrong library.
-#if !defined(OCEAN_AB) && (defined(OCEAN_X_NOBAR) || defined(OCEAN_X_NODUP) || defined(OCEAN_X_NOFFT) || defined(OCEAN_X_INTER16) || \
-                           defined(OCEAN_X2_NOLOAD) || defined(OCEAN_X2_NOSTORE) || defined(OCEAN_X2_NOFFT))
-#error "OCEAN_X* switches produce wrong results on purpose (timing ablations): they require -DOCEAN_AB (tools/ab_variants.sh)"
-#endif
 // The exchanges of a line synchronise the threads OF THAT LINE: a workgroup barrier in general; a wave-level fence when
 // the caller guarantees that the T <= 64 threads of a line are T consecutive lanes of one wave (template flag CONTIG of
 // fft_line / fft_line_to_lds; line_sync<T>, ocean_device_intrinsics.hpp).  SYNC_T below is T with CONTIG, "many" without.
-#if defined(OCEAN_X_NOBAR) && OCEAN_X_NOBAR >= 1
-#define OCEAN_FFT_WAR_BARRIER(T) ((void)0)
-#else
-#define OCEAN_FFT_WAR_BARRIER(T) line_sync<T>()
-#endif
-#if defined(OCEAN_X_NOBAR) && OCEAN_X_NOBAR >= 2
-#define OCEAN_FFT_RAW_BARRIER(T) ((void)0)
-#else
-#define OCEAN_FFT_RAW_BARRIER(T) line_sync<T>()
-#endif
 
 namespace ocean {
 
@@ -272,7 +254,7 @@ template <int N, int E, int R, int NS, int TWS = 1, int SYNC_T = 1024, bool HWTW
 __device__ __forceinline__ void fft_pass_exchange(c32 (&reg)[E], int j, const c32* __restrict__ tw, c32* lds_line) {
     constexpr int T = N / E;
     fft_pass<N, E, R, NS, TWS, HWTW>(reg, j, tw, [&](int, int ppos, c32 v, int) { lds_line[ppos] = v; });
-    OCEAN_FFT_RAW_BARRIER(SYNC_T);
+    line_sync<SYNC_T>();   // RAW: the scatter above is visible
     // lds_pad(j + e*T) == lds_pad(j) + e*(T + T/16)   (T is a multiple of 16)
     const c32* g = lds_line + lds_pad(j);
 #pragma unroll
@@ -292,7 +274,7 @@ __device__ __forceinline__ void fft_line(c32 (&reg)[E], int j, const c32* __rest
     (void)ns;
     if constexpr (R0 > 1) {
         fft_pass_exchange<N, E, R0, 1, TWS, SYNC_T, HWTW>(reg, j, tw, lds_line);
-        OCEAN_FFT_WAR_BARRIER(SYNC_T);   // WAR: next scatter reuses the buffer
+        line_sync<SYNC_T>();   // WAR: next scatter reuses the buffer
     }
     constexpr int NS1 = R0;                  // after the optional small pass
     if constexpr (Q == 1) {
@@ -309,7 +291,7 @@ __device__ __forceinline__ void fft_line(c32 (&reg)[E], int j, const c32* __rest
 #pragma unroll
             for (int e = 0; e < E; ++e) reg[e] = out[e];
         } else {
-            OCEAN_FFT_WAR_BARRIER(SYNC_T);
+            line_sync<SYNC_T>();
             fft_pass_exchange<N, E, E, NS2, TWS, SYNC_T, HWTW>(reg, j, tw, lds_line);
             constexpr int NS3 = NS2 * E;
             c32 out[E];
@@ -331,17 +313,17 @@ __device__ __forceinline__ void fft_line_to_lds(c32 (&reg)[E], int j, const c32*
     static_assert(Q >= 2 && Q <= 3, "unsupported N/E combination");
     if constexpr (R0 > 1) {
         fft_pass_exchange<N, E, R0, 1, TWS, SYNC_T, HWTW>(reg, j, tw, lds_line);
-        OCEAN_FFT_WAR_BARRIER(SYNC_T);
+        line_sync<SYNC_T>();
     }
     constexpr int NS1 = R0;
     fft_pass_exchange<N, E, E, NS1, TWS, SYNC_T, HWTW>(reg, j, tw, lds_line);
-    OCEAN_FFT_WAR_BARRIER(SYNC_T);
+    line_sync<SYNC_T>();
     constexpr int NS2 = NS1 * E;
     if constexpr (Q == 2) {
         fft_pass<N, E, E, NS2, TWS, HWTW>(reg, j, tw, [&](int, int ppos, c32 v, int) { lds_line[ppos] = v; });
     } else {
         fft_pass_exchange<N, E, E, NS2, TWS, SYNC_T, HWTW>(reg, j, tw, lds_line);
-        OCEAN_FFT_WAR_BARRIER(SYNC_T);
+        line_sync<SYNC_T>();
         constexpr int NS3 = NS2 * E;
         fft_pass<N, E, E, NS3, TWS, HWTW>(reg, j, tw, [&](int, int ppos, c32 v, int) { lds_line[ppos] = v; });
     }

@@ -74,15 +74,11 @@ struct OceanContext {
     int scale_log2 = 0;
     float* omegaT = nullptr;
     c32* inter = nullptr;
-    InterLayout lay{0, 0, 0, 0};     // three complex fields, all N columns, B = 1   (staged hand-off; OCEAN_ALGO=c2c)
+    InterLayout lay{0, 0, 0, 0};     // three complex fields, all N columns, B = 1   (the staged path's chunked hand-off)
     InterLayout lay_h{0, 0, 0, 0};   // three complex fields, columns 0..N/2-1       (half-spectrum path)
     c32* nyq = nullptr;           // scratch of the half-spectrum path: the Nyquist column's 3 spectra, 3 x N complex
     bool inter16 = false;         // ocean_set_intermediate(OCEAN_INTER_BFP16): int16 intermediate + block scales (N = 8192)
     float* inter_scale = nullptr; // [3][N/64][N/4] block scales of that mode (allocated on first use)
-    bool half = true;             // OCEAN_ALGO=c2c selects the three-complex-transform frame (A/B)
-    bool split = false;           // lines as two interleaved N/2 transforms (N = 8192; OCEAN_SPLIT=0/1 for A/B)
-    int P = 0;                    // chunk width of the c2c path (fixed per N)
-    int Ph = 0;                   // chunk width = lines per pass-1 workgroup of the half-spectrum path (2 or 4)
     c32* tw = nullptr;          // e^{+2 pi i k/N}
     float4* out_own = nullptr;  // displacement map (src/render.rs:820-869), linear RGBA32F
     float4* out = nullptr;      // = out_own or the caller's buffer (ocean_bind_displacement)
@@ -91,7 +87,6 @@ struct OceanContext {
     int32_t position_verts = 0;
     unsigned long long* checksum_acc = nullptr;   // ocean_checksum_displacement
     bool uploaded = false;
-    bool pass2_thin = true;           // OCEAN_PASS2=fat selects the 1024-thread variant (A/B measurements)
     float default_domain = 1000.0f;   // src/render.rs:46
     uint32_t quirks = OCEAN_QUIRKS_REFERENCE;   // ocean_set_quirks
     std::string err;
@@ -149,223 +144,99 @@ template <int N> struct Launch {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, G::col_lds);
         if (e != hipSuccess) return e;
         if constexpr (G::stage_chunked) {
-#ifdef OCEAN_STAGE_ROWS_THIN
-            e = hipFuncSetAttribute((const void*)k_stage_rows_thin<N, G::E, G::ROW_LPW>, hipFuncAttributeMaxDynamicSharedMemorySize, G::row_lds);
-            if (e != hipSuccess) return e;
-#endif
             e = hipFuncSetAttribute((const void*)k_stage_rows<N, G::E>, hipFuncAttributeMaxDynamicSharedMemorySize, G::stage_lds);
             if (e != hipSuccess) return e;
             e = hipFuncSetAttribute((const void*)k_stage_cols<N, G::E>, hipFuncAttributeMaxDynamicSharedMemorySize, G::stage_lds);
             if (e != hipSuccess) return e;
         }
-#ifdef OCEAN_AB   // A/B builds only (tools/ab_variants.sh): the three-complex-transform frame and the other line counts
-        e = hipFuncSetAttribute((const void*)k_frame_pass1<N, G::E, G::P>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, G::frame_lds);
-        if (e != hipSuccess) return e;
-        if constexpr (G::P == 4) {      // the 1024-thread A/B variant owns whole 4 x 4 chunks
-            e = hipFuncSetAttribute((const void*)k_frame_pass2<N, G::E, G::P>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, G::frame_lds);
-            if (e != hipSuccess) return e;
-        }
-        e = hipFuncSetAttribute((const void*)k_frame_pass2_thin<N, G::E, CHUNK_W, G::R2>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, G::thin_lds);
-        if (e != hipSuccess) return e;
-        e = prepare_half<0>();
-        if (e != hipSuccess) return e;
-        if constexpr (N <= 4096) e = prepare_half<2>();
-        return e;
-#else
-        return prepare_half<default_psel()>();
-#endif
+        return prepare_fused();
     }
-    // Lines per pass-1 workgroup of the shipped frame, per size (measured best): 2 where two
-    // co-resident workgroups pay (512, 2048) and where 4 lines do not fit (8192), else 4.
-#ifdef OCEAN_FORCE_P                                                   // A/B knob (tools/ab_variants.sh)
-    static constexpr int default_psel() { return OCEAN_FORCE_P; }
-#elif defined(OCEAN_P_SMALL)                                           // A/B knob: lines per pass-1 workgroup at N <= 1024
-    static constexpr int default_psel() { return (N <= 1024) ? OCEAN_P_SMALL : ((N == 2048 || N > 4096 || CHUNK_W < 4) ? 2 : 4); }
-#elif defined(OCEAN_P_2048)                                            // A/B knob: lines per pass-1 workgroup at N = 2048
-    static constexpr int default_psel() { return (N == 2048) ? OCEAN_P_2048 : ((N == 512 || N > 4096 || CHUNK_W < 4) ? 2 : 4); }
-#elif defined(OCEAN_P_1024)                                            // A/B knob: lines per pass-1 workgroup at N = 1024
-    static constexpr int default_psel() { return (N == 512) ? 1 : ((N == 1024) ? OCEAN_P_1024 : ((N <= 2048 || N > 4096 || CHUNK_W < 4) ? 2 : 4)); }
-#else
-    static constexpr int default_psel() { return (N == 512) ? 1 : ((N <= 2048 || N > 4096 || CHUNK_W < 4) ? 2 : 4); }
-#endif
-    static constexpr bool default_split() { return N > 4096; }
-    // Which (plain, split) kernel pairs exist in this build: everything selectable in an A/B build, only the
-    // size's default in the shipped one (no untested kernel ships).
-#ifdef OCEAN_AB
-    template <int PSEL> static constexpr bool plain_built() { return true; }
-    template <int PSEL> static constexpr bool split_built() { return Geo<N, PSEL>::can_split; }
-#else
-    template <int PSEL> static constexpr bool plain_built() { return !default_split(); }
-    template <int PSEL> static constexpr bool split_built() { return default_split() && Geo<N, PSEL>::can_split; }
-#endif
-    template <int PSEL> static hipError_t prepare_half() {
-        using H = Geo<N, PSEL>;
+    // Lines per pass-1 workgroup of the fused frame, per size (measured best): one column at 512 (the
+    // latency path), two where two co-resident workgroups pay (256, 1024, 2048) and where four lines do not fit the LDS
+    // (8192), four at 4096.  N = 8192 runs the split kernels (every line as two interleaved 4096-point transforms).
+    static constexpr int PSEL = (N == 512) ? 1 : ((N <= 2048 || N > 4096) ? 2 : 4);
+    static constexpr bool SPLIT = N > 4096;
+    using H = Geo<N, PSEL>;
+    static_assert(!SPLIT || H::can_split, "split geometry");
+    // the shipped kernel instances of this size (fp32 / fp16-stored spectrum; split: + the opt-in 16-bit intermediate)
+    template <bool H16> static constexpr auto pass1_kernel() { return k_half_pass1<N, H::E1, H::P, H16, H::dma, H::fpar>; }
+    template <bool H16, bool I16> static constexpr auto pass1_split_kernel() { return k_half_pass1_split<N, H::E1S, H::P, H16, I16>; }
+    template <bool SHARD> static constexpr auto pass2_kernel() { return k_half_pass2<N, H::E2, CHUNK_W, H::R2h, H::p2_group, H::ppar, SHARD>; }
+    template <bool SHARD, bool I16> static constexpr auto pass2_split_kernel() { return k_half_pass2_split<N, H::E, CHUNK_W, H::p2_group, SHARD, I16>; }
+    static hipError_t prepare_fused() {
         hipError_t e = hipSuccess;
-        if constexpr (plain_built<PSEL>()) {
-            e = hipFuncSetAttribute((const void*)k_half_pass1<N, H::E1, H::P, false, H::loader, H::fpar>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, H::half_lds1);
-            if (e != hipSuccess) return e;
-            e = hipFuncSetAttribute((const void*)k_half_pass1<N, H::E1, H::P, true, H::loader, H::fpar>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, H::half_lds1);
-            if (e != hipSuccess) return e;
-            e = hipFuncSetAttribute((const void*)k_half_pass2<N, H::E2, CHUNK_W, H::R2h, H::p2_group, H::ppar>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, H::half_lds2);
-            if (e != hipSuccess) return e;
-            e = hipFuncSetAttribute((const void*)k_half_pass2<N, H::E2, CHUNK_W, H::R2h, H::p2_group, H::ppar, true>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, H::half_lds2);
-            if (e != hipSuccess) return e;
-        }
-        if constexpr (split_built<PSEL>()) {
-            e = hipFuncSetAttribute((const void*)k_half_pass1_split<N, H::E1S, H::P, false, H::loader>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, H::split_lds1);
-            if (e != hipSuccess) return e;
-            e = hipFuncSetAttribute((const void*)k_half_pass1_split<N, H::E1S, H::P, true, H::loader>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, H::split_lds1);
-            if (e != hipSuccess) return e;
-            e = hipFuncSetAttribute((const void*)k_half_pass2_split<N, H::E, CHUNK_W, H::p2_group>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, H::split_lds2);
-            if (e != hipSuccess) return e;
-            e = hipFuncSetAttribute((const void*)k_half_pass2_split<N, H::E, CHUNK_W, H::p2_group, true>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, H::split_lds2);
-            if (e != hipSuccess) return e;
-            e = hipFuncSetAttribute((const void*)k_half_pass2_split<N, H::E, CHUNK_W, H::p2_group, false, true>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, H::split_lds2);
-            if (e != hipSuccess) return e;
-            e = hipFuncSetAttribute((const void*)k_half_pass1_split<N, H::E1S, H::P, false, H::loader, true>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, H::split_lds1);
-            if (e != hipSuccess) return e;
-            e = hipFuncSetAttribute((const void*)k_half_pass1_split<N, H::E1S, H::P, true, H::loader, true>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, H::split_lds1);
+        auto lds = [&](auto kernel, int bytes) {
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        };
+        if constexpr (SPLIT) {
+            lds(pass1_split_kernel<false, false>(), H::split_lds1); lds(pass1_split_kernel<true, false>(), H::split_lds1);
+            lds(pass1_split_kernel<false, true>(), H::split_lds1);  lds(pass1_split_kernel<true, true>(), H::split_lds1);
+            lds(pass2_split_kernel<false, false>(), H::split_lds2); lds(pass2_split_kernel<true, false>(), H::split_lds2);
+            lds(pass2_split_kernel<false, true>(), H::split_lds2);
+        } else {
+            lds(pass1_kernel<false>(), H::half_lds1); lds(pass1_kernel<true>(), H::half_lds1);
+            lds(pass2_kernel<false>(), H::half_lds2); lds(pass2_kernel<true>(), H::half_lds2);
         }
         return e;
     }
-    template <int PSEL> static void half_pass1(OceanContext* c, float time, float domain, hipStream_t s, Timing t) {
-        using H = Geo<N, PSEL>;
-        const float descale = std::ldexp(1.0f, -c->scale_log2);
-        if constexpr (split_built<PSEL>()) {
-            if (c->split) {
-                if (c->inter16) {                                  // opt-in precision mode (ocean_set_intermediate)
-                    if (c->h0_f16)
-                        launch(k_half_pass1_split<N, H::E1S, H::P, true, H::loader, true>, dim3(H::half_grid1), dim3(H::split_threads1),
-                               H::split_lds1, s, t, (const void*)c->h0T, descale, (const float*)c->omegaT, c->inter, c->nyq,
-                               (const c32*)c->tw, c->lay_h, time, domain, 0, c->inter_scale);
-                    else
-                        launch(k_half_pass1_split<N, H::E1S, H::P, false, H::loader, true>, dim3(H::half_grid1), dim3(H::split_threads1),
-                               H::split_lds1, s, t, (const void*)c->h0T, 1.0f, (const float*)c->omegaT, c->inter, c->nyq,
-                               (const c32*)c->tw, c->lay_h, time, domain, 0, c->inter_scale);
-                    return;
-                }
-                if (c->h0_f16)
-                    launch(k_half_pass1_split<N, H::E1S, H::P, true, H::loader>, dim3(H::half_grid1), dim3(H::split_threads1),
-                           H::split_lds1, s, t, (const void*)c->h0T, descale, (const float*)c->omegaT, c->inter, c->nyq,
-                           (const c32*)c->tw, c->lay_h, time, domain, 0, (float*)nullptr);
-                else
-                    launch(k_half_pass1_split<N, H::E1S, H::P, false, H::loader>, dim3(H::half_grid1), dim3(H::split_threads1),
-                           H::split_lds1, s, t, (const void*)c->h0T, 1.0f, (const float*)c->omegaT, c->inter, c->nyq,
-                           (const c32*)c->tw, c->lay_h, time, domain, 0, (float*)nullptr);
-                return;
-            }
-        }
-        if constexpr (plain_built<PSEL>()) {
-#ifdef OCEAN_PASS1_ITERS
-            constexpr int GRID1 = (N == 4096 && !H::fpar && !H::loader) ? H::half_grid1 / OCEAN_PASS1_ITERS : H::half_grid1;
-#else
-            constexpr int GRID1 = H::half_grid1;
-#endif
-            if (c->h0_f16)
-                launch(k_half_pass1<N, H::E1, H::P, true, H::loader, H::fpar>, dim3(GRID1), dim3(H::half_threads1), H::half_lds1, s, t,
-                       (const void*)c->h0T, descale, (const float*)c->omegaT, c->inter, c->nyq, (const c32*)c->tw,
-                       c->lay_h, time, domain, 0);
-            else
-                launch(k_half_pass1<N, H::E1, H::P, false, H::loader, H::fpar>, dim3(GRID1), dim3(H::half_threads1), H::half_lds1, s, t,
-                       (const void*)c->h0T, 1.0f, (const float*)c->omegaT, c->inter, c->nyq, (const c32*)c->tw,
-                       c->lay_h, time, domain, 0);
+    // Fused pass 1 on the column groups [x_group0, x_group0 + groups) of the half spectrum, written in layout `lay` to
+    // `inter` (the context's intermediate for ocean_frame; the all-to-all send buffer of a sharded tile).
+    static void pass1_on(OceanContext* c, float time, float domain, c32* inter, const InterLayout& lay, int groups, int x_group0,
+                         hipStream_t s, Timing t) {
+        const float descale = c->h0_f16 ? std::ldexp(1.0f, -c->scale_log2) : 1.0f;
+        const void* h0T = c->h0T;
+        const float* omT = c->omegaT;
+        const c32* tw = c->tw;
+        if constexpr (SPLIT) {
+            const dim3 g(groups), b(H::split_threads1);
+            float* scales = c->inter16 ? c->inter_scale : nullptr;   // opt-in precision mode (ocean_set_intermediate)
+            if (c->inter16 && c->h0_f16) launch(pass1_split_kernel<true, true>(), g, b, H::split_lds1, s, t, h0T, descale, omT, inter, c->nyq, tw, lay, time, domain, x_group0, scales);
+            else if (c->inter16) launch(pass1_split_kernel<false, true>(), g, b, H::split_lds1, s, t, h0T, descale, omT, inter, c->nyq, tw, lay, time, domain, x_group0, scales);
+            else if (c->h0_f16) launch(pass1_split_kernel<true, false>(), g, b, H::split_lds1, s, t, h0T, descale, omT, inter, c->nyq, tw, lay, time, domain, x_group0, scales);
+            else launch(pass1_split_kernel<false, false>(), g, b, H::split_lds1, s, t, h0T, descale, omT, inter, c->nyq, tw, lay, time, domain, x_group0, scales);
+        } else {
+            const dim3 g(groups), b(H::half_threads1);
+            if (c->h0_f16) launch(pass1_kernel<true>(), g, b, H::half_lds1, s, t, h0T, descale, omT, inter, c->nyq, tw, lay, time, domain, x_group0);
+            else launch(pass1_kernel<false>(), g, b, H::half_lds1, s, t, h0T, descale, omT, inter, c->nyq, tw, lay, time, domain, x_group0);
         }
     }
-    template <int PSEL> static void half_pass2(OceanContext* c, hipStream_t s, Timing t) {
-        using H = Geo<N, PSEL>;
-#ifdef OCEAN_E2_8192   // A/B knob: at N = 8192 the plain pass 2 with 32 elements per thread (256 threads per row) instead of the split one
-        if constexpr (N == 8192) {
-            constexpr int lds = Pitch2<N, 1>::elems * (int)sizeof(c32);
-            static bool prepared = false;
-            if (!prepared) {
-                (void)hipFuncSetAttribute((const void*)k_half_pass2<N, OCEAN_E2_8192, CHUNK_W, 1, H::p2_group>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                prepared = true;
-            }
-            launch(k_half_pass2<N, OCEAN_E2_8192, CHUNK_W, 1, H::p2_group>, dim3(N), dim3(N / OCEAN_E2_8192), lds, s, t,
-                   (const c32*)c->inter, c->out, (const c32*)c->tw, c->lay_h);
-            return;
+    static void pass1(OceanContext* c, float time, float domain, hipStream_t s, Timing t = Timing()) {
+        pass1_on(c, time, domain, c->inter, c->lay_h, H::half_grid1, 0, s, t);
+    }
+    static void pass2(OceanContext* c, hipStream_t s, Timing t = Timing()) {
+        const c32* inter = c->inter;
+        const c32* tw = c->tw;
+        if constexpr (SPLIT) {
+            if (c->inter16) launch(pass2_split_kernel<false, true>(), dim3(N), dim3(H::split_threads2), H::split_lds2, s, t, inter, c->out, tw, c->lay_h, (const float*)c->inter_scale);
+            else launch(pass2_split_kernel<false, false>(), dim3(N), dim3(H::split_threads2), H::split_lds2, s, t, inter, c->out, tw, c->lay_h, (const float*)nullptr);
+        } else {
+            launch(pass2_kernel<false>(), dim3(H::half_grid2), dim3(H::half_threads2), H::half_lds2, s, t, inter, c->out, tw, c->lay_h);
         }
-#endif
-        if constexpr (split_built<PSEL>()) {
-            if (c->split) {
-                if (c->inter16)
-                    launch(k_half_pass2_split<N, H::E, CHUNK_W, H::p2_group, false, true>, dim3(N), dim3(H::split_threads2), H::split_lds2, s, t,
-                           (const c32*)c->inter, c->out, (const c32*)c->tw, c->lay_h, (const float*)c->inter_scale);
-                else
-                    launch(k_half_pass2_split<N, H::E, CHUNK_W, H::p2_group>, dim3(N), dim3(H::split_threads2), H::split_lds2, s, t,
-                           (const c32*)c->inter, c->out, (const c32*)c->tw, c->lay_h, (const float*)nullptr);
-                return;
-            }
-        }
-        if constexpr (plain_built<PSEL>())
-            launch(k_half_pass2<N, H::E2, CHUNK_W, H::R2h, H::p2_group, H::ppar>, dim3(H::half_grid2), dim3(H::half_threads2), H::half_lds2, s, t,
-                   (const c32*)c->inter, c->out, (const c32*)c->tw, c->lay_h);
     }
     // ---- one tile sharded over `world` GPUs (ocean_tile_pass1 / ocean_tile_pass2): the same kernels on this rank's
     // block of half-spectrum columns (pass 1, writing the all-to-all send buffer) and block of rows (pass 2, reading the
     // receive buffer).
-    static bool tile_supported(int world, int parts) {
-        using H = Geo<N, default_psel()>;
-        return H::tile_supported(world, parts);
-    }
+    static bool tile_supported(int world, int parts) { return H::tile_supported(world, parts); }
     static void tile_pass1(OceanContext* c, float time, float domain, int rank, int world, int part, int parts, c32* send, hipStream_t s) {
-        using H = Geo<N, default_psel()>;
-        const InterLayout lay = H::tile_layout(world, parts);
         const int groups = (N / 2 / world / parts) / H::P;
-        const int x_group0 = (rank * parts + part) * groups;
-        const float descale = c->h0_f16 ? std::ldexp(1.0f, -c->scale_log2) : 1.0f;
-        if constexpr (split_built<default_psel()>()) {
-            if (c->h0_f16)
-                hipLaunchKernelGGL((k_half_pass1_split<N, H::E1S, H::P, true, H::loader>), dim3(groups), dim3(H::split_threads1), H::split_lds1, s,
-                                   (const void*)c->h0T, descale, (const float*)c->omegaT, send, c->nyq, (const c32*)c->tw, lay, time, domain, x_group0, (float*)nullptr);
-            else
-                hipLaunchKernelGGL((k_half_pass1_split<N, H::E1S, H::P, false, H::loader>), dim3(groups), dim3(H::split_threads1), H::split_lds1, s,
-                                   (const void*)c->h0T, descale, (const float*)c->omegaT, send, c->nyq, (const c32*)c->tw, lay, time, domain, x_group0, (float*)nullptr);
-        } else {
-            if (c->h0_f16)
-                hipLaunchKernelGGL((k_half_pass1<N, H::E1, H::P, true, H::loader, H::fpar>), dim3(groups), dim3(H::half_threads1), H::half_lds1, s,
-                                   (const void*)c->h0T, descale, (const float*)c->omegaT, send, c->nyq, (const c32*)c->tw, lay, time, domain, x_group0);
-            else
-                hipLaunchKernelGGL((k_half_pass1<N, H::E1, H::P, false, H::loader, H::fpar>), dim3(groups), dim3(H::half_threads1), H::half_lds1, s,
-                                   (const void*)c->h0T, descale, (const float*)c->omegaT, send, c->nyq, (const c32*)c->tw, lay, time, domain, x_group0);
-        }
+        const bool i16 = c->inter16;
+        c->inter16 = false;                                        // (the 16-bit intermediate is not combined with the sharded tile)
+        pass1_on(c, time, domain, send, H::tile_layout(world, parts), groups, (rank * parts + part) * groups, s, Timing());
+        c->inter16 = i16;
     }
     static void tile_pass2(OceanContext* c, int world, int parts, const c32* recv, float4* out_rows, hipStream_t s) {
-        using H = Geo<N, default_psel()>;
         const InterLayout lay = H::tile_layout(world, parts);
         const int rows = N / world;
-        if constexpr (split_built<default_psel()>())
-            hipLaunchKernelGGL((k_half_pass2_split<N, H::E, CHUNK_W, H::p2_group, true>), dim3(rows), dim3(H::split_threads2), H::split_lds2, s,
-                               recv, out_rows, (const c32*)c->tw, lay, (const float*)nullptr);
+        const c32* tw = c->tw;
+        if constexpr (SPLIT)
+            hipLaunchKernelGGL((pass2_split_kernel<true, false>()), dim3(rows), dim3(H::split_threads2), H::split_lds2, s, recv, out_rows, tw, lay, (const float*)nullptr);
         else
-            hipLaunchKernelGGL((k_half_pass2<N, H::E2, CHUNK_W, H::R2h, H::p2_group, H::ppar, true>), dim3(rows / H::R2h), dim3(H::half_threads2),
-                               H::half_lds2, s, recv, out_rows, (const c32*)c->tw, lay);
+            hipLaunchKernelGGL((pass2_kernel<true>()), dim3(rows / H::R2h), dim3(H::half_threads2), H::half_lds2, s, recv, out_rows, tw, lay);
     }
     static void stage_rows(OceanContext* c, int f, hipStream_t s) {
-#ifdef OCEAN_STAGE_ROWS_THIN   // A/B: one row per 256-thread workgroup, 32-byte chunk pieces merged in L2
-        if constexpr (G::stage_chunked && G::T >= 4)
-            hipLaunchKernelGGL((k_stage_rows_thin<N, G::E, G::ROW_LPW>), dim3(G::row_grid), dim3(G::row_threads), G::row_lds, s,
-                               (const c32*)c->field[f], c->cfield[f], (const c32*)c->tw, c->lay);
-#else
         if constexpr (G::stage_chunked)
             hipLaunchKernelGGL((k_stage_rows<N, G::E>), dim3(G::stage_grid), dim3(G::stage_threads), G::stage_lds, s,
                                (const c32*)c->field[f], c->cfield[f], (const c32*)c->tw, c->lay);
-#endif
     }
     static void stage_cols(OceanContext* c, int f, hipStream_t s) {
         if constexpr (G::stage_chunked)
@@ -380,39 +251,6 @@ template <int N> struct Launch {
         hipLaunchKernelGGL((k_fft_lines<N, G::E, G::COL_LPW, true>), dim3(G::col_grid), dim3(G::col_threads),
                            G::col_lds, s, data, c->tw);
     }
-    static void pass1(OceanContext* c, float time, float domain, hipStream_t s, Timing t = Timing()) {
-#ifdef OCEAN_AB
-        if (c->half) {
-            if constexpr (N <= 4096) { if (c->Ph == 2) { half_pass1<2>(c, time, domain, s, t); return; } }
-            half_pass1<0>(c, time, domain, s, t);
-            return;
-        }
-        launch(k_frame_pass1<N, G::E, G::P>, dim3(G::frame_grid), dim3(G::frame_threads), G::frame_lds, s, t,
-               (const c32*)c->h0T, (const float*)c->omegaT, c->inter, (const c32*)c->tw, c->lay, time, domain);
-#else
-        half_pass1<default_psel()>(c, time, domain, s, t);
-#endif
-    }
-    static void pass2(OceanContext* c, hipStream_t s, Timing t = Timing()) {
-#ifdef OCEAN_AB
-        if (c->half) {
-            if constexpr (N <= 4096) { if (c->Ph == 2) { half_pass2<2>(c, s, t); return; } }
-            half_pass2<0>(c, s, t);
-            return;
-        }
-        if constexpr (G::P == 4) {
-            if (!c->pass2_thin) {
-                launch(k_frame_pass2<N, G::E, G::P>, dim3(G::frame_grid), dim3(G::frame_threads), G::frame_lds, s, t,
-                       (const c32*)c->inter, c->out, (const c32*)c->tw, c->lay);
-                return;
-            }
-        }
-        launch(k_frame_pass2_thin<N, G::E, CHUNK_W, G::R2>, dim3(G::thin_grid), dim3(G::thin_threads), G::thin_lds, s, t,
-               (const c32*)c->inter, c->out, (const c32*)c->tw, c->lay);
-#else
-        half_pass2<default_psel()>(c, s, t);
-#endif
-    }
 };
 
 #define OCEAN_DISPATCH(n, STMT)                           \
@@ -425,8 +263,6 @@ template <int N> struct Launch {
         case 8192: { using L = Launch<8192>; STMT; } break; \
         default: break;                                   \
     }
-
-int frame_p(int n) { int p = 0; OCEAN_DISPATCH(n, p = L::G::P); return p; }
 
 hipStream_t pick(OceanContext* c, void* stream) {
     if (stream && (hipStream_t)stream != c->stream) c->foreign_stream = true;
@@ -540,42 +376,26 @@ int32_t ocean_context_create(int32_t device, int32_t resolution, OceanContext** 
     c->generation = g_generation.fetch_add(1);
     DeviceGuard guard(device);
     const size_t n2 = (size_t)resolution * resolution;
-    c->P = frame_p(resolution);
     {
         // Chunks are 4 x 4 complex (128 B); chunk (X, Y) at X*sx + Y*sy, +32 elements
         // (256 B) of padding per slab so that the strided side of the hand-off does not revisit one channel.
         // Pass-2-contiguous: the chunks of one chunk row are adjacent.
-        int bshift = 0, padx = 0;                  // blocks of 2^bshift chunk rows (Geo::inter_bshift: 0 = pass-2-contiguous)
-        OCEAN_DISPATCH(resolution, { bshift = L::G::inter_bshift; padx = L::G::inter_padx; });
-        // lines per pass-1 workgroup of the half-spectrum path: measured best per size (run 14): two
-        // co-resident 2-line workgroups win where the intermediate is cache-resident (512, 2048) and
-        // are the only option at 8192; one 4-line workgroup wins at 4096 (whole-chunk non-temporal stores).
-        OCEAN_DISPATCH(resolution, { c->Ph = L::default_psel(); c->split = L::default_split(); });
-#ifdef OCEAN_AB
-        // A/B builds (tools/ab_variants.sh) read their variant from the environment; the shipped library has no
-        // environment-dependent behaviour.
-        if (const char* v = std::getenv("OCEAN_PASS2")) c->pass2_thin = (std::strcmp(v, "fat") != 0);
-        if (const char* v = std::getenv("OCEAN_INTER_LAYOUT")) { if (std::strcmp(v, "p1") == 0) { bshift = 30; padx = 32; } }   // pass-1-contiguous
-        if (const char* pe = std::getenv("OCEAN_P")) { const int pv = std::atoi(pe); if (pv == 2 || (pv == 4 && resolution <= 4096)) c->Ph = pv; }
-        if (const char* a = std::getenv("OCEAN_ALGO")) c->half = (std::strcmp(a, "c2c") != 0);
-        // N = 8192 = 2 * 16^3 has no three-pass plan: its lines run as two interleaved 4096-point transforms
-        if (const char* sp = std::getenv("OCEAN_SPLIT")) c->split = (std::atoi(sp) != 0) && c->Ph == 2 && resolution >= 512;
-#endif
+        int bshift = 0;                            // blocks of 2^bshift chunk rows (Geo::inter_bshift: 0 = pass-2-contiguous)
+        OCEAN_DISPATCH(resolution, bshift = L::H::inter_bshift);
         // chunk (X, Y) at (Y / B) * sy + X * sx + (Y % B) * 16, B = 2^bshift (ocean_kernels.hpp InterLayout); +32
-        // elements (256 B) per block slab and `padx` per chunk column so that the strided side of the hand-off does not
-        // revisit one channel
-        auto make = [&](size_t columns, int bs, int px) {
+        // elements (256 B) per block slab so that the strided side of the hand-off does not revisit one channel
+        auto make = [&](size_t columns, int bs) {
             const size_t gx = columns / CHUNK_W, gy = (size_t)resolution / CHUNK_R;
             while (((size_t)1 << bs) > gy) --bs;
             const size_t B = (size_t)1 << bs;
             InterLayout l{0, 0, 0, bs};
-            l.sx = B * 16 + (size_t)px;
+            l.sx = B * 16;
             l.sy = gx * l.sx + 32;
             l.fs = l.sy * (gy / B);
             return l;
         };
-        c->lay = make((size_t)resolution, 0, 0);                // staged hand-off and (A/B builds) the three-complex-transform frame
-        c->lay_h = make((size_t)resolution / 2, bshift, padx);  // the fused frame's half-spectrum intermediate
+        c->lay = make((size_t)resolution, 0);                   // the staged path's chunked hand-off
+        c->lay_h = make((size_t)resolution / 2, bshift);  // the fused frame's half-spectrum intermediate
     }
     auto bail = [&](hipError_t err, const char* what) {
         const int32_t code = hip_fail(nullptr, err, what);
@@ -595,11 +415,7 @@ int32_t ocean_context_create(int32_t device, int32_t resolution, OceanContext** 
         for (int f = 0; f < 3; ++f) CTX_TRY(hipMalloc((void**)&c->cfield[f], c->lay.fs * sizeof(c32)));
     CTX_TRY(hipMalloc((void**)&c->h0T, n2 * sizeof(c32)));
     CTX_TRY(hipMalloc((void**)&c->omegaT, n2 * sizeof(float)));
-    #ifdef OCEAN_AB
-    CTX_TRY(hipMalloc((void**)&c->inter, 3 * c->lay.fs * sizeof(c32)));
-#else
     CTX_TRY(hipMalloc((void**)&c->inter, 3 * c->lay_h.fs * sizeof(c32)));
-#endif
     CTX_TRY(hipMalloc((void**)&c->nyq, 3 * (size_t)resolution * sizeof(c32)));
     CTX_TRY(hipMalloc((void**)&c->out_own, n2 * sizeof(float4)));
     CTX_TRY(hipMalloc((void**)&c->tw, (size_t)resolution * sizeof(c32)));
@@ -627,7 +443,7 @@ void ocean_context_destroy(OceanContext* ctx) {
     if (!valid(ctx)) return;
     live_remove(ctx);
     DeviceGuard guard(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)sync_for_readback(ctx);       // frames put on a caller stream may still be using the buffers freed below
     free_all(ctx);
     ctx->magic = 0;
     delete ctx;
@@ -683,7 +499,6 @@ int32_t ocean_upload_spectrum(OceanContext* ctx, const float* h0_re_im, const fl
     return upload_common(ctx, h0_re_im, omega, false);
 }
 int32_t ocean_upload_spectrum_f16(OceanContext* ctx, const float* h0_re_im, const float* omega) {
-    if (valid(ctx) && !ctx->half) return fail(ctx, OCEAN_E_STATE, "fp16 spectrum needs the half-spectrum frame (OCEAN_ALGO=c2c is set)");
     return upload_common(ctx, h0_re_im, omega, true);
 }
 int32_t ocean_spectrum_scale_log2(const OceanContext* ctx) { return valid(ctx) ? ctx->scale_log2 : OCEAN_E_INVALID_ARG; }
@@ -781,7 +596,7 @@ int32_t ocean_frame_ex(OceanContext* ctx, const OceanPropagateLocals* locals, vo
     if (!ctx->uploaded) return fail(ctx, OCEAN_E_STATE, "ocean_upload_spectrum has not been called");
     DeviceGuard guard(ctx->device);
     launch_frame(ctx, locals->time, locals->domain_size, pick(ctx, stream));
-    return check_launch(ctx, "k_frame_pass1/2 launch");
+    return check_launch(ctx, "ocean_frame launch");
 }
 int32_t ocean_set_quirks(OceanContext* ctx, uint32_t quirks) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
@@ -796,7 +611,7 @@ int32_t ocean_set_intermediate(OceanContext* ctx, int32_t mode) {
     if (mode != OCEAN_INTER_F32 && mode != OCEAN_INTER_BFP16) return fail(ctx, OCEAN_E_INVALID_ARG, "unknown intermediate mode");
     if (mode == OCEAN_INTER_BFP16) {
         bool ok = false;
-        OCEAN_DISPATCH(ctx->n, ok = L::template split_built<L::default_psel()>() && ctx->split);
+        OCEAN_DISPATCH(ctx->n, ok = L::SPLIT);
         if (!ok) return fail(ctx, OCEAN_E_UNSUPPORTED_N, "the 16-bit intermediate exists for the split-line kernels only (N = 8192, BASELINE config 5)");
         if (!ctx->inter_scale) {
             DeviceGuard guard(ctx->device);
@@ -865,7 +680,7 @@ int32_t ocean_read_positions(OceanContext* ctx, float* host_xyz1) {
 int32_t ocean_sync(OceanContext* ctx) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
     DeviceGuard guard(ctx->device);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, sync_for_readback(ctx));   // the context stream; the whole device once a dispatch ran on a caller stream
     return OCEAN_OK;
 }
 
@@ -1032,8 +847,7 @@ static int32_t profile_common(OceanContext* ctx, float time, int32_t cap, const 
                                           "k_fft_lines<COL> dx [natural layout, 16-byte pieces: compatibility path, ~1.3 TB/s]",
                                           "k_fft_lines<COL> dy [compatibility path]", "k_fft_lines<COL> dz [compatibility path]", "k_correct"};
     const char* const* kStaged = ctx->stage_chunked ? kChunked : (ctx->n >= 8192 ? kNatural8192 : kNatural);
-    const char* kFused[2] = {ctx->half ? "k_half_pass1" : "k_frame_pass1",
-                             ctx->half ? "k_half_pass2" : (ctx->pass2_thin ? "k_frame_pass2_thin" : "k_frame_pass2")};
+    const char* kFused[2] = {"k_half_pass1", "k_half_pass2"};
     const int count = staged ? 8 : 2;
     if (cap < count) return fail(ctx, OCEAN_E_INVALID_ARG, "capacity too small");
     if (!staged && ctx->quirks != OCEAN_QUIRKS_REFERENCE)
@@ -1076,6 +890,65 @@ static int32_t profile_common(OceanContext* ctx, float time, int32_t cap, const 
     }
     *out_n = count;
     return check_launch(ctx, "profile");
+}
+// `batches` x `frames_per_batch` plain frames back to back on the context stream, one stream event between batches and a
+// single sync at the end: batch_ms[b] = the b-th batch.  What a frame costs in an undisturbed loop, as a distribution
+// (an event per FRAME adds ~5 % of gaps: measured r04_run3, 193 against 185.5 us at N = 4096; one per 10 frames does not).
+int32_t ocean_time_frame_batches(OceanContext* ctx, int32_t batches, int32_t frames_per_batch, float t0, float dt, float* batch_ms) {
+    if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    if (batches <= 0 || batches > 4096 || frames_per_batch <= 0 || !batch_ms) return fail(ctx, OCEAN_E_INVALID_ARG, "batches in [1, 4096], frames_per_batch > 0, batch_ms non-NULL");
+    if (!ctx->uploaded) return fail(ctx, OCEAN_E_STATE, "ocean_upload_spectrum has not been called");
+    DeviceGuard guard(ctx->device);
+    struct Events {
+        std::vector<hipEvent_t> e;
+        ~Events() { for (hipEvent_t x : e) (void)hipEventDestroy(x); }
+    } bag;
+    for (int i = 0; i <= batches; ++i) { hipEvent_t x; HIP_TRY(ctx, hipEventCreate(&x)); bag.e.push_back(x); }
+    HIP_TRY(ctx, hipEventRecord(bag.e[0], ctx->stream));
+    for (int b = 0; b < batches; ++b) {
+        for (int i = 0; i < frames_per_batch; ++i) launch_frame(ctx, t0 + dt * (float)(b * frames_per_batch + i), ctx->default_domain, ctx->stream);
+        HIP_TRY(ctx, hipEventRecord(bag.e[b + 1], ctx->stream));
+    }
+    HIP_TRY(ctx, hipEventSynchronize(bag.e[batches]));
+    for (int b = 0; b < batches; ++b) HIP_TRY(ctx, hipEventElapsedTime(&batch_ms[b], bag.e[b], bag.e[b + 1]));
+    return check_launch(ctx, "ocean_time_frame_batches");
+}
+// Per-frame times of a back-to-back frame loop ("median + p10/p90"): every dispatch carries its own begin/end
+// events (hipExtLaunchKernelGGL: the kernel's timestamps, no extra packets on the stream), read after one sync.
+//   pass1_ms[i], pass2_ms[i]: the two kernels of frame i;   period_ms[i] = begin(pass 1 of frame i + 1) - begin(pass 1 of
+//   frame i), the last entry begin(pass 1) -> end(pass 2) -- in THIS loop, whose event-carrying launches leave larger gaps
+//   than plain ones (ocean_time_frame_batches is the undisturbed loop).
+int32_t ocean_frame_times(OceanContext* ctx, int32_t frames, float t0, float dt, float* pass1_ms, float* pass2_ms, float* period_ms) {
+    if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    if (frames <= 0 || frames > 4096) return fail(ctx, OCEAN_E_INVALID_ARG, "frames must be in [1, 4096]");
+    if (!ctx->uploaded) return fail(ctx, OCEAN_E_STATE, "ocean_upload_spectrum has not been called");
+    if (ctx->quirks != OCEAN_QUIRKS_REFERENCE)
+        return fail(ctx, OCEAN_E_STATE, "the fused kernels implement the reference quirks only (ocean_set_quirks)");
+    DeviceGuard guard(ctx->device);
+    struct Events {
+        std::vector<hipEvent_t> e;
+        hipError_t add(size_t count) {
+            for (size_t i = 0; i < count; ++i) { hipEvent_t x; hipError_t r = hipEventCreate(&x); if (r != hipSuccess) return r; e.push_back(x); }
+            return hipSuccess;
+        }
+        ~Events() { for (hipEvent_t x : e) (void)hipEventDestroy(x); }
+    } bag;
+    HIP_TRY(ctx, bag.add((size_t)frames * 4));
+    hipStream_t s = ctx->stream;
+    for (int i = 0; i < frames; ++i) {
+        hipEvent_t* k = bag.e.data() + (size_t)i * 4;
+        const float time = t0 + dt * (float)i;
+        OCEAN_DISPATCH(ctx->n, L::pass1(ctx, time, ctx->default_domain, s, Timing{k[0], k[1]}));
+        OCEAN_DISPATCH(ctx->n, L::pass2(ctx, s, Timing{k[2], k[3]}));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    for (int i = 0; i < frames; ++i) {
+        hipEvent_t* k = bag.e.data() + (size_t)i * 4;
+        if (pass1_ms) HIP_TRY(ctx, hipEventElapsedTime(&pass1_ms[i], k[0], k[1]));
+        if (pass2_ms) HIP_TRY(ctx, hipEventElapsedTime(&pass2_ms[i], k[2], k[3]));
+        if (period_ms) HIP_TRY(ctx, hipEventElapsedTime(&period_ms[i], k[0], (i + 1 < frames) ? k[4] : k[3]));
+    }
+    return check_launch(ctx, "ocean_frame_times");
 }
 int32_t ocean_profile_frame(OceanContext* ctx, float time, int32_t cap, const char** names, float* ms, int32_t* out_n) {
     return profile_common(ctx, time, cap, names, ms, out_n, false);

@@ -5,17 +5,14 @@
 
 namespace ocean {
 
-// Race hunting (A/B builds only, -DOCEAN_RACE_JITTER): every workgroup barrier of the kernels is wrapped in pseudo-random
+// Race hunting (-DOCEAN_RACE_JITTER): every workgroup barrier of the kernels is wrapped in pseudo-random
 // wave-uniform sleeps (0 .. ~2.7 us, from the low bits of the shader clock), before and after.  The arithmetic is
 // untouched, so a frame of this build must be BIT-identical to the product build's; a missing or misplaced barrier --
 // two waves touching the same LDS words with only "they usually arrive in this order" between them -- shows up as a
 // difference within a few hundred frames (tests/test_gpu_race.py::test_barrier_jitter_build_is_bit_identical).
 // AddressSanitizer for the device is not available on this pool (xnack-, no instrumented runtime:
 // profiles/r03_run16_asan_attempt_log.txt).
-#ifdef OCEAN_RACE_JITTER
-#ifndef OCEAN_AB
-#error "OCEAN_RACE_JITTER is a test build: it requires -DOCEAN_AB"
-#endif
+#ifdef OCEAN_RACE_JITTER   // (a test build: tests/test_gpu_race.py compiles it next to the product and compares checksums)
 __device__ __forceinline__ void race_jitter() {
     const unsigned t = (unsigned)__builtin_readcyclecounter();
     switch ((t >> 2) & 7u) {                                       // wave-uniform (scalar clock)
@@ -49,13 +46,6 @@ __host__ __device__ __forceinline__ c32 yy(c32 a) { return __builtin_shufflevect
 __host__ __device__ __forceinline__ c32 yx(c32 a) { return __builtin_shufflevector(a, a, 1, 0); }
 __host__ __device__ __forceinline__ c32 vfma(c32 a, c32 b, c32 c) { return __builtin_elementwise_fma(a, b, c); }
 
-// Two consecutive complex numbers (16 bytes) / two consecutive packed-half2 spectrum entries (8 bytes) / two floats
-// that are only element-aligned: the structs carry the weaker alignment so that the compiler still emits ONE
-// global_load_dwordx4 / dwordx2 (gfx950 global loads need dword alignment only).
-struct __attribute__((aligned(8))) c32_pair { c32 a, b; };
-struct __attribute__((aligned(4))) u32_pair { uint32_t a, b; };
-struct __attribute__((aligned(4))) f32_pair { float a, b; };
-
 // Returns x unchanged but opaque to GVN/LICM.  The three per-field FFTs of a fused kernel use
 // identical twiddles; without this the compiler keeps ~60 VGPRs of twiddle powers alive across
 // the fields (measured: 195 -> 92 VGPRs for k_frame_pass2<4096>), which spills at the
@@ -68,14 +58,6 @@ __device__ __forceinline__ int opaque_lane(int x) {
 // The two values are computed HERE: an opaque use that keeps the compiler from sinking their arithmetic to a later
 // block (and their inputs alive until then).
 __device__ __forceinline__ void pin_here(c32& a, c32& b) { asm volatile("" : "+v"(a), "+v"(b)); }
-
-// Returns x, but only after `dep` has been computed: orders the loads whose addresses derive from
-// the result behind the arithmetic that produced `dep` (splits a long load phase in two so that
-// the first half's input registers are free before the second half's loads are issued).
-__device__ __forceinline__ int opaque_after(int x, float dep) {
-    asm volatile("" : "+v"(x) : "v"(dep));
-    return x;
-}
 
 // 16-byte store with the non-temporal hint (global_store_dwordx4 ... nt): the intermediate and the
 // displacement map are written once and not re-read by the writing kernel; keeping them from
@@ -147,9 +129,6 @@ __device__ __forceinline__ void ocean_tl_hwid(unsigned long long* slot) {
 #define OCEAN_TL(k)
 #endif
 
-// 4-byte load with the non-temporal hint (read-once streams; see load_omega in ocean_kernels.hpp).
-__device__ __forceinline__ float load_float_nt(const float* p) { return __builtin_nontemporal_load(p); }
-
 // sin / cos of 2*pi*x for x in [-0.5, 0.5] revolutions: the gfx950 transcendental unit
 // (v_sin_f32 / v_cos_f32 take their argument in revolutions).  Measured max abs error on that
 // interval: 1.25e-7 (tools/sincos_acc.hip; ocml's sincospif: 5.2e-8) at 2 instructions instead of ~45.
@@ -193,18 +172,6 @@ __device__ __forceinline__ uint32_t pack_i16x2(c32 v, float inv) {
 }
 __device__ __forceinline__ c32 unpack_i16x2(uint32_t bits, float scale) {
     return mk((float)(short)(bits & 0xFFFFu), (float)((int)bits >> 16)) * scale;
-}
-
-// Static issue priority of this wave (s_setprio, 0..3; wave-uniform argument).  The waves of a workgroup that share
-// a SIMD otherwise move through every barrier-separated phase together (all in VALU, then all in their LDS stores);
-// distinct priorities serialise their VALU phases so that one wave's LDS traffic runs under the others' arithmetic.
-__device__ __forceinline__ void wave_priority(int p) {
-    switch (p & 3) {
-        case 0: __builtin_amdgcn_s_setprio(0); break;
-        case 1: __builtin_amdgcn_s_setprio(1); break;
-        case 2: __builtin_amdgcn_s_setprio(2); break;
-        default: __builtin_amdgcn_s_setprio(3); break;
-    }
 }
 
 // ---- LDS-DMA (global -> LDS without VGPRs): the loader of fused pass 1 at N >= 2048 (half_load_AB_dma) ------------------

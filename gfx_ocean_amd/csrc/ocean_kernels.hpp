@@ -1,31 +1,34 @@
 // ocean_kernels.hpp -- the gfx950 kernels of the gfx-ocean hot path.
 //
-// Staged kernels (1:1 with the reference dispatches, natural layouts, in place):
-//   k_propagate      <- shader/propagate.comp:42-72
-//   k_fft_lines<ROW> <- shader/fft_row.comp:44-63
-//   k_fft_lines<COL> <- shader/fft_col.comp:44-63
-//   k_correct        <- shader/correction.comp:24-35
-// Fused frame (2 launches, 76 B/texel of HBM traffic instead of the reference's 172):
-//   k_frame_pass1: propagate + FFT along y for the three fields, reading the *transposed* static
-//                  inputs (h0T, omegaT; made once at upload) so every line is contiguous;
-//                  writes the intermediate as P x P chunks (128 bytes).
-//   k_frame_pass2_thin (or k_frame_pass2): FFT along x + sign correction + RGBA pack; full-row
-//                  contiguous float4 stores.
-// The column transform runs first in the fused path (a separable 2-D DFT commutes), so that the
-// pass that owns whole rows is the one that writes the row-major RGBA image.
+// Staged kernels (1:1 with the reference dispatches; the compatibility path, include/ocean_hip.h):
+//   k_propagate / k_propagate_paired  <- shader/propagate.comp:42-72
+//   k_fft_lines<ROW>, k_stage_rows    <- shader/fft_row.comp:44-63
+//   k_fft_lines<COL>, k_stage_cols    <- shader/fft_col.comp:44-63
+//   k_correct / k_correct_chunked     <- shader/correction.comp:24-35
+//   k_normals, k_positions            <- shader/ocean.frag:50-66, shader/ocean.vert:21-25
+// Fused frame (ocean_frame: 2 launches, the half-spectrum "real-output" algorithm, 52-54 B/texel of HBM traffic instead of
+// the reference's 172):
+//   k_half_pass1 / k_half_pass1_split (N = 8192): propagate + symmetrise + FFT along y of the half spectrum's columns,
+//                  reading the *transposed* static inputs (h0T, omegaT; made once at upload) so that every line is
+//                  contiguous -- at N >= 2048 streamed through LDS by LDS-DMA (half_load_AB_dma); writes the intermediate
+//                  as 4 x 4 chunks (128 bytes);
+//   k_half_pass2 / k_half_pass2_split: rebuild full rows from the half spectrum, two complex FFTs along x for the three
+//                  real channels, sign correction, RGBA rows.
+// The column transform runs first in the fused path (a separable 2-D DFT commutes), so that the pass that owns whole
+// rows is the one that writes the row-major RGBA image.
+// One tile over several GPUs: the same fused kernels on column / row blocks (x_group0, SHARD) and k_shard_* (row blocks).
 //
-// No launches in this header: it is also compiled by the host emulation harness
-// (tests/hipemu) that checks the index algebra on the CPU.
+// Every kernel in this file ships; measured dead ends live in git history and DESIGN.md 4.3-4.6, not here.
+// No launches in this header: it is also compiled by the host emulation harness (tests/hipemu) that checks the index
+// algebra on the CPU.
 #pragma once
 #include "fft_core.hpp"
 
 namespace ocean {
 
 // Fused kernels at N <= this take the base twiddle of every pass from v_sin/v_cos instead of the table (fft_core.hpp
-// base_twiddle; the reference evaluates cos/sin per butterfly, shader/fft_row.comp:32-33).  A/B knob (0 = table everywhere).
-#ifndef OCEAN_HWTW_MAX_N
-#define OCEAN_HWTW_MAX_N 1024
-#endif
+// base_twiddle; the reference evaluates cos/sin per butterfly, shader/fft_row.comp:32-33): the latency-bound sizes.
+constexpr int HWTW_MAX_N = 1024;
 
 // shader/propagate.comp:6 -- `const float pi = 3.1415926;` (fp32 0x40490FDA)
 #define OCEAN_PI_F 3.1415926f
@@ -294,7 +297,7 @@ struct InterLayout {
 __device__ __forceinline__ size_t tile_slab_offset(const InterLayout& lay, int Xc) {
     const int v = Xc >> lay.xs_shift;
     const int slab = ((v & ((1 << lay.part_bits) - 1)) << lay.rank_bits) | (v >> lay.part_bits);
-    return (size_t)slab * lay.src_stride + (size_t)(Xc & ((1 << lay.xs_shift) - 1)) * lay.sx;
+    return (size_t)slab * lay.src_stride + (size_t)((uint32_t)Xc & ((1u << lay.xs_shift) - 1u)) * lay.sx;
 }
 // Rows of chunks are grouped in blocks of B = 2^bshift: chunk (X, Y) sits at
 //     field * fs + (Y / B) * sy + X * sx + (Y % B) * 16        (elements; 16 = one 128-byte chunk).
@@ -302,7 +305,7 @@ __device__ __forceinline__ size_t tile_slab_offset(const InterLayout& lay, int X
 // scatters single chunks 64 KiB apart); B = N / 4 is pass-1-contiguous (all the chunks of one chunk column adjacent);
 // in between a pass-1 workgroup writes B * 128 contiguous bytes and a pass-2 workgroup finds its row's lines B * 128
 // bytes apart.  Shipped: B = 4 at N >= 2048, B = 1 below (Geo::inter_bshift, measurements there and in DESIGN 4.4).
-// The staged hand-off and the A/B c2c kernels always use B = 1.
+// The staged hand-off always uses B = 1.
 __device__ __forceinline__ size_t chunk_row_offset(const InterLayout& lay, int Y) {
     return (size_t)(Y >> lay.bshift) * lay.sy + (size_t)(Y & ((1 << lay.bshift) - 1)) * (size_t)16;   // one chunk = 16 elements
 }
@@ -310,196 +313,8 @@ __device__ __forceinline__ size_t chunk_row_offset(const InterLayout& lay, int Y
 // chunks, non-temporal stores) or P = 2 lines (the left or right 16 bytes of every chunk row; its
 // neighbour, dispatched in the adjacent slot of the same XCD, writes the other half and the XCD L2
 // merges them into full lines -- plain stores, so that the lines stay in L2 until complete).
-// (Build-time knobs for A/B variants: -DOCEAN_CHUNK_W=2 -DOCEAN_CHUNK_R=8 makes a chunk 2 columns x 8 rows, so that a
-// 2-line pass-1 workgroup owns whole chunks; W * R stays 16 elements = 128 bytes.)
-#ifndef OCEAN_CHUNK_W
-#define OCEAN_CHUNK_W 4
-#endif
-#ifndef OCEAN_CHUNK_R
-#define OCEAN_CHUNK_R 4
-#endif
-constexpr int CHUNK_W = OCEAN_CHUNK_W, CHUNK_R = OCEAN_CHUNK_R;
-static_assert(CHUNK_W * CHUNK_R == 16, "a chunk is one 128-byte line");
-
-// Map block -> x-group so that a group and its mirror (which read the same two h0T line sets)
-// run on the same XCD, 8 blocks apart.
-__device__ __forceinline__ int pass1_group(int b, int groups) {
-    if ((groups & 15) != 0) return b;
-    const int q = b >> 4, r = b & 15;
-    const int p = 8 * q + (r & 7);
-    return (r >> 3) ? (groups - 1 - p) : p;
-}
-
-// Pass 1: propagate + FFT along y of P adjacent columns x = X*P + c for the three fields, reading
-// the transposed static inputs (every line contiguous).  Thread = (c = tid / T, j = tid % T): a
-// wave stays inside one line, so the h0T / omegaT loads are 512-byte contiguous per instruction.
-// The last FFT pass scatters into LDS and the chunks are assembled from there (16-byte lanes,
-// 8 lanes per 128-byte chunk).  [A "column index fastest" mapping that stores chunks straight from
-// registers was measured 10 us slower at N = 4096: 8-byte lanes, 4 lines per wave on the loads.]
-template <int N, int E, int P>
-__global__ void __launch_bounds__((N / E) * P)
-k_frame_pass1(const c32* __restrict__ h0T, const float* __restrict__ omegaT, c32* __restrict__ inter,
-              const c32* __restrict__ tw, InterLayout lay, float time, float domain_size) {
-    constexpr int T = N / E;
-    constexpr int H2 = P / 2;
-    constexpr int CR = CHUNK_R, CW = CHUNK_W;                    // row y of a chunk is y % CR, column x % CW
-    static_assert((2 * T) % CR == 0 && CW % P == 0, "chunk geometry");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    c32* lds = reinterpret_cast<c32*>(smem);
-    const int tid = threadIdx.x;
-    const int c = (T >= 64) ? wave_uniform(tid / T) : (tid / T);   // a wave never straddles lines when T >= 64
-    const int j = tid % T;
-    const int X = pass1_group(blockIdx.x, gridDim.x);
-    const uint32_t x = (uint32_t)(X * P + c);                      // gl_GlobalInvocationID.x
-    c32* lds_line = lds + c * LinePitch<N>::elems;
-
-    // propagate.comp:42-72 along the transposed inputs: own line x, mirror line N-1-x reversed.
-    const c32* own = h0T + (size_t)x * N;
-    const c32* mir = h0T + (size_t)(N - 1 - x) * N;
-    const float* om = omegaT + (size_t)x * N;
-    const float kscale = OCEAN_PI_F / domain_size;                 // k = (pi * float(x)) / L to 1 ulp
-    const float kx = wave_index_q1(x, N) * kscale;
-    c32 hs[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int y = j + e * T;                                   // gl_GlobalInvocationID.y
-        hs[e] = propagate_height(own[y], mir[N - 1 - y], om[y], time);
-    }
-
-    // chunk assembly coordinates: thread -> (column pair h, row y = i + q*2T)
-    const int h = tid % H2;
-    const int i = tid / H2;
-    const c32* l0 = lds + (2 * h) * LinePitch<N>::elems;
-    const c32* l1 = lds + (2 * h + 1) * LinePitch<N>::elems;
-#pragma unroll
-    for (int f = 0; f < 3; ++f) {
-        c32 reg[E];
-        const int jf = opaque_lane(j);   // per-field copy of j: no CSE of twiddles / k_norm across fields
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            if (f == 1) reg[e] = hs[e];
-            else {
-                // k_norm is recomputed per field instead of kept: 2*E fewer live VGPRs
-                const float ky = wave_index_q1((uint32_t)(jf + e * T), N) * kscale;
-                float knx, kny;
-                k_normalised_fast(kx, ky, knx, kny);
-                reg[e] = mul_minus_i_kn((f == 0) ? knx : kny, hs[e]);
-            }
-        }
-        if (f > 0) __syncthreads();                                // previous field's LDS reads done
-        fft_line_to_lds<N, E>(reg, jf, tw, lds_line);              // ends with data in LDS + barrier
-        // row y -> chunk row Y = y / P, r = y % P; (2T) % P == 0 keeps r fixed per thread
-        c32* dst = inter + (size_t)f * lay.fs + (size_t)((X * P) / CW) * lay.sx + (size_t)(i / CR) * lay.sy + (i % CR) * CW +
-                   ((X * P) % CW) + 2 * h;
-#pragma unroll
-        for (int q = 0; q < E / 2; ++q) {
-            const int y = i + q * (2 * T);
-            const c32 v0 = l0[lds_pad(y)];
-            const c32 v1 = l1[lds_pad(y)];
-            float4* o = reinterpret_cast<float4*>(dst + (size_t)q * ((2 * T) / CR) * lay.sy);
-            if constexpr (P == CW) store_float4_nt(o, make_float4(v0.x, v0.y, v1.x, v1.y));
-            else *o = make_float4(v0.x, v0.y, v1.x, v1.y);        // half a chunk row: must meet its other half in L2
-        }
-    }
-}
-
-// Pass 2 ("fat": P rows per workgroup, used for A/B measurements): thread = (r = tid % P, j = tid / P),
-// row index fastest, so 16 lanes read one whole 128-byte chunk and no LDS input exchange is needed.
-template <int N, int E, int P>
-__global__ void __launch_bounds__((N / E) * P)
-k_frame_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32* __restrict__ tw, InterLayout lay) {
-    constexpr int T = N / E;
-    static_assert(T % P == 0, "a thread's elements must keep the same column within a chunk");
-    static_assert(P == CHUNK_W && P == CHUNK_R, "the fat variant owns whole chunks");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    c32* lds = reinterpret_cast<c32*>(smem);
-    const int tid = threadIdx.x;
-    const int r = tid % P;
-    const int j = tid / P;
-    const int Y = blockIdx.x;
-    const int y = Y * P + r;
-    c32* lds_line = lds + r * LinePitch<N>::elems;
-
-    float keep[2][E];
-#pragma unroll
-    for (int f = 0; f < 3; ++f) {
-        const int jf = opaque_lane(j);                             // no twiddle CSE across fields
-        const c32* src = inter + (size_t)f * lay.fs + (size_t)Y * lay.sy + (size_t)(jf / P) * lay.sx + r * P + (jf % P);
-        c32 reg[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) reg[e] = src[(size_t)e * (T / P) * lay.sx];
-        if (f > 0) __syncthreads();                                // previous field's LDS reads done
-        fft_line<N, E>(reg, jf, tw, lds_line);
-        if (f < 2) {
-#pragma unroll
-            for (int e = 0; e < E; ++e) keep[f][e] = reg[e].x;
-        } else {
-            float4* orow = out + (size_t)y * N;
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const int xo = j + e * T;
-                const float s = (((xo + y) & 1) == 0) ? -1.0f : 1.0f;   // correction.comp:29
-                store_float4_nt(orow + xo, make_float4(keep[0][e] * s, keep[1][e] * s, reg[e].x * s, 0.0f));
-            }
-        }
-    }
-}
-
-// Pass 2 ("thin", shipped): R2 rows per workgroup (R2 = 1 at N >= 4096: 256 threads, ~35 KiB LDS,
-// 4 workgroups per CU like k_fft_lines<ROW>), each thread gathering its own row straight from the
-// chunked intermediate (8*P1-byte row of a chunk per P1 lanes).  The (16/P1)/R2 workgroups that
-// share a chunk run on the same XCD in adjacent dispatch slots, so the other rows of a 128-byte
-// line are L2 hits rather than HBM re-reads (measured: +9% fetch over ideal, 270 -> 140 us vs an
-// unmapped grid).  The FFT is fully hidden behind the memory stream here (ablation: removing it
-// does not make the kernel faster).
-template <int N, int E, int P1, int R2>
-__global__ void __launch_bounds__((N / E) * R2)
-k_frame_pass2_thin(const c32* __restrict__ inter, float4* __restrict__ out, const c32* __restrict__ tw, InterLayout lay) {
-    constexpr int T = N / E;
-    static_assert(T % P1 == 0, "a thread's elements must keep the same column within a chunk");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    c32* lds = reinterpret_cast<c32*>(smem);
-    const int tid = threadIdx.x;
-    const int ll = (T >= 64) ? wave_uniform(tid / T) : (tid / T);
-    const int j = tid % T;
-    // block -> row block: sharers of a chunk = S consecutive slots of one XCD (b % 8)
-    constexpr int CR = CHUNK_R;
-    static_assert(P1 == CHUNK_W, "pass 2 reads 4-column chunks");
-    constexpr int S = (CR > R2) ? (CR / R2) : 1;
-    int rb = blockIdx.x;
-    if (S > 1 && (gridDim.x % (8 * S)) == 0) {
-        const int xcd = rb & 7, slot = rb >> 3;
-        rb = ((slot / S) * 8 + xcd) * S + (slot % S);
-    }
-    const int y = rb * R2 + ll;
-    c32* lds_line = lds + ll * LinePitch<N>::elems;
-
-    float keep[2][E];
-#pragma unroll
-    for (int f = 0; f < 3; ++f) {
-        const int jf = opaque_lane(j);                             // no twiddle CSE across fields
-        // element x = jf + e*T: chunk X = x / P1, c = x % P1 (T % P1 == 0); row y: Y = y / P1, r = y % P1
-        const c32* src = inter + (size_t)f * lay.fs + (size_t)(y / CR) * lay.sy + (size_t)(jf / P1) * lay.sx +
-                         (y % CR) * P1 + (jf % P1);
-        c32 reg[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) reg[e] = src[(size_t)e * (T / P1) * lay.sx];
-        if (f > 0) __syncthreads();                                // previous field's LDS reads done
-        fft_line<N, E>(reg, jf, tw, lds_line);
-        if (f < 2) {
-#pragma unroll
-            for (int e = 0; e < E; ++e) keep[f][e] = reg[e].x;
-        } else {
-            float4* orow = out + (size_t)y * N;
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const int xo = j + e * T;
-                const float s = (((xo + y) & 1) == 0) ? -1.0f : 1.0f;   // correction.comp:29
-                store_float4_nt(orow + xo, make_float4(keep[0][e] * s, keep[1][e] * s, reg[e].x * s, 0.0f));
-            }
-        }
-    }
-}
+// (2 x 8 chunks, so that a 2-line workgroup owns whole lines, cost pass 2 more than they gave pass 1: DESIGN 4.4.)
+constexpr int CHUNK_W = 4, CHUNK_R = 4;
 
 // ---------------------------------------------------------------------------------------------
 // Staged path, chunked hand-off (N <= 4096, 4 x 4 chunks)
@@ -542,36 +357,6 @@ k_stage_rows(const c32* __restrict__ nat, c32* __restrict__ chk, const c32* __re
         const c32 v0 = l[lds_pad(x)], v1 = l[lds_pad(x + 1)];
         store_float4_nt(dst + idx, make_float4(v0.x, v0.y, v1.x, v1.y));
     }
-}
-
-// A/B variant of the row pass: ROW_LPW rows per workgroup as k_fft_lines<ROW> (256 threads, 4 workgroups per CU), each row
-// stored as 32-byte pieces of the chunks; the four workgroups that fill a chunk row run in adjacent slots of one XCD
-// and their pieces meet in its L2 (plain stores).
-template <int N, int E, int LPW>
-__global__ void __launch_bounds__((N / E) * LPW)
-k_stage_rows_thin(const c32* __restrict__ nat, c32* __restrict__ chk, const c32* __restrict__ tw, InterLayout lay) {
-    constexpr int T = N / E;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    c32* lds = reinterpret_cast<c32*>(smem);
-    const int tid = threadIdx.x;
-    const int ll = (T >= 64) ? wave_uniform(tid / T) : (tid / T);
-    const int j = tid % T;
-    constexpr int S = (4 > LPW) ? (4 / LPW) : 1;                   // workgroups per chunk row
-    int rb = blockIdx.x;
-    if (S > 1 && (gridDim.x % (8 * S)) == 0) {
-        const int xcd = rb & 7, slot = rb >> 3;
-        rb = ((slot / S) * 8 + xcd) * S + (slot % S);
-    }
-    const int y = rb * LPW + ll;
-    c32* lds_line = lds + ll * LinePitch<N>::elems;
-    c32 reg[E];
-    const c32* src = nat + (size_t)y * N + j;
-#pragma unroll
-    for (int e = 0; e < E; ++e) reg[e] = src[e * T];
-    fft_line<N, E>(reg, j, tw, lds_line);
-    c32* dst = chk + (size_t)(y >> 2) * lay.sy + (size_t)(j >> 2) * lay.sx + (y & 3) * 4 + (j & 3);
-#pragma unroll
-    for (int e = 0; e < E; ++e) dst[(size_t)e * (T / 4) * lay.sx] = reg[e];
 }
 
 template <int N, int E>
@@ -696,219 +481,21 @@ template <bool H16> struct Spec;
 template <> struct Spec<false> {
     typedef c32 elem;
     static __device__ __forceinline__ c32 load(const elem* p, float) { return *p; }
-    static __device__ __forceinline__ void load2(const elem* p, float, c32& a, c32& b) {       // p[0], p[1] in one load
-        const c32_pair v = *reinterpret_cast<const c32_pair*>(p);
-        a = v.a; b = v.b;
-    }
 };
 template <> struct Spec<true> {
     typedef uint32_t elem;
     static __device__ __forceinline__ c32 load(const elem* p, float descale) { return unpack_half2(*p, descale); }
-    static __device__ __forceinline__ void load2(const elem* p, float descale, c32& a, c32& b) {
-        const u32_pair v = *reinterpret_cast<const u32_pair*>(p);
-        a = unpack_half2(v.a, descale); b = unpack_half2(v.b, descale);
-    }
 };
 
-// A = H(y, x), B = conj(H((-y)%N, (-x)%N)) for the E positions of a thread on column x.
-// The dispersion streams are read exactly once per frame and shared with nobody; at the sizes whose working set
-// exceeds the caches (N >= 4096) they are loaded with the non-temporal hint, which keeps them from displacing the
-// spectrum lines that neighbouring columns re-read from the L2 (own/mirror rows: 10 distinct lines per 16
-// requested).  Measured (run 22): pass 1 -5 us / +3% fps at 4096, +1% at 8192, but -2.5% at 2048 where everything
-// stays cache-resident from frame to frame; the hint on ALL loads was +6% slower.
-template <int N>
-__device__ __forceinline__ float load_omega(const float* p) {
-    if constexpr (N >= 4096) return load_float_nt(p);
-    else return *p;
-}
-#define OCEAN_OMEGA_LOAD(p) load_omega<N>(p)
-template <int N, int E, bool H16, int S = 1>
-__device__ __forceinline__ void half_load_AB(const void* __restrict__ h0T_, float descale, const float* __restrict__ omegaT,
-                                             uint32_t x, int j, float time, c32 (&A)[E], c32 (&B)[E], int par = 0) {
-    typedef typename Spec<H16>::elem Sp;
-    constexpr int T = N / (E * S);                                 // threads per (sub-)line; y = S * (jj + e*T) + par
-    const Sp* h0T = reinterpret_cast<const Sp*>(h0T_);
-    const uint32_t x2 = (N - x) & (N - 1);
-    const uint32_t xm = (x - 1u) & (N - 1);
-    const Sp* own = h0T + (size_t)x * N + par;
-    const Sp* mir = h0T + (size_t)(N - 1 - x) * N - par;
-    const Sp* own2 = h0T + (size_t)x2 * N - par;
-    const Sp* mir2 = h0T + (size_t)xm * N + par;
-    const float* om = omegaT + (size_t)x * N + par;
-    const float* om2 = omegaT + (size_t)x2 * N - par;
-    // LOAD_BATCHES batches: a batch's 6 loads per element are issued only after the previous batch's
-    // inputs have been consumed (otherwise 16 x 10 input VGPRs are live at once next to A and B and
-    // the kernel spills at the 128-VGPR budget of a 1024-thread workgroup; a spill reload in the
-    // load phase also drains every outstanding global load, vmcnt being in-order)
-    // (N <= 1024: the frame is latency-bound and a thread has half the elements and no register pressure -- one batch:
-    // the four dependent rounds of L2 latency were 1.1 us of a 3.7 us workgroup at N = 512, timeline r03)
-#ifndef OCEAN_ONE_BATCH_MAX_N
-#define OCEAN_ONE_BATCH_MAX_N 1024
-#endif
-    constexpr int LOAD_BATCHES = (N <= OCEAN_ONE_BATCH_MAX_N) ? 1 : 4;   // measured: 2 and 8 spill more; issuing a batch ahead: +8 us
-    constexpr int PER = E / LOAD_BATCHES;
-    int jj = j;
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        if (e > 0 && (e % PER) == 0) jj = opaque_after(j, A[e - 1].x + B[e - 1].y);
-        // y = S*(jj + e*T) + par.  Every address is written as (uniform base + e-dependent constant)[small lane
-        // index] so that the six streams share three lane offsets and the bases stay in SGPRs; only e == 0 can
-        // hit the wrap of y2 = (N - y) % N and ym = (y - 1) % N (at y == 0).
-        const c32 a = Spec<H16>::load((own + S * e * T) + S * jj, descale);
-        const c32 m = Spec<H16>::load((mir + (N - 1 - S * (e + 1) * T + S)) + S * (T - 1 - jj), descale);   // mir[N - 1 - y]
-        const float w = OCEAN_OMEGA_LOAD((om + S * e * T) + S * jj);
-        c32 a2, m2;
-        float w2;
-        if (e == 0) {
-            const int y0 = S * jj + par;
-            const int y2 = (N - y0) & (N - 1);
-            const int ym = (y0 - 1) & (N - 1);
-#ifdef OCEAN_X_NODUP   // timing experiment only (wrong results): the two streams that re-read lines another wave of the
-                       // workgroup loads (own2 of column c+1 = mirror of c, mirror2 of c+1 = own of c) are not loaded
-            (void)ym; a2 = m; m2 = a;
-#else
-            a2 = Spec<H16>::load(h0T + (size_t)x2 * N + y2, descale);
-            m2 = Spec<H16>::load(h0T + (size_t)xm * N + ym, descale);
-#endif
-            w2 = OCEAN_OMEGA_LOAD((omegaT + (size_t)x2 * N) + y2);
-        } else {
-#ifdef OCEAN_X_NODUP
-            a2 = m; m2 = a;
-#else
-            a2 = Spec<H16>::load((own2 + (N - S * (e + 1) * T)) + S * (T - jj), descale);   // own2[N - y]
-            m2 = Spec<H16>::load((mir2 + (S * e * T - 1)) + S * jj, descale);               // mir2[y - 1]
-#endif
-            w2 = OCEAN_OMEGA_LOAD((om2 + (N - S * (e + 1) * T)) + S * (T - jj));
-        }
-        A[e] = propagate_height(a, m, w, time);
-        const c32 h2 = propagate_height(a2, m2, w2, time);
-        B[e] = cconj(h2);
-    }
-}
-
-// half_load_AB with the intra-workgroup duplicate streams handed over through LDS instead of re-read from memory.
-// Column x + 1 of a workgroup asks for two lines its left neighbour x asks for as well:
-//     own2 (x + 1) = h0T[N - x - 1][.] = mirror (x),      mirror2 (x + 1) = h0T[x][.] = own (x),
-// displaced by one element:  a2(c, y) = m(c - 1, (y - 1) % N),   m2(c, y) = a(c - 1, (y - 1) % N)
-// (a = own[y], m = mirror[N - 1 - y] as loaded by the thread of column c - 1 that sits at position y - 1).  In the
-// lock-step load phase of 256 one-per-CU workgroups those twin requests are issued within a microsecond of each other
-// and mostly miss the L2 together (counters, DESIGN 4.4: 269 MB fetched where the distinct lines of the workgroups are
-// 235 MB; at N = 8192 every line twice).  The LDS is idle during the load phase, so, per load batch of PER elements:
-//   * columns 0 .. P-2 park (a, m) of their elements (16 bytes each) in region c + 1 of a batch buffer, one slot to the
-//     right of their own position;
-//   * region 0 is column 0's left neighbour, which lives in another workgroup: all threads of the workgroup together
-//     load the batch's stretch of its two lines (own2 / mirror2 of column 0: one pair per thread when PER == P);
-//   * ONE barrier; then every column reads (m2, a2) of its PER elements from its region -- no column-dependent control
-//     flow (branches around the loads cost 25-50 spilled VGPRs at the 128-register budget of this kernel).
-// Slot 0 of regions 1 .. P-1 is position y0 - 1 of the line, which belongs to the previous batch (to the end of the
-// line for y0 = 0): lane j == 0 takes that pair from memory -- a wave-uniform address, i.e. a scalar load.
-// Two batch buffers make one barrier per batch enough: batch b + 2 overwrites buffer b & 1 only after barrier b + 1,
-// which every thread reaches after its reads of batch b.
-template <int N, int E, int P, bool H16>
-__device__ __forceinline__ void half_load_AB_handover(const void* __restrict__ h0T_, float descale, const float* __restrict__ omegaT,
-                                                      uint32_t x, int c, int j, int tid, float time, float4* xbuf,
-                                                      c32 (&A)[E], c32 (&B)[E]) {
-    typedef typename Spec<H16>::elem Sp;
-    constexpr int T = N / E;
-    const Sp* h0T = reinterpret_cast<const Sp*>(h0T_);
-    const uint32_t x0 = x - (uint32_t)c;                           // the workgroup's first column
-    const uint32_t x2 = (N - x) & (N - 1);
-    const uint32_t xm = (x - 1u) & (N - 1);
-    const Sp* own = h0T + (size_t)x * N;
-    const Sp* mir = h0T + (size_t)(N - 1 - x) * N;
-    const Sp* nb_own2 = h0T + (size_t)((N - x0) & (N - 1)) * N;    // column 0's own2 and mirror2 lines (region 0)
-    const Sp* nb_mir2 = h0T + (size_t)((x0 - 1u) & (N - 1)) * N;
-    const float* om = omegaT + (size_t)x * N;
-    const float* om2 = omegaT + (size_t)x2 * N;
-    constexpr int LOAD_BATCHES = 4;
-    constexpr int PER = E / LOAD_BATCHES;
-    constexpr int SPAN = PER * T;                                  // positions of a line per batch
-    constexpr int THREADS = P * T;
-    constexpr int REG = SPAN + 4;                                  // slots per region (+1 for the shift, padded)
-    constexpr int BUF = P * REG;                                   // one batch buffer
-    static_assert(2 * BUF * (int)sizeof(float4) <= P * LinePitch<N>::elems * (int)sizeof(c32), "hand-over buffers fit the line buffers");
-    static_assert(SPAN % THREADS == 0 || THREADS % SPAN == 0, "region 0 is loaded by whole rounds of the workgroup");
-    constexpr int NB_ROUNDS = (SPAN + THREADS - 1) / THREADS;
-    // Software-pipelined by one batch: the loads of batch b + 1 are issued before the barrier of batch b (behind the
-    // arithmetic that frees batch b's own / mirror / omega registers), so that the memory system is never left without
-    // requests while the workgroup meets at a barrier.
-    c32 a[PER], m[PER];
-    float w[PER], w2[PER];
-    c32 nb_n2[NB_ROUNDS], nb_o2[NB_ROUNDS];
-    auto issue = [&](int b, int jq, int tq) {
-#pragma unroll
-        for (int t = 0; t < PER; ++t) {
-            const int e = b * PER + t;
-            a[t] = Spec<H16>::load((own + e * T) + jq, descale);
-            m[t] = Spec<H16>::load((mir + (N - 1 - (e + 1) * T + 1)) + (T - 1 - jq), descale);   // mir[N - 1 - y]
-            w[t] = OCEAN_OMEGA_LOAD((om + e * T) + jq);
-        }
-        // region 0: (m2, a2) of column 0 at positions y0 + k, k < SPAN
-#pragma unroll
-        for (int r = 0; r < NB_ROUNDS; ++r) {
-            const int y = b * SPAN + tq + r * THREADS;
-            nb_n2[r] = Spec<H16>::load(nb_mir2 + ((y - 1) & (N - 1)), descale);    // mirror2[y - 1]
-            nb_o2[r] = Spec<H16>::load(nb_own2 + ((N - y) & (N - 1)), descale);    // own2[N - y]
-        }
-    };
-    auto issue_w2 = [&](int b, int jq) {
-#pragma unroll
-        for (int t = 0; t < PER; ++t) {
-            const int e = b * PER + t;
-            if (e == 0) w2[t] = OCEAN_OMEGA_LOAD((omegaT + (size_t)x2 * N) + ((N - jq) & (N - 1)));   // y may be 0: (N - y) % N wraps
-            else w2[t] = OCEAN_OMEGA_LOAD((om2 + (N - (e + 1) * T)) + (T - jq));
-        }
-    };
-    issue(0, j, tid);
-    issue_w2(0, j);
-#pragma unroll
-    for (int b = 0; b < LOAD_BATCHES; ++b) {
-        const int y0 = b * SPAN;                                   // a constant per unrolled batch
-        float4* buf = xbuf + (b & 1) * BUF;
-#pragma unroll
-        for (int r = 0; r < NB_ROUNDS; ++r) {
-            const int k = tid + r * THREADS;
-            if (SPAN % THREADS == 0 || k < SPAN) buf[k] = make_float4(nb_n2[r].x, nb_n2[r].y, nb_o2[r].x, nb_o2[r].y);
-        }
-        // slot 0 of the other regions (position y0 - 1 of the left neighbour's lines)
-        const c32 edge_a2 = Spec<H16>::load(h0T + (size_t)x2 * N + ((N - y0) & (N - 1)), descale);
-        const c32 edge_m2 = Spec<H16>::load(h0T + (size_t)xm * N + ((y0 - 1) & (N - 1)), descale);
-        if (c < P - 1) {                                           // stores only: nothing is defined inside the branch
-            float4* dst = buf + (c + 1) * REG + 1 + j;
-#pragma unroll
-            for (int t = 0; t < PER; ++t) dst[t * T] = make_float4(a[t].x, a[t].y, m[t].x, m[t].y);
-        }
-#pragma unroll
-        for (int t = 0; t < PER; ++t) A[b * PER + t] = propagate_height(a[t], m[t], w[t], time);   // frees a, m, w
-        float w2c[PER];
-#pragma unroll
-        for (int t = 0; t < PER; ++t) w2c[t] = w2[t];
-        if (b + 1 < LOAD_BATCHES) {                                // next batch's loads, behind this batch's arithmetic
-            const float dep = A[b * PER + PER - 1].x + A[b * PER].y;
-            issue(b + 1, opaque_after(j, dep), opaque_after(tid, dep));
-        }
-        __syncthreads();
-        const float4* src = buf + c * REG + j;
-        const bool edge = (j == 0) && (c > 0);                     // region 0 holds column 0's true left neighbour, unshifted
-#pragma unroll
-        for (int t = 0; t < PER; ++t) {
-            const float4 v = src[t * T];
-            c32 m2 = mk(v.x, v.y), a2 = mk(v.z, v.w);
-            if (t == 0) { m2 = edge ? edge_m2 : m2; a2 = edge ? edge_a2 : a2; }
-            B[b * PER + t] = cconj(propagate_height(a2, m2, w2c[t], time));
-        }
-        if (b + 1 < LOAD_BATCHES) issue_w2(b + 1, opaque_after(j, B[b * PER + PER - 1].y));
-    }
-}
-
-// A/B variant of half_load_AB (whole lines, S = 1): every line of the spectrum is asked for twice within a microsecond --
-// own[x + c] by wave group c and mirror2 of column x + c + 1 by wave group c + 1 (the next workgroup for c = 3), likewise
-// mirror / own2 -- and most of those pairs miss the L2 together.  Here the second-use streams (own2,
-// mirror2 and their dispersion stream) trail the first-use streams (own, mirror) by one load batch, so that the line is
-// in the L2 when it is asked for again.  One more stage in the batch chain (LOAD_BATCHES + 1).
+// A = H(y, x), B = conj(H((-y)%N, (-x)%N)) for the E positions y = j + e T of a thread on column x, straight into
+// registers: the loader of the latency-bound sizes (N <= 1024; Geo::dma selects half_load_AB_dma above that), where the
+// working set is cache-resident, a thread has 8 elements and all 6 x 8 loads are issued at once (four dependent batches
+// were 1.1 us of a 3.7 us workgroup at N = 512, timeline r03).  Every address is written as (uniform base + e-dependent
+// constant)[small lane index], so that the six streams share three lane offsets and the bases stay in SGPRs; only
+// e == 0 can hit the wrap of y2 = (N - y) % N and ym = (y - 1) % N (at y == 0).
 template <int N, int E, bool H16>
-__device__ __forceinline__ void half_load_AB_skewed(const void* __restrict__ h0T_, float descale, const float* __restrict__ omegaT,
-                                                    uint32_t x, int j, float time, c32 (&A)[E], c32 (&B)[E]) {
+__device__ __forceinline__ void half_load_AB(const void* __restrict__ h0T_, float descale, const float* __restrict__ omegaT,
+                                             uint32_t x, int j, float time, c32 (&A)[E], c32 (&B)[E]) {
     typedef typename Spec<H16>::elem Sp;
     constexpr int T = N / E;
     const Sp* h0T = reinterpret_cast<const Sp*>(h0T_);
@@ -920,52 +507,26 @@ __device__ __forceinline__ void half_load_AB_skewed(const void* __restrict__ h0T
     const Sp* mir2 = h0T + (size_t)xm * N;
     const float* om = omegaT + (size_t)x * N;
     const float* om2 = omegaT + (size_t)x2 * N;
-    constexpr int LOAD_BATCHES = 4;
-    constexpr int PER = E / LOAD_BATCHES;
-    int jj = j;
-    float dep = 0.0f;
 #pragma unroll
-    for (int b = 0; b <= LOAD_BATCHES; ++b) {
-        if (b > 0) jj = opaque_after(j, dep);
-        c32 a[PER], m[PER], a2[PER], m2[PER];
-        float w[PER], w2[PER];
-        if (b < LOAD_BATCHES) {
-#pragma unroll
-            for (int t = 0; t < PER; ++t) {
-                const int e = b * PER + t;
-                a[t] = Spec<H16>::load((own + e * T) + jj, descale);
-                m[t] = Spec<H16>::load((mir + (N - 1 - (e + 1) * T + 1)) + (T - 1 - jj), descale);   // mir[N - 1 - y]
-                w[t] = OCEAN_OMEGA_LOAD((om + e * T) + jj);
-            }
+    for (int e = 0; e < E; ++e) {
+        const c32 a = Spec<H16>::load((own + e * T) + j, descale);
+        const c32 m = Spec<H16>::load((mir + (N - (e + 1) * T)) + (T - 1 - j), descale);   // mir[N - 1 - y]
+        const float w = ((om + e * T))[j];
+        c32 a2, m2;
+        float w2;
+        if (e == 0) {
+            const int y2 = (N - j) & (N - 1);
+            const int ym = (j - 1) & (N - 1);
+            a2 = Spec<H16>::load(own2 + y2, descale);
+            m2 = Spec<H16>::load(mir2 + ym, descale);
+            w2 = om2[y2];
+        } else {
+            a2 = Spec<H16>::load((own2 + (N - (e + 1) * T)) + (T - j), descale);           // own2[N - y]
+            m2 = Spec<H16>::load((mir2 + (e * T - 1)) + j, descale);                       // mir2[y - 1]
+            w2 = ((om2 + (N - (e + 1) * T)))[T - j];
         }
-        if (b >= 1) {
-#pragma unroll
-            for (int t = 0; t < PER; ++t) {
-                const int e = (b - 1) * PER + t;
-                if (e == 0) {                                      // y may be 0: (N - y) % N and (y - 1) % N wrap
-                    const int y2 = (N - jj) & (N - 1);
-                    const int ym = (jj - 1) & (N - 1);
-                    a2[t] = Spec<H16>::load(h0T + (size_t)x2 * N + y2, descale);
-                    m2[t] = Spec<H16>::load(h0T + (size_t)xm * N + ym, descale);
-                    w2[t] = OCEAN_OMEGA_LOAD((omegaT + (size_t)x2 * N) + y2);
-                } else {
-                    a2[t] = Spec<H16>::load((own2 + (N - (e + 1) * T)) + (T - jj), descale);   // own2[N - y]
-                    m2[t] = Spec<H16>::load((mir2 + (e * T - 1)) + jj, descale);               // mir2[y - 1]
-                    w2[t] = OCEAN_OMEGA_LOAD((om2 + (N - (e + 1) * T)) + (T - jj));
-                }
-            }
-        }
-        dep = 0.0f;
-        if (b < LOAD_BATCHES) {
-#pragma unroll
-            for (int t = 0; t < PER; ++t) A[b * PER + t] = propagate_height(a[t], m[t], w[t], time);
-            dep += A[b * PER + PER - 1].x;
-        }
-        if (b >= 1) {
-#pragma unroll
-            for (int t = 0; t < PER; ++t) B[(b - 1) * PER + t] = cconj(propagate_height(a2[t], m2[t], w2[t], time));
-            dep += B[(b - 1) * PER + PER - 1].y;
-        }
+        A[e] = propagate_height(a, m, w, time);
+        B[e] = cconj(propagate_height(a2, m2, w2, time));
     }
 }
 
@@ -997,11 +558,7 @@ __device__ __forceinline__ void half_load_AB_skewed(const void* __restrict__ h0T
 template <int N, int E, int P, bool H16, int S>
 struct DmaRing {
     static constexpr int TS = N / (S * E);                         // threads per (sub-)line
-#ifndef OCEAN_DMA_Q
-#define OCEAN_DMA_Q 1
-#endif
-    static constexpr int QMIN = (S * TS >= 256) ? 1 : 256 / (S * TS);   // a dispersion segment is at least one 1 KiB instruction
-    static constexpr int Q = (OCEAN_DMA_Q > QMIN) ? OCEAN_DMA_Q : QMIN;   // elements per thread and piece
+    static constexpr int Q = (S * TS >= 256) ? 1 : 256 / (S * TS); // elements per thread and piece (a dispersion segment is >= one 1 KiB instruction)
     static constexpr int L = S * TS * Q;                           // positions of a line per piece
     static constexpr int NP = E / Q;                               // pieces
     static constexpr int SPB = H16 ? 4 : 8;                        // bytes per spectrum texel
@@ -1016,11 +573,9 @@ struct DmaRing {
     static constexpr int SPW = (SLOTS + WAVES - 1) / WAVES;        // ... per wave (the first SLOTS % WAVES waves when uneven)
     static constexpr int REM = SLOTS % WAVES;
     static constexpr int BASE = SLOTS / WAVES;
-#ifndef OCEAN_DMA_DEPTH
-#define OCEAN_DMA_DEPTH 4
-#endif
-    static constexpr int D = (NP < OCEAN_DMA_DEPTH) ? (NP < 2 ? 2 : NP) : OCEAN_DMA_DEPTH;   // ring slots (>= 2: the protocol below)
-    static_assert(OCEAN_DMA_DEPTH >= 2, "the ring needs two slots");
+    // ring slots: 4 (2-3 pieces in flight while one is consumed; measured r04_run1 at N = 4096 / 8192: 3, 4, 5 slots and
+    // 2 slots of double pieces within the noise of each other, so the depth is not what bounds the load phase)
+    static constexpr int D = (NP < 4) ? (NP < 2 ? 2 : NP) : 4;
     static constexpr int bytes = D * PIECE;
     static_assert(E % Q == 0 && SEG_H % 1024 == 0 && SEG_W % 1024 == 0 && (P * S * TS) % 64 == 0, "DMA ring geometry");
 };
@@ -1049,19 +604,13 @@ __device__ __forceinline__ void half_load_AB_dma(const void* __restrict__ h0T_, 
 #pragma unroll
     for (int k = 0; k < R::SPW; ++k) {
         const int byte = (wave + k * R::WAVES) * 1024;             // offset within the piece = offset within its LDS image
-#ifdef OCEAN_X_NODUP   // timing experiment only (wrong results): the left neighbour's two lines (k = 0) are not asked for -- an
-                       // upper bound on what keeping the inter-workgroup duplicates out of the memory system can buy
-#define OCEAN_DMA_LINE_K(k) (((k) == 0) ? 1 : (k))
-#else
-#define OCEAN_DMA_LINE_K(k) (k)
-#endif
         if (byte < R::OFF_OWN) {
-            const uint32_t line = (uint32_t)(N - (int)x0 - OCEAN_DMA_LINE_K(byte / R::SEG_H)) & (uint32_t)(N - 1);
+            const uint32_t line = (uint32_t)(N - (int)x0 - byte / R::SEG_H) & (uint32_t)(N - 1);
             src0[k] = h0T + ((size_t)line * N + (N - L)) * R::SPB + (byte % R::SEG_H);
             step[k] = -R::SEG_H; stream_once[k] = false;
         } else if (byte < R::OFF_OM2) {
             const int bb = byte - R::OFF_OWN;
-            const uint32_t line = (uint32_t)((int)x0 - 1 + OCEAN_DMA_LINE_K(bb / R::SEG_H)) & (uint32_t)(N - 1);
+            const uint32_t line = (uint32_t)((int)x0 - 1 + bb / R::SEG_H) & (uint32_t)(N - 1);
             src0[k] = h0T + (size_t)line * N * R::SPB + (bb % R::SEG_H);
             step[k] = R::SEG_H; stream_once[k] = false;
         } else if (byte < R::OFF_OM) {
@@ -1082,12 +631,9 @@ __device__ __forceinline__ void half_load_AB_dma(const void* __restrict__ h0T_, 
                 const char* src = src0[k] + (ptrdiff_t)b * step[k];
                 const uint32_t dst = ring_lds + (uint32_t)((b % D) * R::PIECE + (wave + k * R::WAVES) * 1024);
                 // the dispersion lines are read once per frame by one workgroup: non-temporal where the working set exceeds the caches
-#ifndef OCEAN_DMA_NT
-#define OCEAN_DMA_NT 1                                              // A/B knob: 0 = no hint, 1 = the dispersion lines, 2 = everything
-#endif
-                if constexpr (OCEAN_DMA_NT == 2) glds16<true>(src, lane16, dst);
-                else if constexpr (OCEAN_DMA_NT == 0) glds16<false>(src, lane16, dst);
-                else if (N >= 4096 && stream_once[k]) glds16<true>(src, lane16, dst);
+                // (measured r04_run1, pass 1 at N = 4096: the hint on nothing +6 us, on everything +6 us; run 22 of round 1
+                //  found the same for plain loads, and -2.5 % at 2048 where everything stays cache-resident)
+                if (N >= 4096 && stream_once[k]) glds16<true>(src, lane16, dst);
                 else glds16<false>(src, lane16, dst);
             }
         }
@@ -1215,10 +761,9 @@ template <int E> constexpr int pass1_waves_per_simd(int threads) {
 // other.  At N = 512 a workgroup is two waves on a CU with four SIMDs and every instruction's latency is exposed
 // (timeline r03_run4: load 1.0 us, then 1.45 + 1.0 + 1.3 us of transforms, 3 x 0.2 us of stores): the three
 // transforms now run side by side.
-// LD: how the inputs arrive -- LOAD_REGS (half_load_AB), LOAD_HANDOVER (+ the duplicate streams through LDS), LOAD_DMA
-// (half_load_AB_dma: streamed through the idle line buffers by LDS-DMA).
-constexpr int LOAD_REGS = 0, LOAD_HANDOVER = 1, LOAD_DMA = 2;
-template <int N, int E, int P, bool H16, int LD = LOAD_REGS, bool FPAR = false>
+// DMA: the inputs are streamed through the idle line buffers by LDS-DMA (half_load_AB_dma, N >= 2048) instead of loaded
+// into registers (half_load_AB).
+template <int N, int E, int P, bool H16, bool DMA = false, bool FPAR = false>
 __global__ void __launch_bounds__((N / E) * P * (FPAR ? 3 : 1), pass1_waves_per_simd<E>((N / E) * P * (FPAR ? 3 : 1)))
 k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restrict__ omegaT, c32* __restrict__ inter,
              c32* nyq_spec, const c32* __restrict__ tw, InterLayout lay, float time, float domain_size, int x_group0) {
@@ -1227,9 +772,7 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
     constexpr int H2 = P / 2;
     constexpr int CR = CHUNK_R, CW = CHUNK_W;                    // row y of a chunk is y % CR, column x % CW
     static_assert((2 * T) % CR == 0 && CW % P == 0, "chunk geometry");
-    constexpr bool HAND = (LD == LOAD_HANDOVER);
-    static_assert(!FPAR || (GT % 64 == 0 && LD == LOAD_REGS), "a field group is whole waves");
-    static_assert(P > 1 || !HAND, "the hand-over needs a left neighbour inside the workgroup");
+    static_assert(!FPAR || (GT % 64 == 0 && !DMA), "a field group is whole waves");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     c32* lds = reinterpret_cast<c32*>(smem);
     const int tid = threadIdx.x;
@@ -1241,49 +784,21 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
     c32* lds_line = lds_grp + c * LinePitch<N>::elems;
     const float kscale = OCEAN_PI_F / domain_size;
 
-    // A/B knob OCEAN_PASS1_ITERS (N = 4096 only): a persistent workgroup transforms that many column groups one after the
-    // other (grid / ITERS workgroups) instead of leaving the second dispatch round to the hardware.
-#ifdef OCEAN_PASS1_ITERS
-    constexpr int ITERS = (N == 4096 && !FPAR && !HAND) ? OCEAN_PASS1_ITERS : 1;
-#pragma unroll 1
-    for (int it = 0; it < ITERS; ++it) {
-#else
-    constexpr int ITERS = 1, it = 0;                               // (no loop in the product build: its mere presence moves the register allocation)
-    {
-#endif
     // X: the workgroup's column group within this launch (= within the intermediate it writes); Xg: within the tile.
     // They differ only when the tile is sharded over several GPUs and this rank transforms the column groups
     // [x_group0, x_group0 + gridDim.x) (ocean_tile_pass1).
-    const int X = xcd_contiguous((int)blockIdx.x + it * (int)gridDim.x, (int)gridDim.x * ITERS);
+    const int X = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
     const int Xg = X + x_group0;
     if (Xg == 0) nyquist_spectra<N, H16, GT * (FPAR ? 3 : 1)>(h0T, descale, omegaT, nyq_spec, tid, time, kscale);   // uniform branch
-#ifdef OCEAN_SETPRIO
-    // One wave of every line sits on each SIMD (T = 4 waves per line, waves dealt to the SIMDs cyclically):
-    // the line index is a priority that differs between the waves sharing a SIMD.
-    if constexpr (T >= 64) wave_priority((OCEAN_SETPRIO == 2) ? (3 - c) : c);
-#endif
-#ifdef OCEAN_STAGGER_SLOT2   // A/B knob: with two co-resident workgroups per CU (P = 2), the second dispatch slot of every CU
-                             // (blocks 256 .. 511 of the first round) starts late by OCEAN_STAGGER_SLOT2 x 3.4 us, so that the
-                             // two workgroups of a CU are in different phases (one loads while the other transforms)
-    if (blockIdx.x >= 256 && blockIdx.x < 512) {
-#pragma unroll 1
-        for (int s_ = 0; s_ < OCEAN_STAGGER_SLOT2; ++s_) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
     const bool packs_nyquist = (Xg == 0) && (c == 0);              // line 0 of that workgroup: column 0 + i * Nyquist
     const uint32_t x = (uint32_t)(Xg * P + c);                     // kx in [0, N/2)
     const uint32_t x2 = (N - x) & (N - 1);
     c32 A[E], B[E];
     OCEAN_TL(0);
-#ifdef OCEAN_SKEW_DUP
-    half_load_AB_skewed<N, E, H16>(h0T, descale, omegaT, x, j, time, A, B);
-#else
-    if constexpr (LD == LOAD_DMA) {
+    if constexpr (DMA) {
         static_assert(DmaRing<N, E, P, H16, 1>::bytes <= 160 * 1024, "the DMA ring fits the LDS");
         half_load_AB_dma<N, E, P, H16, 1>(h0T, descale, omegaT, (uint32_t)(Xg * P), c, 0, j, tid, time, smem, A, B);
-    } else if constexpr (HAND) half_load_AB_handover<N, E, P, H16>(h0T, descale, omegaT, x, c, j, tid, time, reinterpret_cast<float4*>(smem), A, B);
-    else half_load_AB<N, E, H16>(h0T, descale, omegaT, x, j, time, A, B);
-#endif
+    } else half_load_AB<N, E, H16>(h0T, descale, omegaT, x, j, time, A, B);
     OCEAN_TL(1);
     const c32 kxv = mk(wave_index_q1(x, N), wave_index_q1(x2, N)) * kscale;
 
@@ -1292,16 +807,9 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
     const int i = gt / H2S;
     const c32* l0 = lds_grp + (2 * h) * LinePitch<N>::elems;
     const c32* l1 = lds_grp + (2 * h + 1) * LinePitch<N>::elems;
-#ifdef OCEAN_ROTQ
-    const int rotq = (OCEAN_ROTQ == 2) ? (int)((blockIdx.x * 5u + (blockIdx.x >> 3)) & (E / 2 - 1)) : (X & (E / 2 - 1));
-#endif
 #pragma unroll
     for (int ff = 0; ff < (FPAR ? 1 : 3); ++ff) {
-#ifdef OCEAN_FIELD_ORDER   // A/B knob: height first (its spectrum is the cheapest and the first transform of a round is exposed)
-        const int f = FPAR ? fg : ((ff == 0) ? 1 : ((ff == 1) ? 0 : 2));
-#else
         const int f = FPAR ? fg : ff;
-#endif
         c32 reg[E];
         const int jf = FPAR ? j : opaque_lane(j);                  // (one field per thread: nothing to keep apart, and the twiddle loads may move up)
         half_spectrum<N, E>(f, A, B, kxv, kscale, jf, reg);
@@ -1312,21 +820,13 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
                 reg[e] = cadd_i(reg[e], z[e * T]);                 // + i * Sn
             }
         }
-        if (LD != LOAD_REGS || ff > 0) __syncthreads();           // the line buffers' previous readers (loader ring / hand-over / chunk stores) are done
-#ifdef OCEAN_X_NOFFT   // timing experiment only (wrong results): the transform replaced by its final LDS scatter
-        {
-            c32* g = lds_line + lds_pad(jf);
-#pragma unroll
-            for (int e = 0; e < E; ++e) g[e * (T + T / 16)] = reg[e];
-            __syncthreads();
-        }
-#else
+        if (DMA || ff > 0) __syncthreads();                       // the line buffers' previous readers (loader ring / chunk stores) are done
         if constexpr (P == 1) {
             // One column per workgroup (the latency-bound sizes, where a column per CU is the whole grid): the transform
             // ends in registers, X[j + e T], and every lane stores its 8-byte elements straight into the chunks (a
             // quarter of a chunk row each; the four column workgroups of a chunk column run on one XCD and the
             // cache-resident intermediate merges there).
-            fft_line<N, E, 1, true, (N <= OCEAN_HWTW_MAX_N)>(reg, jf, tw, lds_line);   // the threads of a line are consecutive lanes
+            fft_line<N, E, 1, true, (N <= HWTW_MAX_N)>(reg, jf, tw, lds_line);   // the threads of a line are consecutive lanes
             OCEAN_TL(2 + 2 * (FPAR ? f : ff));
             c32* dcol = inter + (size_t)f * lay.fs + (size_t)(X / CW) * lay.sx + (X % CW);
 #pragma unroll
@@ -1337,8 +837,7 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
             OCEAN_TL(3 + 2 * (FPAR ? f : ff));
             continue;
         }
-        fft_line_to_lds<N, E, 1, true, (N <= OCEAN_HWTW_MAX_N)>(reg, jf, tw, lds_line);
-#endif
+        fft_line_to_lds<N, E, 1, true, (N <= HWTW_MAX_N)>(reg, jf, tw, lds_line);
         OCEAN_TL(2 + 2 * (FPAR ? f : ff));
         // chunk row Y = i / CR + q * (2T / CR): the thread's part and the (wave-uniform, scalar) part of the address add
         // up because 2T / CR is a power of two > i / CR (no carry between them in chunk_row_offset)
@@ -1346,15 +845,7 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
                    ((X * P) % CW) + 2 * h;
 #pragma unroll
         for (int q0 = 0; q0 < E / 2; ++q0) {
-#ifdef OCEAN_ROTQ
-            // Every workgroup walks the rows of its columns from a different starting block: without this all 256
-            // resident workgroups store to the same few chunk rows at the same time (a moving 8 MB window of the
-            // intermediate), which the memory system serves at the rate of a grid-stride store (4.1-4.8 TB/s in
-            // tools/membench2) instead of the 5.4-6.2 TB/s of stores spread over the whole buffer.
-            const int q = (q0 + rotq) & (E / 2 - 1);
-#else
             const int q = q0;
-#endif
             const int y = i + q * (2 * T);
             const c32 v0 = l0[lds_pad(y)];
             const c32 v1 = l1[lds_pad(y)];
@@ -1364,223 +855,6 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
         }
         OCEAN_TL(3 + 2 * (FPAR ? f : ff));
     }
-    if (ITERS > 1) __syncthreads();                               // the next group's transforms reuse the line buffers
-    }
-}
-
-// Loads for the split geometry: sub-line thread (p, j) finally needs A, B at y = 2 (j + e TS) + p, e < E -- a
-// stride-2 pattern that halves the bytes per load instruction and cost +14 us on the load phase at N = 8192.
-// Instead thread (p, j) loads BOTH parities (16 contiguous bytes per stream) for e in [8p, 8p + 8), propagates
-// them, keeps its own parity and hands the other one to its partner (p ^ 1, j) through LDS (free during the
-// load phase): one 16-byte write and read per element, once per workgroup.
-template <int N, int E, bool H16, int THREADS>
-__device__ __forceinline__ void half_load_AB_pairs(const void* __restrict__ h0T_, float descale,
-                                                   const float* __restrict__ omegaT, uint32_t x, int j, int p, int tid,
-                                                   float time, float4* xchg, c32 (&A)[E], c32 (&B)[E]) {
-    typedef typename Spec<H16>::elem Sp;
-    constexpr int TS = N / (2 * E);                                // threads per sub-line
-    constexpr int EH = E / 2;
-    const Sp* h0T = reinterpret_cast<const Sp*>(h0T_);
-    const uint32_t x2 = (N - x) & (N - 1);
-    const uint32_t xm = (x - 1u) & (N - 1);
-    const int e0 = EH * p;                                         // this thread loads m = j + (e0 + t) TS, t < EH
-    const Sp* own = h0T + (size_t)x * N + 2 * e0 * TS;             // pair at 2m
-    const Sp* mir = h0T + (size_t)(N - 1 - x) * N - 2 * e0 * TS;   // pair at N - 2 - 2m
-    const Sp* own2 = h0T + (size_t)x2 * N - 2 * e0 * TS;           // pair at N - 1 - 2m
-    const Sp* mir2 = h0T + (size_t)xm * N + 2 * e0 * TS;           // pair at 2m - 1
-    const float* om = omegaT + (size_t)x * N + 2 * e0 * TS;
-    const float* om2 = omegaT + (size_t)x2 * N - 2 * e0 * TS;
-    c32 mineA[EH], mineB[EH];
-#ifdef OCEAN_X_NODUP
-    const bool nodup_skip = (tid / (2 * TS)) != 0;                 // the workgroup's second column (wave-uniform)
-#endif
-    constexpr int PER = 2;                                         // iterations per load batch (4 elements, as half_load_AB)
-    int jj = j;
-#pragma unroll
-    for (int t = 0; t < EH; ++t) {
-        if (t > 0 && (t % PER) == 0) jj = opaque_after(j, mineA[t - 1].x + mineB[t - 1].y);
-        c32 a0, a1, m0, m1, b0, b1, n0, n1;                        // own, mirror, own2, mirror2 for y0 = 2m, y1 = 2m + 1
-        float w0, w1, v0, v1;
-        Spec<H16>::load2((own + 2 * t * TS) + 2 * jj, descale, a0, a1);
-        Spec<H16>::load2((mir + (N - 2 * (t + 1) * TS)) + 2 * (TS - 1 - jj), descale, m1, m0);   // mir[N-2-2m], mir[N-1-2m]
-        { const float* wp = (om + 2 * t * TS) + 2 * jj; w0 = OCEAN_OMEGA_LOAD(wp); w1 = OCEAN_OMEGA_LOAD(wp + 1); }
-#ifdef OCEAN_X_NODUP   // timing experiment only (wrong results): column 1 of the workgroup does not load the two streams that
-                       // re-read column 0's lines (its own2 = column 0's mirror, its mirror2 = column 0's own)
-        if (nodup_skip) {
-            b0 = m0; b1 = m1; n0 = a0; n1 = a1;
-            const float* wp = (om2 + (N - 1 - 2 * (t + 1) * TS)) + 2 * (TS - jj);
-            v1 = OCEAN_OMEGA_LOAD(wp); v0 = OCEAN_OMEGA_LOAD(wp + (t == 0 && jj == 0 ? 0 : 1));
-        } else
-#endif
-        if (t == 0) {                                              // m may be 0: y2 = (N - y) % N and ym = (y - 1) % N wrap
-            const int y0 = 2 * (jj + e0 * TS), y1 = y0 + 1;
-            const int y20 = (N - y0) & (N - 1), y21 = (N - y1) & (N - 1);
-            const int ym0 = (y0 - 1) & (N - 1), ym1 = y0;
-            const Sp* r2 = h0T + (size_t)x2 * N;
-            const Sp* rm = h0T + (size_t)xm * N;
-            const float* o2 = omegaT + (size_t)x2 * N;
-            b0 = Spec<H16>::load(r2 + y20, descale); b1 = Spec<H16>::load(r2 + y21, descale);
-            n0 = Spec<H16>::load(rm + ym0, descale); n1 = Spec<H16>::load(rm + ym1, descale);
-            v0 = OCEAN_OMEGA_LOAD(o2 + y20); v1 = OCEAN_OMEGA_LOAD(o2 + y21);
-        } else {
-            Spec<H16>::load2((own2 + (N - 1 - 2 * (t + 1) * TS)) + 2 * (TS - jj), descale, b1, b0);   // own2[N-1-2m], own2[N-2m]
-            Spec<H16>::load2((mir2 + (2 * t * TS - 1)) + 2 * jj, descale, n0, n1);                      // mir2[2m-1], mir2[2m]
-            const float* wp = (om2 + (N - 1 - 2 * (t + 1) * TS)) + 2 * (TS - jj);
-            v1 = OCEAN_OMEGA_LOAD(wp); v0 = OCEAN_OMEGA_LOAD(wp + 1);
-        }
-        const c32 Aev = propagate_height(a0, m0, w0, time), Aod = propagate_height(a1, m1, w1, time);
-        const c32 Bev = cconj(propagate_height(b0, n0, v0, time)), Bod = cconj(propagate_height(b1, n1, v1, time));
-        mineA[t] = p ? Aod : Aev;
-        mineB[t] = p ? Bod : Bev;
-        const c32 sA = p ? Aev : Aod, sB = p ? Bev : Bod;
-        xchg[t * THREADS + tid] = make_float4(sA.x, sA.y, sB.x, sB.y);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < EH; ++t) {
-        const float4 r = xchg[t * THREADS + (tid ^ TS)];
-        const c32 rA = mk(r.x, r.y), rB = mk(r.z, r.w);
-        A[t] = p ? rA : mineA[t];
-        B[t] = p ? rB : mineB[t];
-        A[EH + t] = p ? mineA[t] : rA;
-        B[EH + t] = p ? mineB[t] : rB;
-    }
-    __syncthreads();                                               // the exchange buffer is the FFT's line buffer next
-}
-
-// half_load_AB_pairs with the hand-over of half_load_AB_handover: the workgroup's second column takes its own2 / mirror2
-// pairs from what the first column loaded as mirror / own (at N = 8192 every 64 KiB spectrum line was fetched twice:
-// 1306 MB where 940 MB are the workgroups' distinct lines).  Per batch of PER pair loads, column 0 parks
-// (a0, a1) and (m0, m1) by position in one of two batch buffers; after the batch's barrier column 1 reads positions
-// y - 1 and y:  n0 = a(y0 - 1), n1 = a(y0), b0 = m(y0 - 1), b1 = m(y0).  The parity exchange of half_load_AB_pairs
-// moves into the same loop (two batch buffers as well; batch b's exchange is read behind barrier b + 1), so the load
-// phase has NB + 2 barriers instead of 2.  Position y0 - 1 of a batch's first pair belongs to the previous batch: that
-// lane takes the pair from memory (a wave-uniform address: scalar loads).
-template <int N, int E, bool H16, int THREADS>
-__device__ __forceinline__ void half_load_AB_pairs_handover(const void* __restrict__ h0T_, float descale,
-                                                            const float* __restrict__ omegaT, uint32_t x, int j, int p, int c,
-                                                            int tid, float time, float4* lds4, c32 (&A)[E], c32 (&B)[E]) {
-    typedef typename Spec<H16>::elem Sp;
-    constexpr int TS = N / (2 * E);                                // threads per sub-line
-    constexpr int EH = E / 2;
-    constexpr int PER = 2;                                         // pair loads per batch
-    constexpr int NB = EH / PER;
-    constexpr int XB = PER * THREADS;                              // parity exchange: 16-byte slots per batch
-    constexpr int DP = 2 * PER * TS;                               // pairs column 0 loads per batch (both parities' spans)
-    static_assert(THREADS == 4 * TS, "two columns of two sub-lines");
-    static_assert((2 * XB + 4 * DP) * (int)sizeof(float4) <= 4 * LinePitch<N / 2>::elems * (int)sizeof(c32), "exchange buffers fit the line buffers");
-    float4* xchg = lds4;                                           // [2][PER][THREADS]
-    float4* dupA = lds4 + 2 * XB;                                  // [2][DP]: (a(2m), a(2m + 1)) of column 0
-    float4* dupM = dupA + 2 * DP;                                  // [2][DP]: (m(2m), m(2m + 1))
-    const Sp* h0T = reinterpret_cast<const Sp*>(h0T_);
-    const uint32_t x2 = (N - x) & (N - 1);
-    const uint32_t xm = (x - 1u) & (N - 1);
-    const int e0 = EH * p;                                         // this thread loads m = j + (e0 + t) TS, t < EH
-    const Sp* own = h0T + (size_t)x * N + 2 * e0 * TS;             // pair at 2m
-    const Sp* mir = h0T + (size_t)(N - 1 - x) * N - 2 * e0 * TS;   // pair at N - 2 - 2m
-    const Sp* own2 = h0T + (size_t)x2 * N - 2 * e0 * TS;           // pair at N - 1 - 2m
-    const Sp* mir2 = h0T + (size_t)xm * N + 2 * e0 * TS;           // pair at 2m - 1
-    const float* om = omegaT + (size_t)x * N + 2 * e0 * TS;
-    const float* om2 = omegaT + (size_t)x2 * N - 2 * e0 * TS;
-    c32 mineA[EH], mineB[EH];
-    int jj = j;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        if (b > 0) jj = opaque_after(j, mineA[b * PER - 1].x + mineB[b * PER - 1].y);
-        c32 a0[PER], a1[PER], m0[PER], m1[PER], b0[PER], b1[PER], n0[PER], n1[PER];
-        float w0[PER], w1[PER], v0[PER], v1[PER];
-#pragma unroll
-        for (int tb = 0; tb < PER; ++tb) {
-            const int t = b * PER + tb;
-            Spec<H16>::load2((own + 2 * t * TS) + 2 * jj, descale, a0[tb], a1[tb]);
-            Spec<H16>::load2((mir + (N - 2 * (t + 1) * TS)) + 2 * (TS - 1 - jj), descale, m1[tb], m0[tb]);   // mir[N-2-2m], mir[N-1-2m]
-            { const float* wp = (om + 2 * t * TS) + 2 * jj; w0[tb] = OCEAN_OMEGA_LOAD(wp); w1[tb] = OCEAN_OMEGA_LOAD(wp + 1); }
-            if (t == 0) {                                          // m may be 0: y2 = (N - y) % N wraps
-                const int y0 = 2 * (jj + e0 * TS), y1 = y0 + 1;
-                const float* o2 = omegaT + (size_t)x2 * N;
-                v0[tb] = OCEAN_OMEGA_LOAD(o2 + ((N - y0) & (N - 1))); v1[tb] = OCEAN_OMEGA_LOAD(o2 + ((N - y1) & (N - 1)));
-            } else {
-                const float* wp = (om2 + (N - 1 - 2 * (t + 1) * TS)) + 2 * (TS - jj);
-                v1[tb] = OCEAN_OMEGA_LOAD(wp); v0[tb] = OCEAN_OMEGA_LOAD(wp + 1);
-            }
-        }
-        // position y - 1 of the batch's first pair (previous batch / end of the line): wave-uniform, scalar loads
-        const int ye = 2 * (e0 + b * PER) * TS;
-        const c32 edge_n0 = Spec<H16>::load(h0T + (size_t)xm * N + ((ye - 1) & (N - 1)), descale);
-        const c32 edge_b0 = Spec<H16>::load(h0T + (size_t)x2 * N + ((N - ye) & (N - 1)), descale);
-        float4* dA = dupA + (b & 1) * DP + p * (PER * TS) + jj;
-        float4* dM = dupM + (b & 1) * DP + p * (PER * TS) + jj;
-        if (c == 0) {                                              // wave-uniform: the first column's own2 / mirror2 come from memory
-#pragma unroll
-            for (int tb = 0; tb < PER; ++tb) {
-                const int t = b * PER + tb;
-                if (t == 0) {
-                    const int y0 = 2 * (jj + e0 * TS), y1 = y0 + 1;
-                    const Sp* r2 = h0T + (size_t)x2 * N;
-                    const Sp* rm = h0T + (size_t)xm * N;
-                    b0[tb] = Spec<H16>::load(r2 + ((N - y0) & (N - 1)), descale); b1[tb] = Spec<H16>::load(r2 + ((N - y1) & (N - 1)), descale);
-                    n0[tb] = Spec<H16>::load(rm + ((y0 - 1) & (N - 1)), descale); n1[tb] = Spec<H16>::load(rm + y0, descale);
-                } else {
-                    Spec<H16>::load2((own2 + (N - 1 - 2 * (t + 1) * TS)) + 2 * (TS - jj), descale, b1[tb], b0[tb]);   // own2[N-1-2m], own2[N-2m]
-                    Spec<H16>::load2((mir2 + (2 * t * TS - 1)) + 2 * jj, descale, n0[tb], n1[tb]);                      // mir2[2m-1], mir2[2m]
-                }
-                dA[tb * TS] = make_float4(a0[tb].x, a0[tb].y, a1[tb].x, a1[tb].y);
-                dM[tb * TS] = make_float4(m0[tb].x, m0[tb].y, m1[tb].x, m1[tb].y);
-            }
-        }
-        c32 Aev[PER], Aod[PER];
-#pragma unroll
-        for (int tb = 0; tb < PER; ++tb) {                         // before the barrier: frees a, m, w
-            Aev[tb] = propagate_height(a0[tb], m0[tb], w0[tb], time);
-            Aod[tb] = propagate_height(a1[tb], m1[tb], w1[tb], time);
-        }
-        __syncthreads();
-        if (b > 0) {                                               // the previous batch's parity exchange
-#pragma unroll
-            for (int tb = 0; tb < PER; ++tb) {
-                const int t = (b - 1) * PER + tb;
-                const float4 r = xchg[((b - 1) & 1) * XB + tb * THREADS + (tid ^ TS)];
-                const c32 rA = mk(r.x, r.y), rB = mk(r.z, r.w);
-                A[t] = p ? rA : mineA[t];
-                B[t] = p ? rB : mineB[t];
-                A[EH + t] = p ? mineA[t] : rA;
-                B[EH + t] = p ? mineB[t] : rB;
-            }
-        }
-        if (c != 0) {
-#pragma unroll
-            for (int tb = 0; tb < PER; ++tb) {
-                const bool first = (tb == 0) && (jj == 0);
-                const float4 ca = dA[tb * TS], cm = dM[tb * TS];
-                const float4 pa = dA[tb * TS - (first ? 0 : 1)], pm = dM[tb * TS - (first ? 0 : 1)];
-                n1[tb] = mk(ca.x, ca.y);                            // a(y0)
-                b1[tb] = mk(cm.x, cm.y);                            // m(y0)
-                n0[tb] = first ? edge_n0 : mk(pa.z, pa.w);          // a(y0 - 1)
-                b0[tb] = first ? edge_b0 : mk(pm.z, pm.w);          // m(y0 - 1)
-            }
-        }
-#pragma unroll
-        for (int tb = 0; tb < PER; ++tb) {
-            const int t = b * PER + tb;
-            const c32 Bev = cconj(propagate_height(b0[tb], n0[tb], v0[tb], time)), Bod = cconj(propagate_height(b1[tb], n1[tb], v1[tb], time));
-            mineA[t] = p ? Aod[tb] : Aev[tb];
-            mineB[t] = p ? Bod : Bev;
-            const c32 sA = p ? Aev[tb] : Aod[tb], sB = p ? Bev : Bod;
-            xchg[(b & 1) * XB + tb * THREADS + tid] = make_float4(sA.x, sA.y, sB.x, sB.y);
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int tb = 0; tb < PER; ++tb) {
-        const int t = (NB - 1) * PER + tb;
-        const float4 r = xchg[((NB - 1) & 1) * XB + tb * THREADS + (tid ^ TS)];
-        const c32 rA = mk(r.x, r.y), rB = mk(r.z, r.w);
-        A[t] = p ? rA : mineA[t];
-        B[t] = p ? rB : mineB[t];
-        A[EH + t] = p ? mineA[t] : rA;
-        B[EH + t] = p ? mineB[t] : rB;
-    }
-    __syncthreads();                                               // the exchange buffers are the FFT's line buffers next
 }
 
 // The same pass for lines too long for a three-pass plan (N = 8192 = 2 * 16^3): every column is transformed
@@ -1597,7 +871,10 @@ __device__ __forceinline__ void half_load_AB_pairs_handover(const void* __restri
 // The scale is the wave maximum of |re|, |im| (DPP reduction) rounded up to a power of two: values are exact multiples of
 // 2^(e-15).  Numerics (tools/inter16_numerics.py, N = 8192, fp16-quantised spectrum): 2.7-3.1e-5 normalised max against
 // the unquantised result, tolerance 1e-4.
-template <int N, int E, int P, bool H16, int LD = LOAD_REGS, bool I16 = false>
+// The inputs always arrive through the LDS-DMA ring (half_load_AB_dma with S = 2: sub-line thread (par, j) reads positions
+// y = 2 (j + e TS) + par out of the staged lines; rounds 1-3 loaded pairs into registers and exchanged parities and
+// duplicate lines through LDS: 454 -> 420 us, r04_run1).
+template <int N, int E, int P, bool H16, bool I16 = false>
 __global__ void __launch_bounds__((N / E) * P, pass1_waves_per_simd<E>((N / E) * P))
 k_half_pass1_split(const void* __restrict__ h0T, float descale, const float* __restrict__ omegaT, c32* __restrict__ inter,
                    c32* nyq_spec, const c32* __restrict__ tw, InterLayout lay, float time, float domain_size, int x_group0,
@@ -1619,21 +896,14 @@ k_half_pass1_split(const void* __restrict__ h0T, float descale, const float* __r
     const int X = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);   // within this launch; Xg within the tile (k_half_pass1)
     const int Xg = X + x_group0;
     if (Xg == 0) nyquist_spectra<N, H16, THREADS>(h0T, descale, omegaT, nyq_spec, tid, time, kscale);   // uniform branch
-#ifdef OCEAN_SETPRIO
-    if constexpr (TS >= 64) wave_priority((OCEAN_SETPRIO == 2) ? (3 - l) : l);   // one wave of every sub-line per SIMD
-#endif
     const bool packs_nyquist = (Xg == 0) && (c == 0);              // both parities of column 0 carry the Nyquist column
     const uint32_t x = (uint32_t)(Xg * P + c);
     const uint32_t x2 = (N - x) & (N - 1);
     c32 A[E], B[E];
     OCEAN_TL(0);
-    static_assert(E / 2 * THREADS * (int)sizeof(float4) <= 2 * P * LinePitch<M>::elems * (int)sizeof(c32), "exchange fits the line buffers");
-    if constexpr (LD == LOAD_DMA) {
-        static_assert(DmaRing<N, E, P, H16, 2>::bytes <= 160 * 1024, "the DMA ring fits the LDS");
-        half_load_AB_dma<N, E, P, H16, 2>(h0T, descale, omegaT, (uint32_t)(Xg * P), c, par, j, tid, time, smem, A, B);
-        __syncthreads();                                           // the ring is the transforms' line buffers next
-    } else if constexpr (LD == LOAD_HANDOVER) half_load_AB_pairs_handover<N, E, H16, THREADS>(h0T, descale, omegaT, x, j, par, c, tid, time, reinterpret_cast<float4*>(smem), A, B);
-    else half_load_AB_pairs<N, E, H16, THREADS>(h0T, descale, omegaT, x, j, par, tid, time, reinterpret_cast<float4*>(smem), A, B);
+    static_assert(DmaRing<N, E, P, H16, 2>::bytes <= 160 * 1024, "the DMA ring fits the LDS");
+    half_load_AB_dma<N, E, P, H16, 2>(h0T, descale, omegaT, (uint32_t)(Xg * P), c, par, j, tid, time, smem, A, B);
+    __syncthreads();                                               // the ring is the transforms' line buffers next
     OCEAN_TL(1);
     const c32 kxv = mk(wave_index_q1(x, N), wave_index_q1(x2, N)) * kscale;
 
@@ -1659,11 +929,7 @@ k_half_pass1_split(const void* __restrict__ h0T, float descale, const float* __r
                    ((X * P) % CW);                                  // + the wave-uniform part of the chunk row below (see k_half_pass1)
 #pragma unroll
         for (int q0 = 0; q0 < M / THREADS; ++q0) {
-#ifdef OCEAN_ROTQ
-            const int q = (q0 + (X & (M / THREADS - 1))) & (M / THREADS - 1);   // see k_half_pass1
-#else
             const int q = q0;
-#endif
             const int k = tf + q * THREADS;                        // rows k and k + M
             const c32 w = tw[k];
             const c32 wr = crot(w);
@@ -1693,17 +959,6 @@ k_half_pass1_split(const void* __restrict__ h0T, float descale, const float* __r
                 }
                 continue;
             }
-#ifdef OCEAN_X_INTER16   // timing experiment only (wrong results): the access pattern of a 16-bit intermediate -- every
-                         // element offset halved (4-byte complex numbers), 8 bytes per lane -- without its arithmetic: an
-                         // upper bound on what SURVEY 8d's B_frame16 can buy at N = 8192
-            {
-                float2* qlo = reinterpret_cast<float2*>(reinterpret_cast<float*>(inter) + (reinterpret_cast<c32*>(olo) - inter));
-                float2* qhi = reinterpret_cast<float2*>(reinterpret_cast<float*>(inter) + (reinterpret_cast<c32*>(ohi) - inter));
-                *qlo = make_float2(lo0.x + lo0.y, lo1.x + lo1.y);
-                *qhi = make_float2(hi0.x + hi0.y, hi1.x + hi1.y);
-                continue;
-            }
-#endif
             if constexpr (P == CW) {                               // whole chunk rows (2-column chunks): streamed
                 store_float4_nt(olo, make_float4(lo0.x, lo0.y, lo1.x, lo1.y));
                 store_float4_nt(ohi, make_float4(hi0.x, hi0.y, hi1.x, hi1.y));
@@ -1763,9 +1018,6 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
         rb = ((slot / S) * 8 + xcd) * S + (slot % S);
     }
     const int y = rb * R2 + ll;                                    // the row this thread transforms and stores
-#ifdef OCEAN_SETPRIO2
-    wave_priority(wave_uniform((int)(blockIdx.x >> 3) & 3));        // co-resident workgroups: one wave each per SIMD
-#endif
     c32* lds_grp = lds + pg * (R2 * LP);                           // the group's R2 line buffers
     c32* lds_line = lds_grp + ll * LP;
     float* hbuf = reinterpret_cast<float*>(lds + 2 * R2 * LP);     // PPAR: R2 rows of N height values
@@ -1781,13 +1033,8 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
     // N <= 2048: all three fields' loads are issued before the first transform (a workgroup has 8, then 16, 8-byte loads
     // per thread in flight otherwise).  Run 34: N = 2048 20.07-20.24k frames/s against 19.84-19.94k; at N = 4096 the same
     // costs 2-3 us (pass 2 91-94 us against 88-91): more lines in flight than the L2 keeps for the four sharers.
-#ifdef OCEAN_P2_PREFETCH   // A/B knob: 0 = none, 1 = disp_x and disp_z, 2 = disp_x only
-    constexpr bool PREFETCH = (OCEAN_P2_PREFETCH != 0) && !PPAR && !SHARD;
-    constexpr bool PREFETCH_Z = (OCEAN_P2_PREFETCH == 1);
-#else
     constexpr bool PREFETCH = (N <= 2048) && !PPAR && !SHARD;
     constexpr bool PREFETCH_Z = true;
-#endif
     c32 pre_x[EH], pre_z[EH];
     if constexpr (PREFETCH) {
         const size_t off0 = chunk_row_offset(lay, ly / CR) + (size_t)(lk0 / P1) * lay.sx + (ly % CR) * P1 + (lk0 % P1);
@@ -1803,10 +1050,6 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
         const int lk = (R2 == 1) ? jf : opaque_lane(lk0);
         const size_t off = chunk_row_offset(lay, ly / CR) + (size_t)(lk / P1) * lay.sx + (ly % CR) * P1 + (lk % P1);
         c32 a[EH], b[EH];
-#ifdef OCEAN_X2_NOLOAD   // timing experiment only: no reads of the intermediate (the write side alone)
-#pragma unroll
-        for (int e = 0; e < EH; ++e) { a[e] = mk((float)(off & 7) + e, 1.0f); b[e] = mk(2.0f, (float)e); }
-#else
         if constexpr (SHARD) {
             // chunk column X of the tile sits in the slab of source rank X >> xs_shift
             const size_t offy = chunk_row_offset(lay, ly / CR) + (ly % CR) * P1 + (lk % P1);
@@ -1831,7 +1074,6 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
 #pragma unroll
             for (int e = 0; e < EH; ++e) { a[e] = sx_[(size_t)e * (T / P1) * lay.sx]; b[e] = sz_[(size_t)e * (T / P1) * lay.sx]; }
         }
-#endif
         if (it > 0) __syncthreads();                               // previous FFT's LDS reads done
         // rebuild the full row: C[k] = A + iB, C[N-k] = conj(A) + i conj(B).  Column 0 of the intermediate
         // holds two real columns, (kx = 0, kx = N/2) as (re, im): C[0] = re(A) + i re(B), C[N/2] = im(A) + i im(B)
@@ -1868,9 +1110,7 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
 #pragma unroll
         for (int e = 0; e < E; ++e) reg[e] = g[e * (T + T / 16)];
         __syncthreads();
-#ifndef OCEAN_X2_NOFFT   // timing experiment only (wrong results): pass 2 without its transforms
-        fft_line<N, E, 1, true, (N <= OCEAN_HWTW_MAX_N)>(reg, jf, tw, lds_line);   // (ll, j): the threads of a row are consecutive lanes
-#endif
+        fft_line<N, E, 1, true, (N <= HWTW_MAX_N)>(reg, jf, tw, lds_line);   // (ll, j): the threads of a row are consecutive lanes
         OCEAN_TL(2 + 3 * pass);
         if constexpr (PPAR) {                                      // group 0 hands its row of heights to group 1
             if (pass == 0) {
@@ -1897,9 +1137,6 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
                 const int xo = j + e * T;
                 const float s = (((xo + y) & 1) == 0) ? -0.5f : 0.5f;   // correction.comp:29 and the 1/2 of S(F)
                 const c32 d = reg[e] * s;
-#ifdef OCEAN_X2_NOSTORE   // timing experiment only: one store per thread instead of 16 (the read side alone)
-                if (e == 0 && d.x == 12345.678f)
-#endif
                 store_float4_nt(orow + xo, make_float4(d.x, keep_h[e] * s, d.y, 0.0f));
             }
             OCEAN_TL(6);
@@ -1943,11 +1180,7 @@ k_half_pass2_split(const c32* __restrict__ inter, float4* __restrict__ out, cons
     // 512-thread workgroups per CU the gather is short of requests in flight, not of L2 -- pass 2 462-470 -> 426-429 us,
     // 1084-1098 -> 1148-1149 frames/s at N = 8192 (r03_run21; the same idea costs 2-3 us at 4096, where four workgroups
     // per CU already fill the queues: k_half_pass2).  A/B knob: -DOCEAN_P2S_PREFETCH=0.
-#ifdef OCEAN_P2S_PREFETCH
-    constexpr bool PREFETCH = (OCEAN_P2S_PREFETCH != 0);
-#else
     constexpr bool PREFETCH = true;
-#endif
     c32 pre_x[EH], pre_z[EH];                                      // (I16: the raw int16 pairs in .x, their scales in .y)
     if constexpr (PREFETCH) {
         const size_t offy0 = chunk_row_offset(lay, y / CR) + (y % CR) * P1 + (tid % P1);
@@ -2004,21 +1237,6 @@ k_half_pass2_split(const c32* __restrict__ inter, float4* __restrict__ out, cons
                 }
             }
         }
-#ifdef OCEAN_X_INTER16   // timing experiment only (wrong results): 4-byte elements at halved offsets (see k_half_pass1_split)
-        else if (pass == 0) {
-            const float* src = reinterpret_cast<const float*>(inter) + (size_t)1 * lay.fs + off;
-#pragma unroll
-            for (int e = 0; e < EH; ++e) { const float v = src[(size_t)e * (T / P1) * lay.sx]; a[e] = mk(v, -v); }
-        } else {
-            const float* sx_ = reinterpret_cast<const float*>(inter) + off;
-            const float* sz_ = reinterpret_cast<const float*>(inter) + (size_t)2 * lay.fs + off;
-#pragma unroll
-            for (int e = 0; e < EH; ++e) {
-                const float v = sx_[(size_t)e * (T / P1) * lay.sx], w = sz_[(size_t)e * (T / P1) * lay.sx];
-                a[e] = mk(v, -v); b[e] = mk(w, w);
-            }
-        }
-#else
         else if (pass == 0) {
             const c32* src = inter + (size_t)1 * lay.fs + off;
 #pragma unroll
@@ -2032,7 +1250,6 @@ k_half_pass2_split(const c32* __restrict__ inter, float4* __restrict__ out, cons
 #pragma unroll
             for (int e = 0; e < EH; ++e) { a[e] = sx_[(size_t)e * (T / P1) * lay.sx]; b[e] = sz_[(size_t)e * (T / P1) * lay.sx]; }
         }
-#endif
         if (pass > 0) __syncthreads();
         // C[kx] goes to sub-line kx & 1 at index kx >> 1; kx = tf + e*T keeps its parity (T is even).  Its mirror
         // C[N - kx] has the same parity and index N/2 - (kx >> 1) - (kx & 1).
@@ -2161,92 +1378,51 @@ template <int N, int PSEL = 0> struct Geo {
     static constexpr int E = 16;                                   // elements per thread
     // Elements per thread of fused pass 1.  At N <= 1024 a frame is launch- and latency-bound (a 512-point line with 16
     // elements per thread is half a wave): 8 elements per thread double the waves that share a workgroup's serial chain
-    // of load batches and transforms (run r02_run12: N = 512 51.0k -> 67.1k frames/s, 256 63k -> 77k, 1024 38.9k -> 41.3k;
-    // 2048 unchanged).  A/B knobs: OCEAN_E1 (large N: 32 and 64 measured slower), OCEAN_E1_SMALL.
-#ifdef OCEAN_E1
-#ifndef OCEAN_E1_MIN_N
-#define OCEAN_E1_MIN_N 4096
-#endif
-    static constexpr int E1 = (N >= OCEAN_E1_MIN_N) ? OCEAN_E1 : 16;
-    static constexpr int E1S = (N / 2 >= OCEAN_E1_MIN_N) ? OCEAN_E1 : 16;    // split kernels: lines of N / 2 points
-#elif defined(OCEAN_E1_SMALL)
-    static constexpr int E1 = (N <= OCEAN_E1_SMALL_MAX_N) ? OCEAN_E1_SMALL : 16;
-    static constexpr int E1S = 16;
-#else
+    // of loads and transforms (run r02_run12: N = 512 51.0k -> 67.1k frames/s, 256 63k -> 77k, 1024 38.9k -> 41.3k;
+    // 2048 unchanged; 32 and 64 elements at large N: slower).
     static constexpr int E1 = (N <= 1024) ? 8 : 16;
-    static constexpr int E1S = 16;
-#endif
+    static constexpr int E1S = 16;                                 // split kernels: lines of N / 2 points
     static constexpr int T = N / E;                                // threads per line
     static constexpr int ROW_LPW = (256 / T) > 1 ? (256 / T) : 1;  // rows per workgroup (staged)
     static constexpr int COL_LPW = (N > 4096) ? 2 : ((256 / T) > 4 ? (256 / T) : 4);  // columns per workgroup (staged)
-    // lines per workgroup of fused pass 1.  4 lines = 1024 threads at N = 4096 (one workgroup per CU,
-    // whole 4 x 4 chunks); 2 lines = 512 threads and 70 KiB LDS, i.e. two co-resident workgroups whose
-    // load / compute / store phases overlap (each writes half of every chunk row).  PSEL = 0 = default.
-    static constexpr int P = PSEL ? PSEL : ((N > 4096 || CHUNK_W < 4) ? 2 : 4);
+    // Lines per workgroup of fused pass 1.  4 lines = 1024 threads at N = 4096 (one workgroup per CU, whole 4 x 4 chunks);
+    // 2 lines = 512 threads and 70 KiB LDS (two co-resident workgroups, each writing half of every chunk row).
+    // PSEL = 0 = this default; the API picks per size (Launch<N>::default_psel).
+    static constexpr int P = PSEL ? PSEL : ((N > 4096) ? 2 : 4);
     static constexpr int row_threads = T * ROW_LPW;
     static constexpr int col_threads = T * COL_LPW;
-    static constexpr int frame_threads = T * P;
-    // Fused pass 1 hands the intra-workgroup duplicate spectrum streams over through LDS (the split kernels' pair
-    // loader half_load_AB_pairs_handover; half_load_AB_handover for whole lines) instead of asking the memory system
-    // twice.  Shipped at N = 8192, where every 64 KiB line was fetched twice: pass 1 486-490 -> 444-460 us, 1044-1049 ->
-    // 1091-1094 frames/s (run r03_run2, two interleaved repetitions).  NOT at 4096: there the L2 already merges most
-    // twins (269 MB fetched against 235 MB of distinct lines), and the four barriers the hand-over puts into the load
-    // phase cost more than the 30 MB are worth -- 96.0-100.0 us against 91.8-96.6 (runs r03_run2/3; software-pipelining
-    // the batches across the barriers changed nothing).  Below 4096 the working set is cache-resident.
-    // A/B knob: OCEAN_HANDOVER_MIN_N (the CPU emulation builds with 256 to run the hand-over geometry of every size).
-#ifndef OCEAN_HANDOVER_MIN_N
-#define OCEAN_HANDOVER_MIN_N 8192
-#endif
-    static constexpr bool handover = (N >= OCEAN_HANDOVER_MIN_N) && (P >= 2);
     // LDS-DMA loader of fused pass 1 (half_load_AB_dma): the inputs streamed through the idle line buffers, no register
-    // staging, every line of the workgroup requested once.  A/B knob: OCEAN_DMA_MIN_N (0 = off).
+    // staging, every line of the workgroup requested once -- N >= 2048; the latency-bound sizes load straight into
+    // registers (half_load_AB).  Measured (r04_run1/2): pass 1 at N = 8192 454 -> 405-424 us, 4096 97.8 -> 93-95 us (fetched
+    // 267 -> 216 MB), 2048 unchanged.  OCEAN_DMA_MIN_N exists for the CPU emulation, which builds with 256 to run the ring's
+    // geometry at the sizes it can afford (tests/test_emu_kernels.py).
 #ifndef OCEAN_DMA_MIN_N
-#define OCEAN_DMA_MIN_N 4096
+#define OCEAN_DMA_MIN_N 2048
 #endif
-    static constexpr bool dma = (OCEAN_DMA_MIN_N > 0) && (N >= OCEAN_DMA_MIN_N) && (((N / E1) * P) % 64 == 0);
-    static constexpr int loader = dma ? LOAD_DMA : (handover ? LOAD_HANDOVER : LOAD_REGS);
-    // Field-parallel pass 1 (k_half_pass1<.., FPAR>): three wave groups per workgroup, one per field, at the latency-bound
-    // sizes.  A/B knob: OCEAN_FPAR_MAX_N (0 = off).
-#ifndef OCEAN_FPAR_MAX_N
-#define OCEAN_FPAR_MAX_N 512
-#endif
-    static constexpr bool fpar = (N <= OCEAN_FPAR_MAX_N) && (((N / E1) * P) % 64 == 0) && (3 * (N / E1) * P <= 1024) && !handover && !dma;
-    static constexpr int half_threads1 = (N / E1) * P * (fpar ? 3 : 1);   // fused pass 1 (half-spectrum path)
+    static constexpr bool dma = (N >= OCEAN_DMA_MIN_N) && (((N / E1) * P) % 64 == 0);
+    // Field-parallel pass 1 (k_half_pass1<.., FPAR>): three wave groups per workgroup, one per field, at N <= 512.
+    static constexpr bool fpar = (N <= 512) && (((N / E1) * P) % 64 == 0) && (3 * (N / E1) * P <= 1024) && !dma;
+    static constexpr int half_threads1 = (N / E1) * P * (fpar ? 3 : 1);   // fused pass 1
     static constexpr int split_threads1 = (N / E1S) * P;
     static constexpr int line_bytes = LinePitch<N>::elems * (int)sizeof(c32);
     static constexpr int row_lds = ROW_LPW * line_bytes;
     static constexpr int col_lds = COL_LPW * line_bytes;
-    static constexpr int frame_lds = P * line_bytes;
     static constexpr int max_i(int a, int b) { return a > b ? a : b; }
-    static constexpr int dma_lds1 = DmaRingBytes<dma, N, E1, P, 1>::value;
-    static constexpr int half_lds1 = max_i(P * line_bytes * (fpar ? 3 : 1), dma_lds1);
+    static constexpr int half_lds1 = max_i(P * line_bytes * (fpar ? 3 : 1), DmaRingBytes<dma, N, E1, P, 1>::value);
     static constexpr int row_grid = N / ROW_LPW;
     static constexpr int col_grid = N / COL_LPW;
-    static constexpr int frame_grid = N / P;
     // Rows per workgroup of fused pass 2: 256 threads' worth at N >= 2048; at most two at the launch-bound sizes, where
     // 8 or 16 rows per workgroup leave most CUs without one (N = 512: 64 workgroups; run r02_run13: 67.0k -> 72-73k
-    // frames/s at 512, 76.8k -> 80-85k at 256).  A/B knobs: OCEAN_R2 (more rows at N >= 4096: slower), OCEAN_R2_SMALL.
-#ifdef OCEAN_R2
-    static constexpr int R2 = (OCEAN_R2 > ROW_LPW && T * OCEAN_R2 <= 1024) ? OCEAN_R2 : ROW_LPW;
-#elif defined(OCEAN_R2_SMALL)
-    static constexpr int R2 = (ROW_LPW > OCEAN_R2_SMALL) ? OCEAN_R2_SMALL : ROW_LPW;
-#else
+    // frames/s at 512, 76.8k -> 80-85k at 256; more rows at N >= 4096: slower).
     static constexpr int R2 = (N <= 1024 && ROW_LPW > 2) ? ((T * 2 >= 64) ? 2 : (64 / T)) : ROW_LPW;   // >= one wave per transform group
-#endif
-    // Transform-parallel pass 2 (k_half_pass2<.., PPAR>): two wave groups per workgroup, height and (disp_x, disp_z), at
-    // the latency-bound sizes.  A/B knob: OCEAN_PPAR_MAX_N (0 = off).
-#ifndef OCEAN_PPAR_MAX_N
-#define OCEAN_PPAR_MAX_N 1024
-#endif
-    // Elements per thread of fused pass 2: 8 at the smallest sizes (a 512-point row is then one wave instead of half of
-    // one, and a workgroup is one row: twice the workgroups, four waves per CU).  A/B knob: OCEAN_E2_SMALL_MAX_N (0 = off).
-#ifndef OCEAN_E2_SMALL_MAX_N
-#define OCEAN_E2_SMALL_MAX_N 512
-#endif
-    static constexpr int E2 = (N <= OCEAN_E2_SMALL_MAX_N) ? 8 : E;
+    // Elements per thread of fused pass 2: 8 at N <= 512 (a 512-point row is then one wave instead of half of one, and
+    // a workgroup is one row: twice the workgroups, four waves per CU).
+    static constexpr int E2 = (N <= 512) ? 8 : E;
     static constexpr int T2 = N / E2;                              // threads per row of fused pass 2
     static constexpr int R2h = (E2 == E) ? R2 : ((T2 >= 64) ? 1 : (64 / T2));   // rows per workgroup (whole waves per transform group)
-    static constexpr bool ppar = (N <= OCEAN_PPAR_MAX_N) && ((T2 * R2h) % 64 == 0) && (2 * T2 * R2h <= 1024);
+    // Transform-parallel pass 2 (k_half_pass2<.., PPAR>): two wave groups per workgroup, height and (disp_x, disp_z), at
+    // the latency-bound sizes N <= 1024.
+    static constexpr bool ppar = (N <= 1024) && ((T2 * R2h) % 64 == 0) && (2 * T2 * R2h <= 1024);
     // Intermediate layout of the fused frame (InterLayout): blocks of B = 2^inter_bshift chunk rows.
     // B = 1 is pass-2-contiguous (pass 2 streams, pass 1 scatters single 128-byte chunks), B = N / 4 pass-1-contiguous.
     // At N >= 2048, where pass 1 is bound by its scattered stores, B = 4: a pass-1 wave stores 512-byte pieces, and the
@@ -2255,39 +1431,22 @@ template <int N, int PSEL = 0> struct Geo {
     // frames/s against 4905-5270 with B = 1 and 5170-5220 with B = N / 4 (pass 1 93-95 us against 101-115 and 92-98,
     // pass 2 88-91 us against 88-92 and 99-100); N = 8192 1047-1065 against 1034-1054; N = 2048 19.6-19.9k against
     // 19.3-19.5k (run 31; four lines per pass-1 workgroup there: 17.2k).
-    // A/B knobs: OCEAN_INTER_BSHIFT, OCEAN_INTER_PADX, OCEAN_P2_GROUP.
-    static constexpr int chunk_rows_log2() { int l = 0; while ((CHUNK_R << l) < N) ++l; return l; }
-#ifdef OCEAN_INTER_BSHIFT
-    static constexpr int inter_bshift = (OCEAN_INTER_BSHIFT < chunk_rows_log2()) ? OCEAN_INTER_BSHIFT : chunk_rows_log2();
-#else
     static constexpr int inter_bshift = (N >= 2048) ? 2 : 0;
-#endif
-#ifdef OCEAN_INTER_PADX                                                // elements added to the pitch between chunk columns (B > 1)
-    static constexpr int inter_padx = (inter_bshift > 0) ? OCEAN_INTER_PADX : 0;
-#else
-    static constexpr int inter_padx = 0;
-#endif
-#ifdef OCEAN_P2_GROUP
-    static constexpr int p2_group = OCEAN_P2_GROUP;
-#else
     static constexpr int p2_group = (inter_bshift > 0) ? 8 : 1;
-#endif
-    static constexpr int thin_threads = T * R2;
-    static constexpr int thin_lds = R2 * Pitch2<N, R2>::elems * (int)sizeof(c32);
-    static constexpr int half_threads2 = T2 * R2h * (ppar ? 2 : 1);  // fused pass 2 (half-spectrum path)
+    static constexpr int half_threads2 = T2 * R2h * (ppar ? 2 : 1);  // fused pass 2
     static constexpr int half_grid2 = N / R2h;
     static constexpr int half_lines2 = R2h * Pitch2<N, R2h>::elems * (int)sizeof(c32);
     static constexpr int half_lds2 = ppar ? (2 * half_lines2 + R2h * N * (int)sizeof(float)) : half_lines2;
-    static constexpr int thin_grid = N / R2;
     static constexpr int half_grid1 = (N / 2) / P;                 // column groups
     // staged path with the chunked hand-off (k_stage_rows / k_stage_cols): 4 lines per workgroup
-    static constexpr bool stage_chunked = (N <= 4096) && CHUNK_W == 4 && CHUNK_R == 4;
+    static constexpr bool stage_chunked = (N <= 4096);
     static constexpr int stage_threads = 4 * T;
     static constexpr int stage_lds = 4 * line_bytes;
     static constexpr int stage_grid = N / 4;
-    // split geometry (lines as two interleaved N/2 transforms; k_half_pass1_split / k_half_pass2_split)
+    // split geometry (lines as two interleaved N/2 transforms; k_half_pass1_split / k_half_pass2_split): N = 8192 in the
+    // product, any N >= 512 in the emulation
     static constexpr bool can_split = (P == 2) && (N >= 512);
-    static constexpr int split_lds1 = max_i(2 * P * LinePitch<N / 2>::elems * (int)sizeof(c32), DmaRingBytes<(dma && can_split), N, E1S, P, 2>::value);
+    static constexpr int split_lds1 = max_i(2 * P * LinePitch<N / 2>::elems * (int)sizeof(c32), DmaRingBytes<can_split, N, E1S, P, 2>::value);
     static constexpr int split_lds2 = 2 * LinePitch<N / 2>::elems * (int)sizeof(c32);
     static constexpr int split_threads2 = T;
     // One tile sharded over `world` GPUs (ocean_tile_pass1 / ocean_tile_pass2): rank r owns the half-spectrum columns
@@ -2317,8 +1476,8 @@ template <int N, int PSEL = 0> struct Geo {
         while ((1 << l.rank_bits) < world) ++l.rank_bits;
         return l;
     }
-    static_assert(row_threads <= 1024 && col_threads <= 1024 && frame_threads <= 1024, "workgroup too large");
-    static_assert(col_lds <= 160 * 1024 && frame_lds <= 160 * 1024, "LDS budget (gfx950: 160 KiB)");
+    static_assert(row_threads <= 1024 && col_threads <= 1024 && half_threads1 <= 1024, "workgroup too large");
+    static_assert(col_lds <= 160 * 1024 && half_lds1 <= 160 * 1024, "LDS budget (gfx950: 160 KiB)");
 };
 
 }  // namespace ocean

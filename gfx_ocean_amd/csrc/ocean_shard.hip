@@ -10,8 +10,11 @@
 struct OceanShard {
     int device = 0, n = 0, rank = 0, world = 1, rows = 0;      // rows = columns per rank = n / world
     hipStream_t stream = nullptr;
-    hipEvent_t last = nullptr;    // recorded behind the most recent rows / cols launches on whichever stream they ran on:
-    bool last_valid = false;      // sync / upload / destroy wait for it (the caller's stream is never named again)
+    // One event per entry point (rows, cols), recorded behind its most recent launches on whichever stream they ran on:
+    // sync / upload / destroy wait for BOTH (rows may run on one caller stream and cols on another; the caller's
+    // streams are never named again).
+    hipEvent_t last[2] = {nullptr, nullptr};
+    bool last_valid[2] = {false, false};
     c32* h0_own = nullptr;        // rows [rank rows, (rank+1) rows) of the initial spectrum
     c32* h0_partner = nullptr;    // rows [n - (rank+1) rows, n - rank rows): where the "-k" partners live (propagate.comp:48)
     float* omega = nullptr;       // own rows of the dispersion
@@ -78,12 +81,13 @@ template <int N> struct ShardLaunch {
 void shard_free_all(OceanShard* s) {
     auto f = [](void* p) { if (p) (void)hipFree(p); };
     f(s->h0_own); f(s->h0_partner); f(s->omega); f(s->fld[0]); f(s->fld[1]); f(s->fld[2]); f(s->tw);
-    if (s->last) (void)hipEventDestroy(s->last);
+    for (hipEvent_t e : s->last) if (e) (void)hipEventDestroy(e);
     if (s->stream) (void)hipStreamDestroy(s->stream);
 }
 // Everything this shard has launched, on its own stream or a caller's, has completed.
 hipError_t shard_wait_all(OceanShard* s) {
-    if (s->last_valid) { hipError_t e = hipEventSynchronize(s->last); if (e != hipSuccess) return e; }
+    for (int i = 0; i < 2; ++i)
+        if (s->last_valid[i]) { hipError_t e = hipEventSynchronize(s->last[i]); if (e != hipSuccess) return e; }
     return hipStreamSynchronize(s->stream);
 }
 
@@ -110,7 +114,8 @@ int32_t ocean_shard_create(int32_t device, int32_t resolution, int32_t rank, int
     auto bail = [&](hipError_t err, const char* what) { const int32_t c = shard_hip_fail(nullptr, err, what); shard_free_all(s); delete s; return c; };
 #define CREATE_TRY(expr) do { hipError_t e2_ = (expr); if (e2_ != hipSuccess) return bail(e2_, #expr); } while (0)
     CREATE_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-    CREATE_TRY(hipEventCreateWithFlags(&s->last, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&s->last[0], hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&s->last[1], hipEventDisableTiming));
     CREATE_TRY(hipMalloc((void**)&s->h0_own, block * sizeof(c32)));
     CREATE_TRY(hipMalloc((void**)&s->h0_partner, block * sizeof(c32)));
     CREATE_TRY(hipMalloc((void**)&s->omega, block * sizeof(float)));
@@ -178,8 +183,8 @@ int32_t ocean_shard_rows(OceanShard* s, const OceanPropagateLocals* locals, void
     for (int f = 0; f < 3; ++f) SHARD_DISPATCH(s->n, L::rows(s, f, (c32*)send_device, st));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return shard_hip_fail(s, e, "ocean_shard_rows launch");
-    SHARD_TRY(s, hipEventRecord(s->last, st));
-    s->last_valid = true;
+    SHARD_TRY(s, hipEventRecord(s->last[0], st));
+    s->last_valid[0] = true;
     return OCEAN_OK;
 }
 
@@ -204,8 +209,8 @@ int32_t ocean_shard_cols(OceanShard* s, const void* recv_device, void* out_rgba_
                        s->rank * cols, cols);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return shard_hip_fail(s, e, "ocean_shard_cols launch");
-    SHARD_TRY(s, hipEventRecord(s->last, st));
-    s->last_valid = true;
+    SHARD_TRY(s, hipEventRecord(s->last[1], st));
+    s->last_valid[1] = true;
     return OCEAN_OK;
 }
 

@@ -182,6 +182,20 @@ class OceanDevice:
         self._check(load_library().ocean_time_frames(self._ctx, int(frames), float(t0), float(dt), ctypes.byref(ms)))
         return float(ms.value)
 
+    def time_frame_batches(self, batches: int, frames_per_batch: int = 10, t0: float = 0.0, dt: float = 1.0 / 60.0):
+        """Milliseconds of each of `batches` consecutive batches of fused frames (one stream event between batches, one sync
+        at the end): the frame-time distribution of an undisturbed loop (ocean_time_frame_batches)."""
+        ms = (ctypes.c_float * int(batches))()
+        self._check(load_library().ocean_time_frame_batches(self._ctx, int(batches), int(frames_per_batch), float(t0), float(dt), ms))
+        return [float(v) for v in ms]
+
+    def frame_times(self, frames: int, t0: float = 0.0, dt: float = 1.0 / 60.0):
+        """Per-frame (pass1_ms, pass2_ms, period_ms) lists of a back-to-back loop of `frames` fused frames, from events bound
+        to the dispatches (ocean_frame_times)."""
+        arr = [(ctypes.c_float * int(frames))() for _ in range(3)]
+        self._check(load_library().ocean_frame_times(self._ctx, int(frames), float(t0), float(dt), *arr))
+        return tuple([float(v) for v in a] for a in arr)
+
     def _profile(self, fn, time):
         cap = 16
         names = (ctypes.c_char_p * cap)()

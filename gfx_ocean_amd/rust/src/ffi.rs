@@ -63,6 +63,8 @@ extern "C" {
     pub fn ocean_bind_displacement(ctx: *mut OceanContext, device_rgba: *mut c_void) -> i32;
     pub fn ocean_stream(ctx: *mut OceanContext) -> *mut c_void;
     pub fn ocean_time_frames(ctx: *mut OceanContext, frames: i32, t0: f32, dt: f32, out_ms: *mut f32) -> i32;
+    pub fn ocean_time_frame_batches(ctx: *mut OceanContext, batches: i32, frames_per_batch: i32, t0: f32, dt: f32, batch_ms: *mut f32) -> i32;
+    pub fn ocean_frame_times(ctx: *mut OceanContext, frames: i32, t0: f32, dt: f32, pass1_ms: *mut f32, pass2_ms: *mut f32, period_ms: *mut f32) -> i32;
     pub fn ocean_profile_frame(ctx: *mut OceanContext, time: f32, cap: i32, names: *mut *const c_char,
                                ms: *mut f32, out_n: *mut i32) -> i32;
     pub fn ocean_profile_staged(ctx: *mut OceanContext, time: f32, cap: i32, names: *mut *const c_char,

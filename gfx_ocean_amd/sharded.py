@@ -166,7 +166,17 @@ def fused_exchange_bytes_per_rank(n: int, world: int) -> int:
 
 class HipTileBackend:
     """ocean_tile_pass1 / ocean_tile_pass2 on an ordinary OceanDevice that holds the whole tile's static inputs; torch
-    supplies the exchange buffers, the streams and the collective."""
+    supplies the exchange buffers, the streams and the collective.
+
+    UNMEASURED on more than one GPU: the pool this was developed on gives one GPU per call, so the RCCL all-to-all, the
+    two-stream pipelining (`exchange` / `join_exchanges`) and the `[part][peer][message]` buffers have run through
+    `all_to_all_single` only at world = 1; every rank's KERNELS of world 2 / 4 / 8 are checked on one device against the
+    oracle (tests/test_sharded.py), the multi-rank driver under gloo on the CPU emulation backend.
+
+    Every rank keeps the whole tile's static inputs (12 B/texel, uploaded once): pass 1 of rank r reads only the 4/R of
+    the transposed lines its column block touches (lines x, x-1, N-x, N-1-x for its x), but they are scattered over the
+    whole of h0T / omegaT -- two bands around r N/2R and N - r N/2R -- and the context's upload, transposes and the
+    single-GPU `ocean_frame` share those buffers; with 288 GB per GPU the 1.5 GiB of a 8192 tile is not what limits a rank."""
 
     def __init__(self, n: int, rank: int, world: int, device_ordinal: int = 0, parts: int = 1):
         import torch
@@ -226,8 +236,8 @@ class HipTileBackend:
 class FusedShardedTile:
     """frame(t) = pass 1 on the rank's half-spectrum columns -> all-to-all (12 B/texel in total) -> pass 2 on the rank's
     rows.  With backend.parts = K > 1 the column block is cut into K pieces and the exchange into K all-to-alls on a second
-    stream: the exchange of piece k runs under pass 1 of piece k + 1 (over xGMI a rank's 7 peer messages move in parallel,
-    ~0.1 ms per 100 MB, against ~0.2 ms of pass 1 at N = 4096 on 8 ranks... per piece both shrink alike).
+    stream: the exchange of piece k runs under pass 1 of piece k + 1 (how much of the exchange that hides is UNMEASURED:
+    no run of this class has had more than one GPU, see HipTileBackend).
     The result is distributed by ROW blocks in the natural orientation: out[y - r N/R, x] = (dx, h, dz, 0).
     `dist`: an initialised torch.distributed (RCCL on GPUs, gloo in the CPU tests); None only for world == 1."""
 

@@ -35,9 +35,10 @@
 extern "C" {
 #endif
 
-/* 2: + ocean_checksum_displacement, ocean_pack_displacement, ocean_packed_bytes, the ocean_shard_* family (additive);
- *    readbacks wait for the whole device once a dispatch has been put on a caller stream */
-#define OCEAN_ABI_VERSION 2
+/* 2: + ocean_set_intermediate, ocean_intermediate, ocean_tile_exchange_bytes, ocean_tile_pass1, ocean_tile_pass2 (additive);
+ *    readbacks wait for the whole device once a dispatch has been put on a caller stream
+ * 3: + ocean_frame_times, ocean_time_frame_batches (additive); ocean_sync and ocean_context_destroy honour caller streams like the readbacks */
+#define OCEAN_ABI_VERSION 3
 
 /* ---- status codes ------------------------------------------------------------------------- */
 #define OCEAN_OK 0
@@ -158,7 +159,9 @@ int32_t ocean_read_normals(OceanContext* ctx, float* host_xyz0 /* N*N*4 */);
 int32_t ocean_positions(OceanContext* ctx, int32_t verts, float offset_x, float offset_z, void* stream);
 int32_t ocean_read_positions(OceanContext* ctx, float* host_xyz1 /* verts*verts*4 */);
 
-int32_t ocean_sync(OceanContext* ctx); /* wait for the context stream (the reference never waits: src/render.rs:1068-1075) */
+/* Wait for everything this context has launched: its own stream, or -- once any dispatch was put on a caller stream -- the
+ * whole device, like the readbacks and ocean_context_destroy (the reference never waits: src/render.rs:1068-1075). */
+int32_t ocean_sync(OceanContext* ctx);
 
 /* ---- readback / injection (the reference has none; needed for parity checks) -------------- */
 int32_t ocean_read_displacement(OceanContext* ctx, float* host_rgba /* N*N*4 */);
@@ -187,6 +190,18 @@ void* ocean_stream(OceanContext* ctx);                            /* the context
 /* ---- measurement (HIP events on the stream the kernels run on) -------------------------------- */
 /* Runs `frames` frames (time = t0 + i*dt) on the context stream between two events; *out_ms = total. */
 int32_t ocean_time_frames(OceanContext* ctx, int32_t frames, float t0, float dt, float* out_ms);
+/* `batches` (<= 4096) x `frames_per_batch` fused frames back to back with one stream event between batches and one sync at
+ * the end: batch_ms[b] = duration of batch b.  The distribution SURVEY 8d asks for (median, p10 / p90 of a frame in an
+ * undisturbed loop); the reference's only timing is an EMA of the vsync-bound frame delta (src/lib.rs:146-148). */
+int32_t ocean_time_frame_batches(OceanContext* ctx, int32_t batches, int32_t frames_per_batch, float t0, float dt,
+                                 float* batch_ms);
+/* Per-frame times of a back-to-back loop of `frames` (<= 4096) fused frames, from events bound to the dispatches themselves
+ * (the kernels' own begin/end timestamps): pass1_ms[i] / pass2_ms[i] = the two kernels of frame i, period_ms[i] = begin of
+ * frame i -> begin of frame i + 1 (the last entry: begin of pass 1 -> end of pass 2).  Any array may be NULL.  Per-KERNEL
+ * distributions; the event-carrying launches leave larger gaps between kernels than plain ones (+5 % on the period at
+ * N = 4096), so the frame's own distribution comes from ocean_time_frame_batches. */
+int32_t ocean_frame_times(OceanContext* ctx, int32_t frames, float t0, float dt, float* pass1_ms, float* pass2_ms,
+                          float* period_ms);
 /* Per-kernel durations of ONE frame (begin/end timestamps of each dispatch, as rocprofv3 reports them; the
  * frame runs behind two untimed ones): names/ms arrays of capacity `cap`; returns count via *out_n. */
 int32_t ocean_profile_frame(OceanContext* ctx, float time, int32_t cap, const char** names, float* ms,

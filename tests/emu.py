@@ -6,7 +6,7 @@ import subprocess
 import numpy as np
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# OCEAN_EMU_FLAGS="-DOCEAN_CHUNK_W=2 -DOCEAN_CHUNK_R=8 ..." builds (and loads) an A/B variant of the kernels
+# OCEAN_EMU_FLAGS="-DOCEAN_DMA_MIN_N=256" builds (and loads) the emulation with the LDS-DMA loader at every size
 _FLAGS = os.environ.get("OCEAN_EMU_FLAGS", "").split()
 _TAG = ("_" + "_".join(f.replace("-D", "").replace("=", "") for f in _FLAGS)) if _FLAGS else ""
 _SO = os.path.join(_ROOT, "tests", "hipemu", f"libocean_emu{_TAG}.so")
@@ -32,9 +32,6 @@ def lib():
     if _LIB is None:
         build()
         _LIB = ctypes.CDLL(_SO)
-        _LIB.emu_frame_pass1.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_size_t] * 3 + [ctypes.c_float] * 2
-        _LIB.emu_frame_pass2.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_size_t] * 3
-        _LIB.emu_frame_pass2_thin.argtypes = _LIB.emu_frame_pass2.argtypes
         _LIB.emu_frame_half.argtypes = ([ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_float] + [ctypes.c_void_p] * 5 +
                                         [ctypes.c_size_t] * 3 + [ctypes.c_int] + [ctypes.c_float] * 2 + [ctypes.c_void_p])
         _LIB.emu_fft_lines.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
@@ -114,24 +111,7 @@ def unpack_inter(inter, n, P, lay, f, columns=None):
     return out
 
 
-def frame(h0, omega, time, L=1000.0, return_inter=False, thin=True, layout="p2"):
-    n = h0.shape[0]
-    P = lib().emu_frame_p(n)
-    h0T = np.ascontiguousarray(h0.T, np.complex64)
-    omT = np.ascontiguousarray(omega.T, np.float32)
-    sx, sy, fs = inter_layout(n, P, layout)
-    inter = np.full(3 * fs, np.nan + 1j * np.nan, np.complex64)
-    tw = twiddles(n)
-    assert lib().emu_frame_pass1(n, _p(h0T), _p(omT), _p(inter), _p(tw), sx, sy, fs, time, L) == 0
-    out = np.full((n, n, 4), np.nan, np.float32)
-    p2 = lib().emu_frame_pass2_thin if thin else lib().emu_frame_pass2
-    assert p2(n, _p(inter), _p(out), _p(tw), sx, sy, fs) == 0
-    if return_inter:
-        return out, inter, (P, (sx, sy, fs))
-    return out
-
-
-def half_layout(n, P, layout="p2", pad=32, bshift=None, padx=None):
+def half_layout(n, P, layout="p2", pad=32, bshift=None):
     """(sx, sy, fs, bshift) of the half-spectrum intermediate (N/2 columns) -- mirrors ocean_context_create:
     chunk (X, Y) at (Y / B) * sy + X * sx + (Y % B) * 16, B = 2^bshift.  layout "p2" = B 1, "p1" = B N/4 (all chunk
     rows), "default" = what the build ships for this N (Geo::inter_bshift); an explicit bshift overrides."""
@@ -140,16 +120,18 @@ def half_layout(n, P, layout="p2", pad=32, bshift=None, padx=None):
     if bshift is None:
         if layout == "default":
             bshift = lib().emu_inter_bshift(n)
-            padx = lib().emu_inter_padx(n) if padx is None else padx
         else:
             bshift = 0 if layout == "p2" else gy.bit_length() - 1
     bshift = min(bshift, gy.bit_length() - 1)
-    if padx is None:
-        padx = 32 if bshift > 0 else 0
     B = 1 << bshift
-    sx = B * 16 + padx
+    sx = B * 16
     sy = gx * sx + pad
     return sx, sy, sy * (gy // B), bshift
+
+
+def uses_dma(n, P=None, split=False):
+    """True when fused pass 1 of this geometry streams its inputs through the LDS-DMA ring (half_load_AB_dma)."""
+    return bool(lib().emu_uses_dma(n, 22 if split else int(P or 0)))
 
 
 def quantize_f16(h0):

@@ -50,35 +50,13 @@ template <int N> static int run_fft_lines(int col, c32* data, const c32* tw) {
     else emu_launch(G::row_grid, G::row_threads, [&] { k_fft_lines<N, G::E, G::ROW_LPW, false>(data, tw); });
     return 0;
 }
-template <int N> static int run_pass1(const c32* h0T, const float* omT, c32* inter, const c32* tw, InterLayout lay,
-                                      float time, float L) {
-    using G = Geo<N>;
-    if constexpr (CHUNK_W % G::P != 0) return -4;
-    else emu_launch(G::frame_grid, G::frame_threads,
-               [&] { k_frame_pass1<N, G::E, G::P>(h0T, omT, inter, tw, lay, time, L); });
-    return 0;
-}
-template <int N> static int run_pass2(const c32* inter, float4* out, const c32* tw, InterLayout lay) {
-    using G = Geo<N>;
-    if constexpr (G::P != CHUNK_W || G::P != CHUNK_R) return -4;
-    else emu_launch(G::frame_grid, G::frame_threads, [&] { k_frame_pass2<N, G::E, G::P>(inter, out, tw, lay); });
-    return 0;
-}
-
-template <int N> static int run_pass2_thin(const c32* inter, float4* out, const c32* tw, InterLayout lay) {
-    using G = Geo<N>;
-    emu_launch(G::thin_grid, G::thin_threads,
-               [&] { k_frame_pass2_thin<N, G::E, CHUNK_W, G::R2>(inter, out, tw, lay); });
-    return 0;
-}
-
 template <int N, int PSEL> static int run_half_p(const void* h0T, int f16, float descale, const float* omT, c32* inter, c32* nyq,
                                                  float4* out, const c32* tw, InterLayout lay, float time, float L) {
     using G = Geo<N, PSEL>;
     if (f16) emu_launch(G::half_grid1, G::half_threads1,
-                        [&] { k_half_pass1<N, G::E1, G::P, true, G::loader, G::fpar>(h0T, descale, omT, inter, nyq, tw, lay, time, L, 0); });
+                        [&] { k_half_pass1<N, G::E1, G::P, true, G::dma, G::fpar>(h0T, descale, omT, inter, nyq, tw, lay, time, L, 0); });
     else emu_launch(G::half_grid1, G::half_threads1,
-                    [&] { k_half_pass1<N, G::E1, G::P, false, G::loader, G::fpar>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L, 0); });
+                    [&] { k_half_pass1<N, G::E1, G::P, false, G::dma, G::fpar>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L, 0); });
     emu_launch(G::half_grid2, G::half_threads2,
                [&] { k_half_pass2<N, G::E2, CHUNK_W, G::R2h, G::p2_group, G::ppar>(inter, out, tw, lay); });
     return 0;
@@ -88,9 +66,9 @@ template <int N, bool I16> static int run_half_split(const void* h0T, int f16, f
     using G = Geo<N, 2>;
     static_assert(G::can_split, "split geometry");
     if (f16) emu_launch(G::half_grid1, G::split_threads1,
-                        [&] { k_half_pass1_split<N, G::E1S, G::P, true, G::loader, I16>(h0T, descale, omT, inter, nyq, tw, lay, time, L, 0, scales); });
+                        [&] { k_half_pass1_split<N, G::E1S, G::P, true, I16>(h0T, descale, omT, inter, nyq, tw, lay, time, L, 0, scales); });
     else emu_launch(G::half_grid1, G::split_threads1,
-                    [&] { k_half_pass1_split<N, G::E1S, G::P, false, G::loader, I16>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L, 0, scales); });
+                    [&] { k_half_pass1_split<N, G::E1S, G::P, false, I16>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L, 0, scales); });
     emu_launch(N, G::split_threads2, [&] { k_half_pass2_split<N, G::E, CHUNK_W, G::p2_group, false, I16>(inter, out, tw, lay, scales); });
     return 0;
 }
@@ -118,9 +96,9 @@ template <int N, int PSEL> static int run_tile_pass1(int rank, int world, int pa
     const int groups = (N / 2 / world / parts) / G::P;
     const int x_group0 = (rank * parts + part) * groups;
     if (f16) emu_launch(groups, G::half_threads1,
-                        [&] { k_half_pass1<N, G::E1, G::P, true, G::loader, G::fpar>(h0T, descale, omT, send, nyq, tw, lay, time, L, x_group0); });
+                        [&] { k_half_pass1<N, G::E1, G::P, true, G::dma, G::fpar>(h0T, descale, omT, send, nyq, tw, lay, time, L, x_group0); });
     else emu_launch(groups, G::half_threads1,
-                    [&] { k_half_pass1<N, G::E1, G::P, false, G::loader, G::fpar>(h0T, 1.0f, omT, send, nyq, tw, lay, time, L, x_group0); });
+                    [&] { k_half_pass1<N, G::E1, G::P, false, G::dma, G::fpar>(h0T, 1.0f, omT, send, nyq, tw, lay, time, L, x_group0); });
     return 0;
 }
 template <int N, int PSEL> static int run_tile_pass2(int world, int parts, const c32* recv, float4* out, const c32* tw) {
@@ -197,8 +175,10 @@ int emu_inter_bshift(int n) {
     DISPATCH(n, C_)
 #undef C_
 }
-int emu_inter_padx(int n) {
-#define C_(N) Geo<N>::inter_padx
+// 1 when fused pass 1 of this size takes its inputs through the LDS-DMA ring (psel as emu_frame_half: 22 / 23 = split kernels, always)
+int emu_uses_dma(int n, int psel) {
+    if (psel == 22 || psel == 23) return 1;
+#define C_(N) ((psel == 2) ? (int)Geo<N, 2>::dma : (psel == 1) ? (int)Geo<N, 1>::dma : (int)Geo<N, 0>::dma)
     DISPATCH(n, C_)
 #undef C_
 }
@@ -209,22 +189,6 @@ int emu_frame_p(int n) {
 }
 int emu_fft_lines(int n, int col, float* data, const float* tw) {
 #define C_(N) run_fft_lines<N>(col, (c32*)data, (const c32*)tw)
-    DISPATCH(n, C_)
-#undef C_
-}
-int emu_frame_pass1(int n, const float* h0T, const float* omT, float* inter, const float* tw, size_t sx, size_t sy,
-                    size_t fs, float time, float L) {
-#define C_(N) run_pass1<N>((const c32*)h0T, omT, (c32*)inter, (const c32*)tw, InterLayout{sx, sy, fs}, time, L)
-    DISPATCH(n, C_)
-#undef C_
-}
-int emu_frame_pass2(int n, const float* inter, float* out, const float* tw, size_t sx, size_t sy, size_t fs) {
-#define C_(N) run_pass2<N>((const c32*)inter, (float4*)out, (const c32*)tw, InterLayout{sx, sy, fs})
-    DISPATCH(n, C_)
-#undef C_
-}
-int emu_frame_pass2_thin(int n, const float* inter, float* out, const float* tw, size_t sx, size_t sy, size_t fs) {
-#define C_(N) run_pass2_thin<N>((const c32*)inter, (float4*)out, (const c32*)tw, InterLayout{sx, sy, fs})
     DISPATCH(n, C_)
 #undef C_
 }

@@ -16,9 +16,6 @@ static inline c32 xx(c32 a) { return c32{a.x, a.x}; }
 static inline c32 yy(c32 a) { return c32{a.y, a.y}; }
 static inline c32 yx(c32 a) { return c32{a.y, a.x}; }
 static inline c32 vfma(c32 a, c32 b, c32 c) { return c32{std::fmaf(a.x, b.x, c.x), std::fmaf(a.y, b.y, c.y)}; }
-struct c32_pair { c32 a, b; };
-struct u32_pair { uint32_t a, b; };
-struct f32_pair { float a, b; };
 static inline int opaque_lane(int x) { return x; }
 static inline float ocean_emu_half_to_float(uint16_t h) {
     const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
@@ -35,12 +32,9 @@ static inline c32 unpack_half2(uint32_t bits, float descale) {
                        ocean_emu_half_to_float((uint16_t)(bits >> 16)) * descale);
 }
 static inline int wave_uniform(int x) { return x; }
-static inline void wave_priority(int) {}
 static inline float sin_rev(float x) { return (float)std::sin(6.283185307179586 * (double)x); }
 static inline float cos_rev(float x) { return (float)std::cos(6.283185307179586 * (double)x); }
 static inline void store_float4_nt(float4* p, float4 v) { *p = v; }
-static inline float load_float_nt(const float* p) { return *p; }
-static inline int opaque_after(int x, float) { return x; }
 static inline void pin_here(c32&, c32&) {}
 template <int T> static inline void line_sync() { __syncthreads(); }   // host threads are not a wave: always the full barrier
 static inline void workgroup_publish() { __syncthreads(); }       // the emulation's barrier is a full fence

@@ -73,38 +73,6 @@ def test_emu_correct(ref_inputs_256):
     assert np.array_equal(emu.correct(h, dx, dz), oc.correction_literal(h, dx, dz))
 
 
-@pytest.mark.parametrize("thin", [True, False])
-@pytest.mark.parametrize("t", [0.0, 1.0, 100.0])
-def test_emu_fused_frame_256(ref_inputs_256, t, thin):
-    h0, om = ref_inputs_256
-    out, inter, _ = emu.frame(h0, om, t, return_inter=True, thin=thin)
-    assert not np.isnan(out).any()
-    assert_parity(out[..., :3], oc.frame_f64(h0, om, t)[..., :3], 5e-6, "emu fused frame")
-    assert np.all(out[..., 3] == 0.0)
-
-
-@pytest.mark.parametrize("thin", [True, False])
-def test_emu_fused_frame_512(ref_inputs, thin):
-    h0, om = ref_inputs
-    out = emu.frame(h0, om, 10.0, thin=thin)
-    assert_parity(out[..., :3], oc.frame_f64(h0, om, 10.0)[..., :3], 5e-6, "emu fused frame 512")
-
-
-@pytest.mark.parametrize("layout", ["p2", "p1"])
-def test_emu_intermediate_layout(ref_inputs_256, layout):
-    """pass 1 writes P x P chunks: chunk (X, Y) of field f at f*fs + X*sx + Y*sy, element (r, c) at
-    r*P + c = the FFT along y of field f at (y = Y*P + r, x = X*P + c); padding is never written."""
-    h0, om = ref_inputs_256
-    n = 256
-    out, inter, (P, lay) = emu.frame(h0, om, 2.0, return_inter=True, layout=layout)
-    h, dx, dz = oc.propagate_f64(h0, om, 2.0)
-    for f, spec in ((0, dx), (1, h), (2, dz)):
-        ref = np.fft.ifft(spec, axis=0) * n          # transform along y only
-        assert_parity(emu.unpack_inter(inter, n, P, lay, f), ref, 5e-6, f"intermediate field {f}")
-    assert np.isnan(inter.real).sum() == 3 * (lay[2] - n * n)     # exactly the padding is untouched
-    assert_parity(out[..., :3], oc.frame_f64(h0, om, 2.0)[..., :3], 5e-6, "frame")
-
-
 @pytest.mark.parametrize("channel", [0, 1])
 def test_emu_normals(ref_inputs_256, channel):
     """SURVEY 8f #1: k_normals vs the restatement of shader/ocean.frag:50-66."""
@@ -239,11 +207,13 @@ def test_emu_staged_chunked_handoff(n, ref_inputs, ref_inputs_256):
     assert np.array_equal(rgba, want)
 
 
-def test_emu_handover_loaders_in_a_variant_build():
-    """The LDS hand-over of the duplicate spectrum streams (half_load_AB_pairs_handover: shipped at N = 8192;
-    half_load_AB_handover: whole lines, A/B only) runs in a build of the emulation with the hand-over enabled at every
-    size: the split geometry at 512 / 1024 (fp32 and fp16-stored spectrum), whole lines with four columns per workgroup
-    at 256 and two at 512.  Own process: the flags are read at import."""
+def test_emu_dma_loader_at_every_size():
+    """The LDS-DMA loader of fused pass 1 (half_load_AB_dma: N >= 2048 in the product) in a build of the emulation that
+    enables it at every size, so that the ring's index algebra (pieces, slots, the three edge values carried from piece
+    to piece, the deferred element of piece 0), its barrier protocol and its 1 KiB instruction slots are checked against
+    the oracle at sizes the CPU can run: whole lines with four columns per workgroup (256: one piece of eight elements),
+    two (512) and two with one-wave lines (1024, four pieces); the split geometry at 512 / 1024; fp32 and fp16-stored
+    spectrum.  Own process: the flags are read at import."""
     import subprocess
     import sys
     code = r"""
@@ -256,20 +226,29 @@ h0, om = oc.load_reference_inputs(GOLDEN + "/spectrum.bin", GOLDEN + "/omega.bin
 h256, o256 = oc.centre_crop(h0, 256), oc.centre_crop(om, 256)
 h1k, o1k = g.synth.make_inputs(1024, seed=4)
 for (h, o, kw, what) in ((h0, om, dict(split=True), "split 512"), (h1k, o1k, dict(split=True), "split 1024"),
-                         (h256, o256, dict(), "lines 256 P=4"), (h0, om, dict(), "lines 512 P=2")):
+                         (h256, o256, dict(), "lines 256 P=4"), (h0, om, dict(P=2), "lines 512 P=2"), (h1k, o1k, dict(), "lines 1024")):
+    assert emu.uses_dma(h.shape[0], kw.get("P"), kw.get("split", False)), what
     out = emu.frame_half(h, o, 2.5, **kw)
     assert_parity(out[..., :3], oc.frame_f64(h, o, 2.5)[..., :3], 5e-6, what)
 _, deq, _ = emu.quantize_f16(h0)
-for kw in (dict(split=True),):
+for kw in (dict(split=True), dict(P=2)):
     out = emu.frame_half(h0, om, 1.0, spectrum_fp16=True, **kw)
     assert_parity(out[..., :3], oc.frame_f64(deq, om, 1.0)[..., :3], 5e-6, "fp16 spectrum " + str(kw))
-print("HANDOVER_EMU_OK")
+print("DMA_EMU_OK")
 """
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, OCEAN_EMU_FLAGS="-DOCEAN_HANDOVER_MIN_N=256")
+    env = dict(os.environ, OCEAN_EMU_FLAGS="-DOCEAN_DMA_MIN_N=256")
     p = subprocess.run([sys.executable, "-c", code, root], capture_output=True, text=True, timeout=1500, env=env)
-    assert p.returncode == 0 and "HANDOVER_EMU_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+    assert p.returncode == 0 and "DMA_EMU_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
+def test_emu_default_build_loads_small_sizes_into_registers():
+    """... and the default build keeps the latency-bound sizes on the register loader (half_load_AB); the split kernels
+    always use the ring."""
+    for n in (256, 512, 1024):
+        assert not emu.uses_dma(n) and not emu.uses_dma(n, 2)
+    assert emu.uses_dma(512, split=True)
 
 
 @pytest.mark.parametrize("n", [512])

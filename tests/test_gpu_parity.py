@@ -36,7 +36,7 @@ def r256(ref_inputs_256):
 
 def test_native_library_is_loaded():
     lib = g.load_library()
-    assert lib.ocean_abi_version() == 2
+    assert lib.ocean_abi_version() == 3
     with open("/proc/self/maps") as f:
         assert "libocean_hip.so" in f.read()
 
@@ -214,6 +214,33 @@ def test_full_size_large_time_4096():
         assert nmax.max() < 3e-5
     finally:
         d.destroy()
+
+
+@pytest.mark.parametrize("t", [2.0e4, 2.0e5, 2.0e6])
+def test_phase_range_of_the_fused_propagate(t, ref_inputs):
+    """the reference feeds wall-clock seconds (src/lib.rs:139-141) into `d = omega * t`
+    (shader/propagate.comp:55-57); the fused kernels reduce that fp32 phase to revolutions with a two-constant product
+    (propagate_height) before the hardware sin/cos.  On the reference's own inputs at t = 2e4 .. 2e6 s (|omega t| up to
+    ~1e7 rad: 23 days of run time) the frame stays within the tolerance of the oracle, whose phase is the same
+    fl32(omega * t) followed by a correctly rounded sin/cos -- the bound is stated next to ocean_frame in
+    include/ocean_hip.h.  (Beyond that the PHASE ITSELF is the problem, for the reference as well: one ulp of
+    fl32(omega t) at 1e7 rad is 1 rad.)  The staged propagate (ocml sincosf) is held to the same frames."""
+    h0, om = ref_inputs
+    assert float(np.abs(om).max()) * t > 0.9 * t                    # phases really reach ~ t radians
+    ref = oc.frame_f64(h0, om, t)
+    r = g.OceanRenderer(512)
+    try:
+        r.upload(h0, om)
+        r.render_fused(t)
+        fused = r.displacement()
+        r.render(t)
+        staged = r.displacement()
+    finally:
+        r.dispose()
+    nmax_f, _ = assert_parity(fused[..., :3], ref[..., :3], TOL, f"fused, t = {t:g}")
+    nmax_s, _ = assert_parity(staged[..., :3], ref[..., :3], TOL, f"staged, t = {t:g}")
+    print(f"phase range t = {t:g}: |omega t| <= {float(np.abs(om).max()) * t:.3g} rad; normalised max fused {nmax_f.max():.2e}, staged {nmax_s.max():.2e}")
+    assert nmax_f.max() < 2e-5 and nmax_s.max() < 2e-5
 
 
 @pytest.mark.parametrize("n", [4096, 8192])
@@ -506,7 +533,9 @@ def test_stale_stage_handle_of_a_reused_context_address_is_rejected():
     """a stage handle kept after its context is destroyed must not become valid again when a new context
     happens to be allocated at the same address (handles carry the generation of their context)."""
     seen = False
-    for _ in range(8):
+    for _ in range(64):
+        if seen:
+            break
         d = g.OceanDevice(256)
         p = g.Propagation.init(d)
         addr = d._ctx.value
@@ -523,7 +552,10 @@ def test_stale_stage_handle_of_a_reused_context_address_is_rejected():
             d2.destroy()
             g.load_library().ocean_propagation_destroy(raw)
             p._h = None
-    # (address reuse is up to the allocator; the call is rejected either way)
+    # Address reuse is up to the allocator.  Without it the stale handle was rejected by the dead-context check alone and
+    # the generation comparison was never what decided: say so instead of passing.
+    if not seen:
+        pytest.skip("the allocator never handed a new context the old address in 64 tries: generation check not exercised")
 
 
 @pytest.mark.parametrize("f16", [True, False])

@@ -9,7 +9,7 @@ import test_gpu_race as t
 from gfx_ocean_amd import _lib
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 so = os.path.join(tempfile.mkdtemp(), "libocean_hip_jitter.so")
-subprocess.check_call(_lib.hipcc_command(out=so, extra=("-DOCEAN_AB", "-DOCEAN_RACE_JITTER")))
+subprocess.check_call(_lib.hipcc_command(out=so, extra=("-DOCEAN_RACE_JITTER",)))
 def sums(lib, n):
     env = dict(os.environ)
     if lib: env["OCEAN_HIP_LIB"] = lib

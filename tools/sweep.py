@@ -6,6 +6,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (moved_bytes_per_texel: the one accounting table)
 import gfx_ocean_amd as g  # noqa: E402
 
 
@@ -21,7 +22,8 @@ def main():
         d.sync()
         frames = 200 if n <= 4096 else 50
         ms = d.time_frames(frames) / frames
-        rec = {"n": n, "fused_ms": ms, "fused_fps": 1000.0 / ms, "frame_GBps": 54.0 * n * n / ms / 1e6,
+        moved = bench.moved_bytes_per_texel(n)
+        rec = {"n": n, "fused_ms": ms, "fused_fps": 1000.0 / ms, "frame_GBps": sum(moved.values()) * n * n / ms / 1e6,
                "frame_GBps_alg": 76.0 * n * n / ms / 1e6}
         reps = 10
         for kind, fn in (("fused", d.profile_frame),) + (() if fused_only else (("staged", d.profile_staged),)):
@@ -31,8 +33,8 @@ def main():
                 for name, t in fn(i / 60.0):
                     acc[name] = acc.get(name, 0.0) + t / reps
             rec[kind] = acc
-        # bytes the half-spectrum kernels move (26 / 28 B/texel) and the three-complex-transform accounting (36 / 40)
-        rec["fused_GBps"] = {k: (26.0 if "pass1" in k else 28.0) * n * n / v / 1e6 for k, v in rec["fused"].items()}
+        # bytes the half-spectrum kernels move (bench.moved_bytes_per_texel) and the three-complex-transform accounting (36 / 40)
+        rec["fused_GBps"] = {k: moved[bench.pass_of(k)] * n * n / v / 1e6 for k, v in rec["fused"].items()}
         rec["fused_GBps_contract"] = {k: (36.0 if "pass1" in k else 40.0) * n * n / v / 1e6 for k, v in rec["fused"].items()}
         if not fused_only:
             st = rec["staged"]
