@@ -20,6 +20,7 @@
 
 #include "../../include/ocean_hip.h"
 #include "ocean_kernels.hpp"
+#include "ocean_staged_kernels.hpp"
 #include "ocean_aux_kernels.hpp"
 
 using namespace ocean;
@@ -33,7 +34,7 @@ constexpr uint32_t MAGIC_FFT = 0x4F464654;
 constexpr uint32_t MAGIC_PRO = 0x4F50524F;
 constexpr uint32_t MAGIC_COR = 0x4F434F52;
 
-bool supported_n(int n) { return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096 || n == 8192; }
+bool supported_n(int n) { return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096 || n == 8192 || n == 16384; }
 
 // Every handle the library has handed out and not yet destroyed.  A handle is checked against this set before it
 // is dereferenced, so a stage object used after ocean_context_destroy, a double destroy or a stray pointer gets
@@ -153,11 +154,13 @@ template <int N> struct Launch {
     }
     // Lines per pass-1 workgroup of the fused frame, per size (measured best): one column at 512 (the
     // latency path), two where two co-resident workgroups pay (256, 1024, 2048) and where four lines do not fit the LDS
-    // (8192), four at 4096.  N = 8192 runs the split kernels (every line as two interleaved 4096-point transforms).
-    static constexpr int PSEL = (N == 512) ? 1 : ((N <= 2048 || N > 4096) ? 2 : 4);
+    // (8192), four at 4096.  N >= 8192 runs the split kernels (every line as two interleaved N/2-point transforms); at
+    // 16384 two 8192-point sub-lines fill the LDS: one column per workgroup (the size that needs several GPUs).
+    static constexpr int PSEL = (N == 512 || N > 8192) ? 1 : ((N <= 2048 || N > 4096) ? 2 : 4);
     static constexpr bool SPLIT = N > 4096;
     using H = Geo<N, PSEL>;
     static_assert(!SPLIT || H::can_split, "split geometry");
+    static constexpr bool I16_BUILT = SPLIT && H::P == 2;      // the opt-in 16-bit intermediate: N = 8192 (BASELINE config 5)
     // the shipped kernel instances of this size (fp32 / fp16-stored spectrum; split: + the opt-in 16-bit intermediate)
     template <bool H16> static constexpr auto pass1_kernel() { return k_half_pass1<N, H::E1, H::P, H16, H::dma, H::fpar>; }
     template <bool H16, bool I16> static constexpr auto pass1_split_kernel() { return k_half_pass1_split<N, H::E1S, H::P, H16, I16>; }
@@ -170,9 +173,11 @@ template <int N> struct Launch {
         };
         if constexpr (SPLIT) {
             lds(pass1_split_kernel<false, false>(), H::split_lds1); lds(pass1_split_kernel<true, false>(), H::split_lds1);
-            lds(pass1_split_kernel<false, true>(), H::split_lds1);  lds(pass1_split_kernel<true, true>(), H::split_lds1);
             lds(pass2_split_kernel<false, false>(), H::split_lds2); lds(pass2_split_kernel<true, false>(), H::split_lds2);
-            lds(pass2_split_kernel<false, true>(), H::split_lds2);
+            if constexpr (I16_BUILT) {
+                lds(pass1_split_kernel<false, true>(), H::split_lds1);  lds(pass1_split_kernel<true, true>(), H::split_lds1);
+                lds(pass2_split_kernel<false, true>(), H::split_lds2);
+            }
         } else {
             lds(pass1_kernel<false>(), H::half_lds1); lds(pass1_kernel<true>(), H::half_lds1);
             lds(pass2_kernel<false>(), H::half_lds2); lds(pass2_kernel<true>(), H::half_lds2);
@@ -190,9 +195,14 @@ template <int N> struct Launch {
         if constexpr (SPLIT) {
             const dim3 g(groups), b(H::split_threads1);
             float* scales = c->inter16 ? c->inter_scale : nullptr;   // opt-in precision mode (ocean_set_intermediate)
-            if (c->inter16 && c->h0_f16) launch(pass1_split_kernel<true, true>(), g, b, H::split_lds1, s, t, h0T, descale, omT, inter, c->nyq, tw, lay, time, domain, x_group0, scales);
-            else if (c->inter16) launch(pass1_split_kernel<false, true>(), g, b, H::split_lds1, s, t, h0T, descale, omT, inter, c->nyq, tw, lay, time, domain, x_group0, scales);
-            else if (c->h0_f16) launch(pass1_split_kernel<true, false>(), g, b, H::split_lds1, s, t, h0T, descale, omT, inter, c->nyq, tw, lay, time, domain, x_group0, scales);
+            if constexpr (I16_BUILT) {
+                if (c->inter16) {
+                    if (c->h0_f16) launch(pass1_split_kernel<true, true>(), g, b, H::split_lds1, s, t, h0T, descale, omT, inter, c->nyq, tw, lay, time, domain, x_group0, scales);
+                    else launch(pass1_split_kernel<false, true>(), g, b, H::split_lds1, s, t, h0T, descale, omT, inter, c->nyq, tw, lay, time, domain, x_group0, scales);
+                    return;
+                }
+            }
+            if (c->h0_f16) launch(pass1_split_kernel<true, false>(), g, b, H::split_lds1, s, t, h0T, descale, omT, inter, c->nyq, tw, lay, time, domain, x_group0, scales);
             else launch(pass1_split_kernel<false, false>(), g, b, H::split_lds1, s, t, h0T, descale, omT, inter, c->nyq, tw, lay, time, domain, x_group0, scales);
         } else {
             const dim3 g(groups), b(H::half_threads1);
@@ -207,8 +217,13 @@ template <int N> struct Launch {
         const c32* inter = c->inter;
         const c32* tw = c->tw;
         if constexpr (SPLIT) {
-            if (c->inter16) launch(pass2_split_kernel<false, true>(), dim3(N), dim3(H::split_threads2), H::split_lds2, s, t, inter, c->out, tw, c->lay_h, (const float*)c->inter_scale);
-            else launch(pass2_split_kernel<false, false>(), dim3(N), dim3(H::split_threads2), H::split_lds2, s, t, inter, c->out, tw, c->lay_h, (const float*)nullptr);
+            if constexpr (I16_BUILT) {
+                if (c->inter16) {
+                    launch(pass2_split_kernel<false, true>(), dim3(N), dim3(H::split_threads2), H::split_lds2, s, t, inter, c->out, tw, c->lay_h, (const float*)c->inter_scale);
+                    return;
+                }
+            }
+            launch(pass2_split_kernel<false, false>(), dim3(N), dim3(H::split_threads2), H::split_lds2, s, t, inter, c->out, tw, c->lay_h, (const float*)nullptr);
         } else {
             launch(pass2_kernel<false>(), dim3(H::half_grid2), dim3(H::half_threads2), H::half_lds2, s, t, inter, c->out, tw, c->lay_h);
         }
@@ -261,6 +276,7 @@ template <int N> struct Launch {
         case 2048: { using L = Launch<2048>; STMT; } break; \
         case 4096: { using L = Launch<4096>; STMT; } break; \
         case 8192: { using L = Launch<8192>; STMT; } break; \
+        case 16384: { using L = Launch<16384>; STMT; } break; \
         default: break;                                   \
     }
 
@@ -364,7 +380,7 @@ int32_t ocean_context_create(int32_t device, int32_t resolution, OceanContext** 
     if (!out_ctx) return fail(nullptr, OCEAN_E_INVALID_ARG, "out_ctx is NULL");
     *out_ctx = nullptr;
     if (!supported_n(resolution))
-        return fail(nullptr, OCEAN_E_UNSUPPORTED_N, "resolution must be a power of two in [256, 8192]");
+        return fail(nullptr, OCEAN_E_UNSUPPORTED_N, "resolution must be a power of two in [256, 16384]");
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess) return hip_fail(nullptr, e, "hipGetDeviceCount");
@@ -611,7 +627,7 @@ int32_t ocean_set_intermediate(OceanContext* ctx, int32_t mode) {
     if (mode != OCEAN_INTER_F32 && mode != OCEAN_INTER_BFP16) return fail(ctx, OCEAN_E_INVALID_ARG, "unknown intermediate mode");
     if (mode == OCEAN_INTER_BFP16) {
         bool ok = false;
-        OCEAN_DISPATCH(ctx->n, ok = L::SPLIT);
+        OCEAN_DISPATCH(ctx->n, ok = L::I16_BUILT);
         if (!ok) return fail(ctx, OCEAN_E_UNSUPPORTED_N, "the 16-bit intermediate exists for the split-line kernels only (N = 8192, BASELINE config 5)");
         if (!ctx->inter_scale) {
             DeviceGuard guard(ctx->device);

@@ -1,22 +1,16 @@
-// ocean_kernels.hpp -- the gfx950 kernels of the gfx-ocean hot path.
+// ocean_kernels.hpp -- the gfx950 kernels of the FUSED frame (ocean_frame), the hot path of gfx-ocean.
 //
-// Staged kernels (1:1 with the reference dispatches; the compatibility path, include/ocean_hip.h):
-//   k_propagate / k_propagate_paired  <- shader/propagate.comp:42-72
-//   k_fft_lines<ROW>, k_stage_rows    <- shader/fft_row.comp:44-63
-//   k_fft_lines<COL>, k_stage_cols    <- shader/fft_col.comp:44-63
-//   k_correct / k_correct_chunked     <- shader/correction.comp:24-35
-//   k_normals, k_positions            <- shader/ocean.frag:50-66, shader/ocean.vert:21-25
-// Fused frame (ocean_frame: 2 launches, the half-spectrum "real-output" algorithm, 52-54 B/texel of HBM traffic instead of
-// the reference's 172):
-//   k_half_pass1 / k_half_pass1_split (N = 8192): propagate + symmetrise + FFT along y of the half spectrum's columns,
-//                  reading the *transposed* static inputs (h0T, omegaT; made once at upload) so that every line is
-//                  contiguous -- at N >= 2048 streamed through LDS by LDS-DMA (half_load_AB_dma); writes the intermediate
-//                  as 4 x 4 chunks (128 bytes);
-//   k_half_pass2 / k_half_pass2_split: rebuild full rows from the half spectrum, two complex FFTs along x for the three
-//                  real channels, sign correction, RGBA rows.
-// The column transform runs first in the fused path (a separable 2-D DFT commutes), so that the pass that owns whole
-// rows is the one that writes the row-major RGBA image.
-// One tile over several GPUs: the same fused kernels on column / row blocks (x_group0, SHARD) and k_shard_* (row blocks).
+// 2 launches, the half-spectrum "real-output" algorithm, 52-54 B/texel of HBM traffic instead of the reference's 172:
+//   k_half_pass1 / k_half_pass1_split (N = 8192): propagate (shader/propagate.comp:42-72) + symmetrise + FFT along y
+//                  (shader/fft_col.comp:44-63) of the half spectrum's columns, reading the *transposed* static inputs (h0T,
+//                  omegaT; made once at upload) so that every line is contiguous -- at N >= 2048 streamed through LDS by
+//                  LDS-DMA (half_load_AB_dma); writes the intermediate as 4 x 4 chunks (128 bytes);
+//   k_half_pass2 / k_half_pass2_split: rebuild full rows from the half spectrum, two complex FFTs along x
+//                  (shader/fft_row.comp:44-63) for the three real channels, sign correction and RGBA pack
+//                  (shader/correction.comp:24-35), whole-row stores.
+// The column transform runs first (a separable 2-D DFT commutes), so that the pass that owns whole rows is the one that
+// writes the row-major RGBA image.  One tile over several GPUs: the same kernels on column / row blocks (x_group0, SHARD).
+// The staged 1:1 kernels, the map's consumers and the row-block sharding kernels: ocean_staged_kernels.hpp.
 //
 // Every kernel in this file ships; measured dead ends live in git history and DESIGN.md 4.3-4.6, not here.
 // No launches in this header: it is also compiled by the host emulation harness (tests/hipemu) that checks the index
@@ -88,193 +82,8 @@ __device__ __forceinline__ void k_normalised_fast(float kx, float ky, float& knx
 // complex_mul(vec2(0, -kn), h) = (kn*h.y, -kn*h.x)   (:70-71)
 __device__ __forceinline__ c32 mul_minus_i_kn(float kn, c32 h) { return yx(h) * mk(kn, -kn); }
 
-// ---------------------------------------------------------------------------------------------
-// Staged kernels
-// ---------------------------------------------------------------------------------------------
-// One thread per 2 texels of a block of `rows` rows starting at row `row0` (the whole tile: row0 = 0, rows = N;
-// grid = rows*N/2/256).  h0 / omega / outputs point at the block's first texel; h0_partner points at the first texel
-// of the rows the "-k" partners live in: the block itself for the whole tile, the opposite row block
-// [N - row0 - rows, N - row0) when the tile is sharded by row blocks (Q2 on only).
-__global__ void __launch_bounds__(256)
-k_propagate(const c32* __restrict__ h0, const c32* __restrict__ h0_partner, const float* __restrict__ omega,
-            c32* __restrict__ height, c32* __restrict__ disp_x, c32* __restrict__ disp_z, int n, int row0, int rows,
-            float time, float domain_size, uint32_t quirks) {
-    const uint32_t un = (uint32_t)n;
-    const uint32_t pair = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t total = un * (uint32_t)rows;
-    const uint32_t index = pair * 2u;
-    if (index >= total) return;
-    const uint32_t gx = index % un, gy = index / un + (uint32_t)row0;   // gx even, gx+1 same row
-    const float4 own = *reinterpret_cast<const float4*>(h0 + index);
-    // index_neg = N*N-1-index (:48): row N-1-gy reversed, i.e. the partner block read backwards; the pair
-    // (index, index+1) mirrors to (ineg, ineg-1).  With Q2 off the partners are columns ((N+1-gx)%N, (N-gx)%N) of
-    // row (N+1-gy)%N: the same reversed pair, other base (whole-tile calls only).
-    const bool q2 = (quirks & OCEAN_QUIRK_Q2) != 0u;
-    const uint32_t pbase = q2 ? (total - 2u - index) : (((un + 1u - gy) & (un - 1u)) * un + ((un - gx) & (un - 1u)));
-    float4 neg = *reinterpret_cast<const float4*>(h0_partner + pbase);
-    if (!q2) { neg.y = -neg.y; neg.w = -neg.w; }                   // conjugated partner
-    const c32 om = *reinterpret_cast<const c32*>(omega + index);
-    const float ky = OCEAN_PI_F * wave_index(gy, un, quirks) / domain_size;
-    const float kx0 = OCEAN_PI_F * wave_index(gx, un, quirks) / domain_size;
-    const float kx1 = OCEAN_PI_F * wave_index(gx + 1u, un, quirks) / domain_size;
-    const c32 h0v = propagate_height(mk(own.x, own.y), mk(neg.z, neg.w), om.x, time);
-    const c32 h1v = propagate_height(mk(own.z, own.w), mk(neg.x, neg.y), om.y, time);
-    float knx0, kny0, knx1, kny1;
-    k_normalised(kx0, ky, knx0, kny0);
-    k_normalised(kx1, ky, knx1, kny1);
-    const c32 dx0 = mul_minus_i_kn(knx0, h0v), dx1 = mul_minus_i_kn(knx1, h1v);
-    const c32 dz0 = mul_minus_i_kn(kny0, h0v), dz1 = mul_minus_i_kn(kny1, h1v);
-    *reinterpret_cast<float4*>(height + index) = make_float4(h0v.x, h0v.y, h1v.x, h1v.y);
-    *reinterpret_cast<float4*>(disp_x + index) = make_float4(dx0.x, dx0.y, dx1.x, dx1.y);
-    *reinterpret_cast<float4*>(disp_z + index) = make_float4(dz0.x, dz0.y, dz1.x, dz1.y);
-}
-
-// The whole tile with the reference quirks: texel i and its "-k" partner N*N-1-i (propagate.comp:48) use the SAME two
-// spectrum values with the roles swapped, so one thread does two adjacent texels AND their two partners from one pair of
-// 16-byte loads: 12 instead of 20 bytes read per texel (k_propagate re-reads every h0 texel as somebody's partner:
-// 738 MB counted at N = 4096 where 604 are the algorithm's).  Same arithmetic per texel as
-// k_propagate: bit-identical fields.  grid = N*N/4/256.
-__global__ void __launch_bounds__(256)
-k_propagate_paired(const c32* __restrict__ h0, const float* __restrict__ omega, c32* __restrict__ height, c32* __restrict__ disp_x,
-                   c32* __restrict__ disp_z, int n, float time, float domain_size) {
-    const uint32_t un = (uint32_t)n;
-    const uint32_t total = un * un;
-    const uint32_t index = (blockIdx.x * 256u + threadIdx.x) * 2u;     // texels index, index + 1 of the first half ...
-    if (index >= total / 2u) return;
-    const uint32_t mindex = total - 2u - index;                        // ... and mindex, mindex + 1 = the partners of index + 1, index
-    const float4 lo = *reinterpret_cast<const float4*>(h0 + index);
-    const float4 hi = *reinterpret_cast<const float4*>(h0 + mindex);
-    const c32 om_lo = *reinterpret_cast<const c32*>(omega + index);
-    const c32 om_hi = *reinterpret_cast<const c32*>(omega + mindex);
-    const uint32_t quirks = OCEAN_QUIRK_Q1 | OCEAN_QUIRK_Q2;
-    auto texels = [&](uint32_t base, float4 own, float4 neg, c32 om) {  // the body of k_propagate for texels base, base + 1
-        const uint32_t gx = base % un, gy = base / un;
-        const float ky = OCEAN_PI_F * wave_index(gy, un, quirks) / domain_size;
-        const float kx0 = OCEAN_PI_F * wave_index(gx, un, quirks) / domain_size;
-        const float kx1 = OCEAN_PI_F * wave_index(gx + 1u, un, quirks) / domain_size;
-        const c32 h0v = propagate_height(mk(own.x, own.y), mk(neg.z, neg.w), om.x, time);
-        const c32 h1v = propagate_height(mk(own.z, own.w), mk(neg.x, neg.y), om.y, time);
-        float knx0, kny0, knx1, kny1;
-        k_normalised(kx0, ky, knx0, kny0);
-        k_normalised(kx1, ky, knx1, kny1);
-        const c32 dx0 = mul_minus_i_kn(knx0, h0v), dx1 = mul_minus_i_kn(knx1, h1v);
-        const c32 dz0 = mul_minus_i_kn(kny0, h0v), dz1 = mul_minus_i_kn(kny1, h1v);
-        *reinterpret_cast<float4*>(height + base) = make_float4(h0v.x, h0v.y, h1v.x, h1v.y);
-        *reinterpret_cast<float4*>(disp_x + base) = make_float4(dx0.x, dx0.y, dx1.x, dx1.y);
-        *reinterpret_cast<float4*>(disp_z + base) = make_float4(dz0.x, dz0.y, dz1.x, dz1.y);
-    };
-    texels(index, lo, hi, om_lo);
-    texels(mindex, hi, lo, om_hi);
-}
-
-// One thread per 2 texels of a block of `lines` lines of N texels starting at line `line0` (whole tile: 0, N).
-// The sign depends on the parity of x + y only, so the same kernel serves a block of rows (line = y) and, in the
-// sharded transform, a block of columns stored as lines (line = x, position = y).
-__global__ void __launch_bounds__(256)
-k_correct(const c32* __restrict__ height, const c32* __restrict__ disp_x, const c32* __restrict__ disp_z,
-          float4* __restrict__ out, int n, int line0, int lines) {
-    const uint32_t un = (uint32_t)n;
-    const uint32_t index = (blockIdx.x * 256u + threadIdx.x) * 2u;
-    if (index >= un * (uint32_t)lines) return;
-    const uint32_t x = index % un, y = index / un + (uint32_t)line0;
-    const float4 h = *reinterpret_cast<const float4*>(height + index);
-    const float4 dx = *reinterpret_cast<const float4*>(disp_x + index);
-    const float4 dz = *reinterpret_cast<const float4*>(disp_z + index);
-    const float s0 = (((x + y) & 1u) == 0u) ? -1.0f : 1.0f;        // correction.comp:29
-    const float s1 = -s0;
-    out[index] = make_float4(dx.x * s0, h.x * s0, dz.x * s0, 0.0f);
-    out[index + 1u] = make_float4(dx.z * s1, h.z * s1, dz.z * s1, 0.0f);
-}
-
-// SURVEY 8f #1 -- the reference's "normal field" (shader/ocean.frag:50-66) as a compute kernel at
-// texel centres: finite differences of one channel of the displacement map with Tile wrap
-// (src/render.rs:398), height_scale 180 (:19), diff = 2/N (the shader's literal 512 -> N).
-// channel 0 = disp_x is what the reference differentiates (quirk Q5); 1 = height is the
-// physically meant source.  One thread per texel; the four neighbours are L1/L2 hits.
-__global__ void __launch_bounds__(256)
-k_normals(const float4* __restrict__ rgba, float4* __restrict__ normals, int n, int channel) {
-    const uint32_t un = (uint32_t)n;
-    const uint32_t index = blockIdx.x * 256u + threadIdx.x;
-    if (index >= un * un) return;
-    const uint32_t x = index % un, y = index / un;
-    const uint32_t xm = (x + un - 1u) % un, xp = (x + 1u) % un, ym = (y + un - 1u) % un, yp = (y + 1u) % un;
-    const float* f = reinterpret_cast<const float*>(rgba) + channel;
-    const float x0 = f[((size_t)y * un + xm) * 4], x1 = f[((size_t)y * un + xp) * 4];
-    const float z0 = f[((size_t)ym * un + x) * 4], z1 = f[((size_t)yp * un + x) * 4];
-    const float d = 2.0f / (float)n;                               // :52
-    // na = normalize(-d, (x1-x0)/180, 0), nb = normalize(0, (z1-z0)/180, d)      :64-65
-    const float ay = (x1 - x0) / 180.0f, by = (z1 - z0) / 180.0f;
-    const float la = sqrtf(d * d + ay * ay), lb = sqrtf(by * by + d * d);
-    const float nax = -d / la, nay = ay / la, nby = by / lb, nbz = d / lb;
-    // cross(na, nb) with na.z = nb.x = 0                                           :66
-    const float cx = nay * nbz, cy = -nax * nbz, cz = nax * nby;
-    const float lc = sqrtf(cx * cx + cy * cy + cz * cz);
-    normals[index] = make_float4(cx / lc, cy / lc, cz / lc, 0.0f);
-}
-
-// SURVEY 8f #2 -- the vertex stage's consumer of the map (shader/ocean.vert:21-25) as a compute kernel: the
-// V x V patch grid of src/render.rs:494-508 (a_Pos = (x, 0, z), a_Uv = (x, z) / (V - 1); V = HALF_RESOLUTION
-// = 128 in the reference), the displacement sampled with the reference's sampler (Filter::Linear,
-// WrapMode::Tile, src/render.rs:398: bilinear at texel coordinates uv * N - 0.5 with wrap, weights in fp32),
-// displacement.y /= 3.0, .xz /= 3.5 (:22-23), pos = a_Pos + displacement + (offset.x, 0, offset.y) (:25).
-// One thread per vertex; positions[z * V + x] = (pos.x, pos.y, pos.z, 1).
-__global__ void __launch_bounds__(256)
-k_positions(const float4* __restrict__ rgba, float4* __restrict__ positions, int n, int verts, float offset_x,
-            float offset_z) {
-    const uint32_t index = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t uv_ = (uint32_t)verts;
-    if (index >= uv_ * uv_) return;
-    const uint32_t vx = index % uv_, vz = index / uv_;
-    const float den = (float)(verts - 1);
-    const float u = (float)vx / den, v = (float)vz / den;          // `(x as f32) / (V - 1) as f32`, src/render.rs:503-504
-    const float tx = u * (float)n - 0.5f, ty = v * (float)n - 0.5f;
-    const float fx = floorf(tx), fy = floorf(ty);
-    const float wx = tx - fx, wy = ty - fy;
-    const uint32_t mask = (uint32_t)n - 1u;                        // N is a power of two: Tile wrap
-    const uint32_t x0 = (uint32_t)(int32_t)fx & mask, x1 = (x0 + 1u) & mask;
-    const uint32_t y0 = (uint32_t)(int32_t)fy & mask, y1 = (y0 + 1u) & mask;
-    const float4 a = rgba[(size_t)y0 * n + x0], b = rgba[(size_t)y0 * n + x1];
-    const float4 c = rgba[(size_t)y1 * n + x0], d = rgba[(size_t)y1 * n + x1];
-    const float w00 = (1.0f - wx) * (1.0f - wy), w10 = wx * (1.0f - wy), w01 = (1.0f - wx) * wy, w11 = wx * wy;
-    const float dx = a.x * w00 + b.x * w10 + c.x * w01 + d.x * w11;
-    const float dy = a.y * w00 + b.y * w10 + c.y * w01 + d.y * w11;
-    const float dz = a.z * w00 + b.z * w10 + c.z * w01 + d.z * w11;
-    positions[index] = make_float4((float)vx + dx / 3.5f + offset_x, dy / 3.0f, (float)vz + dz / 3.5f + offset_z, 1.0f);
-}
-
 // LDS pitch of one line buffer: padded line + 4 elements so that P adjacent lines do not alias.
 template <int N> struct LinePitch { static constexpr int elems = LdsLine<N>::elems + 4; };
-
-// In-place line FFT on the natural layout.  LPW lines per workgroup (across threads).
-// ROW: line = row y, element pos at data[y*N + pos], threads of a line are contiguous lanes.
-// COL: line = column x, element pos at data[pos*N + x]; the LPW columns of a workgroup are
-//      adjacent and the line index is the fastest thread coordinate (8*LPW-byte pieces).
-template <int N, int E, int LPW, bool COL>
-__global__ void __launch_bounds__((N / E) * LPW)
-k_fft_lines(c32* __restrict__ data, const c32* __restrict__ tw) {
-    constexpr int T = N / E;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    c32* lds = reinterpret_cast<c32*>(smem);
-    const int tid = threadIdx.x;
-    const int ll = COL ? (tid % LPW) : ((T >= 64) ? wave_uniform(tid / T) : (tid / T));
-    const int j = COL ? (tid / LPW) : (tid % T);
-    const int group = COL ? xcd_contiguous(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-    const int line = group * LPW + ll;
-    c32* lds_line = lds + ll * LinePitch<N>::elems;
-    c32 reg[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int pos = j + e * T;
-        reg[e] = COL ? data[(size_t)pos * N + line] : data[(size_t)line * N + pos];
-    }
-    fft_line<N, E>(reg, j, tw, lds_line);
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int pos = j + e * T;
-        if (COL) data[(size_t)pos * N + line] = reg[e];
-        else data[(size_t)line * N + pos] = reg[e];
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // Fused frame
@@ -315,118 +124,6 @@ __device__ __forceinline__ size_t chunk_row_offset(const InterLayout& lay, int Y
 // merges them into full lines -- plain stores, so that the lines stay in L2 until complete).
 // (2 x 8 chunks, so that a 2-line workgroup owns whole lines, cost pass 2 more than they gave pass 1: DESIGN 4.4.)
 constexpr int CHUNK_W = 4, CHUNK_R = 4;
-
-// ---------------------------------------------------------------------------------------------
-// Staged path, chunked hand-off (N <= 4096, 4 x 4 chunks)
-// ---------------------------------------------------------------------------------------------
-// The reference's column pass reads its lines with a 4 KiB lane stride (shader/fft_col.comp:45-47) and leaves it to
-// the L2 to merge neighbouring columns; k_fft_lines<COL> does the same with 32-byte pieces and reaches a quarter
-// of the HBM roofline.  The staged calls keep the reference's dispatch structure (ocean_fft_rows, then
-// ocean_fft_cols, per field) but hand the field over in the 4 x 4-chunk layout of the fused path, so that BOTH passes
-// move whole 128-byte lines:
-//   k_stage_rows:   4 natural rows in (contiguous) -> row FFT -> chunk row Y out: one contiguous 4 N-element span;
-//   k_stage_cols:   the 4 columns of chunk column X, in place on the chunked field (whole chunks in and out);
-//   k_correct_chunked / k_unchunk: the consumers (correction.comp:24-35, ocean_read_field) read the chunked field.
-// Results in the natural layout are available after every call through ocean_read_field (include/ocean_hip.h).
-template <int N, int E>
-__global__ void __launch_bounds__((N / E) * 4)
-k_stage_rows(const c32* __restrict__ nat, c32* __restrict__ chk, const c32* __restrict__ tw, InterLayout lay) {
-    constexpr int T = N / E, THREADS = 4 * T;
-    static_assert(CHUNK_W == 4 && CHUNK_R == 4, "the chunked staged path is written for 4 x 4 chunks");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    c32* lds = reinterpret_cast<c32*>(smem);
-    const int tid = threadIdx.x;
-    const int r = (T >= 64) ? wave_uniform(tid / T) : (tid / T);
-    const int j = tid % T;
-    const int Y = blockIdx.x;
-    c32* lds_line = lds + r * LinePitch<N>::elems;
-    c32 reg[E];
-    const c32* src = nat + (size_t)(Y * 4 + r) * N + j;
-#pragma unroll
-    for (int e = 0; e < E; ++e) reg[e] = src[e * T];
-    fft_line_to_lds<N, E>(reg, j, tw, lds_line);
-    // the chunk row is 2 N pieces of 16 bytes (chunk X, piece p: row p / 2, columns 2 (p % 2) and + 1), contiguous in
-    // this order: consecutive lanes store consecutive pieces
-    float4* dst = reinterpret_cast<float4*>(chk + (size_t)Y * lay.sy);
-#pragma unroll
-    for (int q = 0; q < (2 * N) / THREADS; ++q) {
-        const int idx = tid + q * THREADS;
-        const int p = idx & 7;
-        const int x = (idx >> 3) * 4 + 2 * (p & 1);
-        const c32* l = lds + (p >> 1) * LinePitch<N>::elems;
-        const c32 v0 = l[lds_pad(x)], v1 = l[lds_pad(x + 1)];
-        store_float4_nt(dst + idx, make_float4(v0.x, v0.y, v1.x, v1.y));
-    }
-}
-
-template <int N, int E>
-__global__ void __launch_bounds__((N / E) * 4)
-k_stage_cols(c32* __restrict__ chk, const c32* __restrict__ tw, InterLayout lay) {
-    constexpr int T = N / E, THREADS = 4 * T;
-    static_assert(CHUNK_W == 4 && CHUNK_R == 4, "the chunked staged path is written for 4 x 4 chunks");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    c32* lds = reinterpret_cast<c32*>(smem);
-    const int tid = threadIdx.x;
-    const int X = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
-    c32* base = chk + (size_t)X * lay.sx;                          // chunk (X, Y) at + Y * lay.sy
-    // whole chunks in: piece idx -> chunk Y = idx / 8, piece p: row y = 4 Y + p / 2, columns 2 (p % 2) and + 1
-#pragma unroll
-    for (int q = 0; q < (2 * N) / THREADS; ++q) {
-        const int idx = tid + q * THREADS;
-        const int p = idx & 7;
-        const int y = (idx >> 3) * 4 + (p >> 1);
-        const float4 v = *reinterpret_cast<const float4*>(base + (size_t)(idx >> 3) * lay.sy + 2 * p);
-        c32* l = lds + (2 * (p & 1)) * LinePitch<N>::elems + lds_pad(y);
-        l[0] = mk(v.x, v.y);
-        l[LinePitch<N>::elems] = mk(v.z, v.w);
-    }
-    __syncthreads();
-    const int c = (T >= 64) ? wave_uniform(tid / T) : (tid / T);
-    const int j = tid % T;
-    c32* lds_line = lds + c * LinePitch<N>::elems;
-    c32 reg[E];
-    {
-        const c32* g = lds_line + lds_pad(j);
-#pragma unroll
-        for (int e = 0; e < E; ++e) reg[e] = g[e * (T + T / 16)];
-    }
-    __syncthreads();
-    fft_line_to_lds<N, E>(reg, j, tw, lds_line);
-    // whole chunks out, same addresses (every chunk of this column group was read above): thread -> (column pair h, row)
-    const int h = tid & 1;
-    const int i = tid >> 1;
-    const c32* l0 = lds + (2 * h) * LinePitch<N>::elems;
-    const c32* l1 = l0 + LinePitch<N>::elems;
-    c32* dst = base + (size_t)(i / 4) * lay.sy + (i % 4) * 4 + 2 * h;
-#pragma unroll
-    for (int q = 0; q < E / 2; ++q) {
-        const int y = i + q * (2 * T);
-        const c32 v0 = l0[lds_pad(y)], v1 = l1[lds_pad(y)];
-        store_float4_nt(reinterpret_cast<float4*>(dst + (size_t)q * ((2 * T) / 4) * lay.sy), make_float4(v0.x, v0.y, v1.x, v1.y));
-    }
-}
-
-// One workgroup per chunk row Y (4 rows of the field): wave w owns row 4 Y + w, lanes run along x, so the RGBA /
-// natural stores are whole rows; the four waves read the same 128-byte lines at the same time (one HBM fetch).
-__device__ __forceinline__ size_t chunked_index(InterLayout lay, int Y, int r, int x) {
-    return (size_t)Y * lay.sy + (size_t)(x >> 2) * lay.sx + r * 4 + (x & 3);
-}
-__global__ void __launch_bounds__(256)
-k_correct_chunked(const c32* __restrict__ height, const c32* __restrict__ disp_x, const c32* __restrict__ disp_z,
-                  float4* __restrict__ out, int n, InterLayout lay) {
-    const int Y = blockIdx.x, r = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int y = 4 * Y + r;
-    for (int x = lane; x < n; x += 64) {
-        const size_t i = chunked_index(lay, Y, r, x);
-        const float s = (((x + y) & 1) == 0) ? -1.0f : 1.0f;       // correction.comp:29
-        store_float4_nt(out + (size_t)y * n + x, make_float4(disp_x[i].x * s, height[i].x * s, disp_z[i].x * s, 0.0f));
-    }
-}
-__global__ void __launch_bounds__(256)
-k_unchunk(const c32* __restrict__ chk, c32* __restrict__ nat, int n, InterLayout lay) {
-    const int Y = blockIdx.x, r = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int x = lane; x < n; x += 64) nat[(size_t)(4 * Y + r) * n + x] = chk[chunked_index(lay, Y, r, x)];
-}
 
 // ---------------------------------------------------------------------------------------------
 // Fused frame, half-spectrum variant ("real-output" algorithm)
@@ -575,7 +272,9 @@ struct DmaRing {
     static constexpr int BASE = SLOTS / WAVES;
     // ring slots: 4 (2-3 pieces in flight while one is consumed; measured r04_run1 at N = 4096 / 8192: 3, 4, 5 slots and
     // 2 slots of double pieces within the noise of each other, so the depth is not what bounds the load phase)
-    static constexpr int D = (NP < 4) ? (NP < 2 ? 2 : NP) : 4;
+    static constexpr int DFIT = (144 * 1024) / PIECE;              // (N = 16384: 40 KiB pieces -> 3 slots)
+    static constexpr int DMAX = (DFIT < 4) ? DFIT : 4;
+    static constexpr int D = (NP < DMAX) ? (NP < 2 ? 2 : NP) : DMAX;
     static constexpr int bytes = D * PIECE;
     static_assert(E % Q == 0 && SEG_H % 1024 == 0 && SEG_W % 1024 == 0 && (P * S * TS) % 64 == 0, "DMA ring geometry");
 };
@@ -883,7 +582,7 @@ k_half_pass1_split(const void* __restrict__ h0T, float descale, const float* __r
     constexpr int TS = M / E;                                      // threads per sub-line
     constexpr int THREADS = 2 * P * TS;
     constexpr int CR = CHUNK_R, CW = CHUNK_W;
-    static_assert(P == 2 && CW % P == 0 && M % THREADS == 0, "split geometry");
+    static_assert((P == 1 || P == 2) && CW % P == 0 && M % THREADS == 0 && !(I16 && P == 1), "split geometry");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     c32* lds = reinterpret_cast<c32*>(smem);
     const int tid = threadIdx.x;
@@ -909,8 +608,8 @@ k_half_pass1_split(const void* __restrict__ h0T, float descale, const float* __r
 
     const c32* e0 = lds;                                           // column 0: even, odd; column 1: even, odd
     const c32* o0 = lds + LinePitch<M>::elems;
-    const c32* e1 = lds + 2 * LinePitch<M>::elems;
-    const c32* o1 = lds + 3 * LinePitch<M>::elems;
+    const c32* e1 = lds + (P == 2 ? 2 : 0) * LinePitch<M>::elems;  // (P == 1, N = 16384: one column per workgroup, e1 / o1 unused)
+    const c32* o1 = lds + (P == 2 ? 3 : 1) * LinePitch<M>::elems;
 #pragma unroll
     for (int f = 0; f < 3; ++f) {
         c32 reg[E];
@@ -934,6 +633,15 @@ k_half_pass1_split(const void* __restrict__ h0T, float descale, const float* __r
             const c32 w = tw[k];
             const c32 wr = crot(w);
             const int pk = lds_pad(k);
+            if constexpr (P == 1) {
+                // One column per workgroup (N = 16384: two 8192-point sub-lines fill the LDS): 8-byte elements, a quarter of
+                // a chunk row each; the four column workgroups of a chunk column run in adjacent slots of one XCD.
+                const c32 t0 = cmul_r(o0[pk], w, wr);
+                const c32 u0 = e0[pk];
+                dst[chunk_row_offset(lay, q * (THREADS / CR))] = u0 + t0;
+                dst[chunk_row_offset(lay, q * (THREADS / CR) + M / CR)] = u0 - t0;
+                continue;
+            }
             const c32 t0 = cmul_r(o0[pk], w, wr), t1 = cmul_r(o1[pk], w, wr);
             const c32 u0 = e0[pk], u1 = e1[pk];
             const c32 lo0 = u0 + t0, hi0 = u0 - t0, lo1 = u1 + t1, hi1 = u1 - t1;
@@ -1148,7 +856,7 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
 // (C[2m] and C[2m+1]), each transformed by N/(2E) threads in three passes, and the final radix-2 step is done by
 // the thread that owns outputs n and n + N/2 in the epilogue (see k_half_pass1_split).  One row per workgroup.
 template <int N, int E, int P1, int GRP = 1, bool SHARD = false, bool I16 = false>
-__global__ void __launch_bounds__(N / E, ((N / E) >= 512) ? 2 : 1)
+__global__ void __launch_bounds__(N / E, ((N / E) == 512) ? 2 : 1)
 k_half_pass2_split(const c32* __restrict__ inter, float4* __restrict__ out, const c32* __restrict__ tw, InterLayout lay,
                    const float* __restrict__ inter_scale) {
     static_assert(!(SHARD && I16), "the 16-bit intermediate is not combined with the sharded tile");
@@ -1316,61 +1024,6 @@ k_half_pass2_split(const c32* __restrict__ inter, float4* __restrict__ out, cons
 }
 
 // ---------------------------------------------------------------------------------------------
-// One N x N transform sharded by row blocks over `world` GPUs (N up to 16384)
-// ---------------------------------------------------------------------------------------------
-// Rank r owns rows [r N/world, (r+1) N/world) of the three spectra: k_propagate on its block, the row pass below,
-// ONE all-to-all, then the column pass on the N/world columns it receives (k_shard_transpose + k_fft_lines<ROW> +
-// k_correct).  The row pass stores straight into the all-to-all send buffer
-//     send[dest][field][row][column of dest]      (dest = x / cols; pieces of `cols` contiguous elements),
-// and the receive buffer recv[src][field][row of src][my column] is the column block in row-major order.
-template <int N, int E, int LPW>
-__global__ void __launch_bounds__((N / E) * LPW)
-k_shard_rows(const c32* __restrict__ block, c32* __restrict__ send, const c32* __restrict__ tw, int field, int rows,
-             int cols_log2) {
-    constexpr int T = N / E;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    c32* lds = reinterpret_cast<c32*>(smem);
-    const int tid = threadIdx.x;
-    const int ll = (T >= 64) ? wave_uniform(tid / T) : (tid / T);
-    const int j = tid % T;
-    const int line = (int)blockIdx.x * LPW + ll;                   // local row
-    c32* lds_line = lds + ll * LinePitch<N>::elems;
-    c32 reg[E];
-    const c32* src = block + (size_t)line * N + j;
-#pragma unroll
-    for (int e = 0; e < E; ++e) reg[e] = src[e * T];
-    fft_line<N, E>(reg, j, tw, lds_line);
-    const int cols = 1 << cols_log2;
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int x = j + e * T;
-        const int dest = x >> cols_log2;
-        send[(((size_t)dest * 3 + field) * rows + line) * cols + (x & (cols - 1))] = reg[e];
-    }
-}
-
-// recv[src][field][rows][cols] (field f of the column block, row-major: y = src * rows + row) -> out[column][y],
-// 32 x 32 tiles through LDS (32 * 33 * 8 bytes, dynamic), both sides in 256-byte pieces.
-// grid = (N / 32) * (cols / 32), 256 threads.
-__global__ void __launch_bounds__(256)
-k_shard_transpose(const c32* __restrict__ recv, c32* __restrict__ out, int n, int field, int rows, int cols) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    c32 (*tile)[33] = reinterpret_cast<c32 (*)[33]>(smem);
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int tiles_y = n / 32;
-    const int y0 = ((int)blockIdx.x % tiles_y) * 32, c0 = ((int)blockIdx.x / tiles_y) * 32;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int y = y0 + ty + 8 * k;
-        const int src = y / rows, ry = y - src * rows;
-        tile[ty + 8 * k][tx] = recv[(((size_t)src * 3 + field) * rows + ry) * cols + c0 + tx];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 4; ++k) out[(size_t)(c0 + ty + 8 * k) * n + y0 + tx] = tile[tx][ty + 8 * k];
-}
-
-// ---------------------------------------------------------------------------------------------
 // Launch geometry per resolution -- the single source for the API (ocean_api.hip) and for the
 // host emulation harness (tests/hipemu).
 // ---------------------------------------------------------------------------------------------
@@ -1384,11 +1037,11 @@ template <int N, int PSEL = 0> struct Geo {
     static constexpr int E1S = 16;                                 // split kernels: lines of N / 2 points
     static constexpr int T = N / E;                                // threads per line
     static constexpr int ROW_LPW = (256 / T) > 1 ? (256 / T) : 1;  // rows per workgroup (staged)
-    static constexpr int COL_LPW = (N > 4096) ? 2 : ((256 / T) > 4 ? (256 / T) : 4);  // columns per workgroup (staged)
+    static constexpr int COL_LPW = (N > 8192) ? 1 : ((N > 4096) ? 2 : ((256 / T) > 4 ? (256 / T) : 4));  // columns per workgroup (staged)
     // Lines per workgroup of fused pass 1.  4 lines = 1024 threads at N = 4096 (one workgroup per CU, whole 4 x 4 chunks);
     // 2 lines = 512 threads and 70 KiB LDS (two co-resident workgroups, each writing half of every chunk row).
     // PSEL = 0 = this default; the API picks per size (Launch<N>::default_psel).
-    static constexpr int P = PSEL ? PSEL : ((N > 4096) ? 2 : 4);
+    static constexpr int P = PSEL ? PSEL : ((N > 8192) ? 1 : ((N > 4096) ? 2 : 4));
     static constexpr int row_threads = T * ROW_LPW;
     static constexpr int col_threads = T * COL_LPW;
     // LDS-DMA loader of fused pass 1 (half_load_AB_dma): the inputs streamed through the idle line buffers, no register
@@ -1445,7 +1098,7 @@ template <int N, int PSEL = 0> struct Geo {
     static constexpr int stage_grid = N / 4;
     // split geometry (lines as two interleaved N/2 transforms; k_half_pass1_split / k_half_pass2_split): N = 8192 in the
     // product, any N >= 512 in the emulation
-    static constexpr bool can_split = (P == 2) && (N >= 512);
+    static constexpr bool can_split = (P <= 2) && (N >= 512);
     static constexpr int split_lds1 = max_i(2 * P * LinePitch<N / 2>::elems * (int)sizeof(c32), DmaRingBytes<can_split, N, E1S, P, 2>::value);
     static constexpr int split_lds2 = 2 * LinePitch<N / 2>::elems * (int)sizeof(c32);
     static constexpr int split_threads2 = T;

@@ -5,8 +5,8 @@
 //   k_fft_lines<ROW>, k_stage_rows    <- shader/fft_row.comp:44-63
 //   k_fft_lines<COL>, k_stage_cols    <- shader/fft_col.comp:44-63
 //   k_correct / k_correct_chunked     <- shader/correction.comp:24-35
-// the compatibility path (172 B/texel as the reference; what a consumer calls per frame is the fused frame of
-// ocean_kernels.hpp), plus
+// -- the compatibility path (172 B/texel as the reference; what a consumer calls per frame is the fused frame of
+// ocean_kernels.hpp) -- plus
 //   k_normals, k_positions            <- shader/ocean.frag:50-66, shader/ocean.vert:21-25
 //   k_shard_rows, k_shard_transpose   one tile sharded by row blocks over several GPUs (SURVEY 8f #4, N <= 16384).
 // No launches in this header: it is also compiled by the host emulation harness (tests/hipemu).
@@ -14,95 +14,6 @@
 #include "ocean_kernels.hpp"
 
 namespace ocean {
-
-//
-// Staged kernels (1:1 with the reference dispatches; the compatibility path, include/ocean_hip.h):
-//   k_propagate / k_propagate_paired  <- shader/propagate.comp:42-72
-//   k_fft_lines<ROW>, k_stage_rows    <- shader/fft_row.comp:44-63
-//   k_fft_lines<COL>, k_stage_cols    <- shader/fft_col.comp:44-63
-//   k_correct / k_correct_chunked     <- shader/correction.comp:24-35
-//   k_normals, k_positions            <- shader/ocean.frag:50-66, shader/ocean.vert:21-25
-// Fused frame (ocean_frame: 2 launches, the half-spectrum "real-output" algorithm, 52-54 B/texel of HBM traffic instead of
-// the reference's 172):
-//   k_half_pass1 / k_half_pass1_split (N = 8192): propagate + symmetrise + FFT along y of the half spectrum's columns,
-//                  reading the *transposed* static inputs (h0T, omegaT; made once at upload) so that every line is
-//                  contiguous -- at N >= 2048 streamed through LDS by LDS-DMA (half_load_AB_dma); writes the intermediate
-//                  as 4 x 4 chunks (128 bytes);
-//   k_half_pass2 / k_half_pass2_split: rebuild full rows from the half spectrum, two complex FFTs along x for the three
-//                  real channels, sign correction, RGBA rows.
-// The column transform runs first in the fused path (a separable 2-D DFT commutes), so that the pass that owns whole
-// rows is the one that writes the row-major RGBA image.
-// One tile over several GPUs: the same fused kernels on column / row blocks (x_group0, SHARD) and k_shard_* (row blocks).
-//
-// Every kernel in this file ships; measured dead ends live in git history and DESIGN.md 4.3-4.6, not here.
-// No launches in this header: it is also compiled by the host emulation harness (tests/hipemu) that checks the index
-// algebra on the CPU.
-#pragma once
-#include "fft_core.hpp"
-
-namespace ocean {
-
-// Fused kernels at N <= this take the base twiddle of every pass from v_sin/v_cos instead of the table (fft_core.hpp
-// base_twiddle; the reference evaluates cos/sin per butterfly, shader/fft_row.comp:32-33): the latency-bound sizes.
-constexpr int HWTW_MAX_N = 1024;
-
-// shader/propagate.comp:6 -- `const float pi = 3.1415926;` (fp32 0x40490FDA)
-#define OCEAN_PI_F 3.1415926f
-
-// Observed dispatch rule: block b runs on XCD b % 8.  Give each XCD a contiguous range of
-// logical work items so neighbours share an L2 (speed only; any mapping is correct).
-__device__ __forceinline__ int xcd_contiguous(int b, int nblocks) {
-    if ((nblocks & 7) != 0) return b;
-    return (b & 7) * (nblocks >> 3) + (b >> 3);
-}
-
-// Q1: float(uint(2*g - N - 1))  (shader/propagate.comp:45-46, wraps in uint32)
-__device__ __forceinline__ float wave_index_q1(uint32_t g, uint32_t n) {
-    return (float)(uint32_t)(2u * g - n - 1u);
-}
-// Quirk switches of the staged path (include/ocean_hip.h OCEAN_QUIRK_*).  Both set = the reference.
-//   Q1 off: the wave index 2g - N - 1 is evaluated signed (what the shader's author meant).
-//   Q2 off: the "-k" partner of texel g is (N + 1 - g) % N on both axes (k is antisymmetric about (N+1)/2;
-//           the two texels without a partner, g = 0 and 1, pair with each other) and enters conjugated.
-#define OCEAN_QUIRK_Q1 1u
-#define OCEAN_QUIRK_Q2 2u
-__device__ __forceinline__ float wave_index(uint32_t g, uint32_t n, uint32_t quirks) {
-    return (quirks & OCEAN_QUIRK_Q1) ? wave_index_q1(g, n) : (float)((int32_t)(2u * g) - (int32_t)n - 1);
-}
-
-// The per-texel math of propagate.comp:55-71, shared by the staged and the fused kernel.
-// h = h0 * e^{+i w t} + h0[index_neg] * e^{-i w t}   (:55-62; no conjugate, quirk Q2)
-__device__ __forceinline__ c32 propagate_height(c32 h0, c32 h0_neg, float omega, float time) {
-    const float disp = omega * time;                               // :55 (one fp32 multiply, as the shader)
-    // cos/sin of the fp32 phase, full range (phases reach 1e4..1e5 rad): reduce to revolutions in
-    // [-0.5, 0.5] with a two-constant fp32 product (1/(2 pi) = HI + LO, both FMAs exact in the
-    // product: fraction error < 6e-8 revolutions for |disp| < 1e5), then the hardware sin/cos.
-    // Total abs error <= 4e-7 against the correctly rounded value the oracle uses.
-    constexpr float INV_2PI_HI = 0.15915494f;                      // fl32(1 / (2 pi)) = 0x3E22F983
-    constexpr float INV_2PI_LO = 6.4206382e-09f;                   // 1 / (2 pi) - INV_2PI_HI
-    const float turns = rintf(disp * INV_2PI_HI);
-    const float frac = fmaf(disp, INV_2PI_LO, fmaf(disp, INV_2PI_HI, -turns));
-    const float s = sin_rev(frac), c = cos_rev(frac);
-    // h0 (c + i s) + h0_neg (c - i s) = c (h0 + h0_neg) + s * i (h0 - h0_neg): five packed instructions
-    const c32 p = h0 + h0_neg, q = h0 - h0_neg;
-    return vfma(yx(q) * s, mk(-1.0f, 1.0f), p * c);
-}
-// k_norm = k / length(k) if length(k) > 1e-10 else 0   (:64-67)
-__device__ __forceinline__ void k_normalised(float kx, float ky, float& knx, float& kny) {
-    const float len = sqrtf(kx * kx + ky * ky);
-    knx = 0.0f; kny = 0.0f;
-    if (len > 1.0e-10f) { knx = kx / len; kny = ky / len; }
-}
-// Same value to <= 2 ulp with one v_rsq_f32 instead of a square root and two IEEE divisions
-// (used by the fused kernel, where pass 1 is VALU-limited): kn = k * rsqrt(|k|^2).
-__device__ __forceinline__ void k_normalised_fast(float kx, float ky, float& knx, float& kny) {
-    const float l2 = kx * kx + ky * ky;
-    const float r = (l2 > 1.0e-20f) ? rsqrtf(l2) : 0.0f;          // length(k) > 1e-10
-    knx = kx * r;
-    kny = ky * r;
-}
-// complex_mul(vec2(0, -kn), h) = (kn*h.y, -kn*h.x)   (:70-71)
-__device__ __forceinline__ c32 mul_minus_i_kn(float kn, c32 h) { return yx(h) * mk(kn, -kn); }
 
 // ---------------------------------------------------------------------------------------------
 // Staged kernels
@@ -256,6 +167,37 @@ k_positions(const float4* __restrict__ rgba, float4* __restrict__ positions, int
     const float dy = a.y * w00 + b.y * w10 + c.y * w01 + d.y * w11;
     const float dz = a.z * w00 + b.z * w10 + c.z * w01 + d.z * w11;
     positions[index] = make_float4((float)vx + dx / 3.5f + offset_x, dy / 3.0f, (float)vz + dz / 3.5f + offset_z, 1.0f);
+}
+
+// In-place line FFT on the natural layout.  LPW lines per workgroup (across threads).
+// ROW: line = row y, element pos at data[y*N + pos], threads of a line are contiguous lanes.
+// COL: line = column x, element pos at data[pos*N + x]; the LPW columns of a workgroup are
+//      adjacent and the line index is the fastest thread coordinate (8*LPW-byte pieces).
+template <int N, int E, int LPW, bool COL>
+__global__ void __launch_bounds__((N / E) * LPW)
+k_fft_lines(c32* __restrict__ data, const c32* __restrict__ tw) {
+    constexpr int T = N / E;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    c32* lds = reinterpret_cast<c32*>(smem);
+    const int tid = threadIdx.x;
+    const int ll = COL ? (tid % LPW) : ((T >= 64) ? wave_uniform(tid / T) : (tid / T));
+    const int j = COL ? (tid / LPW) : (tid % T);
+    const int group = COL ? xcd_contiguous(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int line = group * LPW + ll;
+    c32* lds_line = lds + ll * LinePitch<N>::elems;
+    c32 reg[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int pos = j + e * T;
+        reg[e] = COL ? data[(size_t)pos * N + line] : data[(size_t)line * N + pos];
+    }
+    fft_line<N, E>(reg, j, tw, lds_line);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int pos = j + e * T;
+        if (COL) data[(size_t)pos * N + line] = reg[e];
+        else data[(size_t)line * N + pos] = reg[e];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -13,6 +13,7 @@ _SO = os.path.join(_ROOT, "tests", "hipemu", f"libocean_emu{_TAG}.so")
 _SRC = [os.path.join(_ROOT, "tests", "hipemu", "emu_kernels.cpp"),
         os.path.join(_ROOT, "tests", "hipemu", "hip", "hip_runtime.h"),
         os.path.join(_ROOT, "gfx_ocean_amd", "csrc", "ocean_kernels.hpp"),
+        os.path.join(_ROOT, "gfx_ocean_amd", "csrc", "ocean_staged_kernels.hpp"),
         os.path.join(_ROOT, "gfx_ocean_amd", "csrc", "fft_core.hpp"),
         os.path.join(_ROOT, "tests", "hipemu", "ocean_device_intrinsics.hpp")]
 _LIB = None
@@ -148,10 +149,10 @@ def quantize_f16(h0):
 
 def frame_half(h0, omega, time, L=1000.0, layout="p2", return_inter=False, spectrum_fp16=False, P=None, split=False, bshift=None,
                inter16=False):
-    """split=True: every line as two interleaved N/2 transforms (the N = 8192 geometry, P = 2); inter16=True (split only):
-    the 16-bit block-floating intermediate (OCEAN_INTER_BFP16)."""
+    """split=True: every line as two interleaved N/2 transforms (the N = 8192 geometry, P = 2; with P=1 the N = 16384 geometry:
+    one column per pass-1 workgroup); inter16=True (split, P = 2 only): the 16-bit block-floating intermediate (OCEAN_INTER_BFP16)."""
     n = h0.shape[0]
-    P = 2 if split else (P or lib().emu_frame_p(n))
+    P = (1 if P == 1 else 2) if split else (P or lib().emu_frame_p(n))
     descale = 1.0
     if spectrum_fp16:
         packed, _, s = quantize_f16(h0)
@@ -167,7 +168,7 @@ def frame_half(h0, omega, time, L=1000.0, layout="p2", return_inter=False, spect
     tw = twiddles(n)
     assert split or not inter16
     scales = np.full(3 * (n // 64) * (n // 4), np.nan, np.float32) if inter16 else None
-    assert lib().emu_frame_half(n, (23 if inter16 else 22) if split else int(P), _p(h0T), int(spectrum_fp16), descale, _p(omT), _p(inter),
+    assert lib().emu_frame_half(n, (23 if inter16 else (21 if P == 1 else 22)) if split else int(P), _p(h0T), int(spectrum_fp16), descale, _p(omT), _p(inter),
                                 _p(nyq), _p(out), _p(tw), sx, sy, fs, bshift, time, L, _p(scales) if inter16 else None) == 0
     if return_inter:
         return out, inter, nyq, (P, (sx, sy, fs, bshift))

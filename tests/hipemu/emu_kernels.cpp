@@ -19,6 +19,7 @@ void __syncthreads() { g_barrier->arrive_and_wait(); }
 namespace ocean { alignas(16) unsigned char smem[160 * 1024]; float g_emu_wave_scratch[16][64]; }
 
 #include "ocean_kernels.hpp"
+#include "ocean_staged_kernels.hpp"
 
 template <class F>
 static void emu_launch(int grid, int threads, F&& body) {
@@ -61,9 +62,9 @@ template <int N, int PSEL> static int run_half_p(const void* h0T, int f16, float
                [&] { k_half_pass2<N, G::E2, CHUNK_W, G::R2h, G::p2_group, G::ppar>(inter, out, tw, lay); });
     return 0;
 }
-template <int N, bool I16> static int run_half_split(const void* h0T, int f16, float descale, const float* omT, c32* inter, c32* nyq,
+template <int N, bool I16, int PS = 2> static int run_half_split(const void* h0T, int f16, float descale, const float* omT, c32* inter, c32* nyq,
                                                      float4* out, const c32* tw, InterLayout lay, float time, float L, float* scales) {
-    using G = Geo<N, 2>;
+    using G = Geo<N, PS>;
     static_assert(G::can_split, "split geometry");
     if (f16) emu_launch(G::half_grid1, G::split_threads1,
                         [&] { k_half_pass1_split<N, G::E1S, G::P, true, I16>(h0T, descale, omT, inter, nyq, tw, lay, time, L, 0, scales); });
@@ -74,6 +75,10 @@ template <int N, bool I16> static int run_half_split(const void* h0T, int f16, f
 }
 template <int N> static int run_half(int psel, const void* h0T, int f16, float descale, const float* omT, c32* inter, c32* nyq,
                                      float4* out, const c32* tw, InterLayout lay, float time, float L, float* scales) {
+    if (psel == 21) {                                   // P = 1 with the split geometry (the N = 16384 kernels: one column per workgroup)
+        if constexpr (N >= 1024) return run_half_split<N, false, 1>(h0T, f16, descale, omT, inter, nyq, out, tw, lay, time, L, nullptr);   // (whole waves)
+        else return -3;
+    }
     if (psel == 22 || psel == 23) {                     // P = 2 with the split geometry; 23: + the 16-bit intermediate
         if constexpr (N >= 512) {
             if (psel == 23) return scales ? run_half_split<N, true>(h0T, f16, descale, omT, inter, nyq, out, tw, lay, time, L, scales) : -6;
@@ -177,7 +182,7 @@ int emu_inter_bshift(int n) {
 }
 // 1 when fused pass 1 of this size takes its inputs through the LDS-DMA ring (psel as emu_frame_half: 22 / 23 = split kernels, always)
 int emu_uses_dma(int n, int psel) {
-    if (psel == 22 || psel == 23) return 1;
+    if (psel == 21 || psel == 22 || psel == 23) return 1;
 #define C_(N) ((psel == 2) ? (int)Geo<N, 2>::dma : (psel == 1) ? (int)Geo<N, 1>::dma : (int)Geo<N, 0>::dma)
     DISPATCH(n, C_)
 #undef C_

@@ -112,6 +112,26 @@ def test_emu_split_line_geometry(n, ref_inputs):
         assert_parity(a, b, 5e-6, f"split intermediate field {f}")
 
 
+@pytest.mark.parametrize("n", [1024, 2048])
+def test_emu_split_one_column_per_workgroup(n):
+    """The N = 16384 geometry of the split kernels (two N/2-point sub-lines fill the LDS: ONE column per pass-1 workgroup,
+    8-byte chunk pieces, the ring with the left neighbour's lines as half of what it stages) at sizes the emulation can
+    run: same frame as the oracle, same intermediate as two columns per workgroup; fp16-stored spectrum too."""
+    import gfx_ocean_amd as g                                       # (a workgroup is whole waves from N = 1024 on: 2 x 32 threads)
+    h0, om = g.synth.make_inputs(n, seed=5)
+    out, inter, _, (P, lay) = emu.frame_half(h0, om, 2.5, return_inter=True, split=True, P=1)
+    assert P == 1
+    assert_parity(out[..., :3], oc.frame_f64(h0, om, 2.5)[..., :3], 5e-6, f"split frame, one column per workgroup, n={n}")
+    assert np.all(out[..., 3] == 0.0)
+    two, inter2, _, (_, lay2) = emu.frame_half(h0, om, 2.5, return_inter=True, split=True)
+    assert lay == lay2 and np.array_equal(out, two)
+    assert np.array_equal(inter[~np.isnan(inter.real)], inter2[~np.isnan(inter2.real)])
+    if n == 1024:
+        _, deq, _ = emu.quantize_f16(h0)
+        o16 = emu.frame_half(h0, om, 1.0, spectrum_fp16=True, split=True, P=1)
+        assert_parity(o16[..., :3], oc.frame_f64(deq, om, 1.0)[..., :3], 5e-6, "fp16 spectrum, one column per workgroup")
+
+
 def test_emu_split_fp16_spectrum(ref_inputs):
     h0, om = ref_inputs
     _, deq, _ = emu.quantize_f16(h0)
