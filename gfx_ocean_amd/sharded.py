@@ -3,7 +3,7 @@ Independent tiles need no exchange (bench.py); this module is for a s
 for one GPU.  Two schemes, both with ONE all-to-all where the reference has its barrier between the row and the column
 dispatches (src/render.rs:1181-1208):
 
-`FusedShardedTile` (N <= 8192, the one to use) -- the fused half-spectrum frame of `ocean_frame`, sharded:
+`FusedShardedTile` (N <= 16384, the one to use) -- the fused half-spectrum frame of `ocean_frame`, sharded:
 
     rank r owns half-spectrum columns [r N/2R, ..)   fused pass 1 on them                  (ocean_tile_pass1)
     all_to_all_single(recv, send)                     3 (N/2) (N/R) 8 bytes per rank: 12 B/texel in total; optionally cut
@@ -13,7 +13,7 @@ dispatches (src/render.rs:1181-1208):
   Result: the rank's ROW block in the natural orientation, ``out[y - r N/R, x] = (disp_x, height, disp_z, 0)``; 54 B/texel
   of HBM traffic, bit-identical to `ocean_frame`.
 
-`ShardedTile` (N <= 16384; the only scheme for 16384) -- the reference's own dispatch order (src/render.rs:1122-1310):
+`ShardedTile` (N <= 16384; the first generation, kept as the 1:1 restatement) -- the reference's own dispatch order (src/render.rs:1122-1310):
 
     rank r owns rows [r N/R, (r+1) N/R)           propagate + row pass on them        (ocean_shard_rows)
     all_to_all_single(recv, send)                 3 N^2 8 / R bytes per rank and frame, (R-1)/R of it over xGMI

@@ -43,7 +43,7 @@ extern "C" {
 /* ---- status codes ------------------------------------------------------------------------- */
 #define OCEAN_OK 0
 #define OCEAN_E_INVALID_ARG (-1)
-#define OCEAN_E_UNSUPPORTED_N (-2) /* resolution must be a power of two in [256, 8192] */
+#define OCEAN_E_UNSUPPORTED_N (-2) /* resolution must be a power of two in [256, 16384] */
 #define OCEAN_E_HIP (-3)
 #define OCEAN_E_OOM (-4)
 #define OCEAN_E_STATE (-5) /* e.g. frame requested before ocean_upload_spectrum */
@@ -247,8 +247,9 @@ void* ocean_shard_stream(OceanShard* shard);
  *                        writes them in the NATURAL orientation: out_rows[(y - r N/world) * N + x] = (disp_x, height, disp_z, 0).
  * Both run on an ordinary context that holds the whole tile's static inputs (ocean_upload_spectrum on every rank: the
  * inputs are static and 12 bytes per texel): no state per rank, so all ranks of a tile can be driven from one context
- * on one GPU (tests) or one context per GPU (gfx_ocean_amd/sharded.py).  N = 256 .. 8192, world a power of two with at
- * least 32 rows per rank.  Same barrier as the reference's between its row and column dispatches (src/render.rs:1181-1208). */
+ * on one GPU (tests) or one context per GPU (gfx_ocean_amd/sharded.py).  N = 256 .. 16384 (16384: every line as two
+ * interleaved 8192-point transforms, one column per pass-1 workgroup; also what ocean_frame runs there), world a power of
+ * two with at least 32 rows per rank.  Same barrier as the reference's between its row and column dispatches (src/render.rs:1181-1208). */
 int64_t ocean_tile_exchange_bytes(const OceanContext* ctx, int32_t world);   /* bytes of a rank's send (= receive) buffer; < 0: error */
 /* `parts` (a power of two, 1 = no pipelining) cuts the rank's column block -- and the exchange -- into that many pieces:
  * pass 1 of piece `part` fills send_part_device (ocean_tile_exchange_bytes / parts bytes, [dest][...]), the caller ships

@@ -344,6 +344,45 @@ def test_gpu_fused_shard_multi_rank_on_one_device(n, world, f16):
 
 
 @pytest.mark.gpu
+def test_gpu_fused_shard_16384_every_rank_against_the_c_oracle():
+    """SURVEY 8f #4 / VERDICT r03 #4: N = 16384 -- the size that motivates sharding one transform -- on the FUSED
+    half-spectrum path (rounds 2-3 ran it on the staged row-block kernels at 220 B/texel): a 16384-point line as two
+    interleaved 8192-point transforms with the last radix-2 step at read-out, one column per pass-1 workgroup (two
+    sub-lines fill the LDS).  EVERY texel of the tile assembled from every rank of world 1, 2, 4 and 8 (all run on this
+    one device, the exchange by device copies) against the C restatement of the shaders, computed once (~1 min of host
+    time); the unsharded ocean_frame must be the same bits, and its time is printed (target <= 4 ms; 11.8 ms on the staged
+    row-block path, profiles/r03_run14_shard_bench_world1.jsonl)."""
+    from oracle import c_oracle as cc
+    n, t = 16384, 1.5
+    h0, om = g.synth.make_inputs(n, seed=16384)
+    cc.build()
+    cc.set_threads(min(32, cc.max_threads()))
+    want = cc.FrameRunner(h0, om).frame(t)[..., :3].copy()
+    first = None
+    for world in (1, 2, 4, 8):
+        got, _ = _fused_loopback_frame(n, world, t, h0, om)
+        nmax, rl2 = oc.parity_errors(got[..., :3], want)
+        print(f"N = 16384 fused sharded tile, world {world}: normalised max {nmax.max():.2e}, rel-L2 {rl2.max():.2e}")
+        assert nmax.max() <= 1e-4 and rl2.max() <= 1e-4, (world, nmax, rl2)      # north_star tolerance
+        assert nmax.max() < 2e-5 and np.all(got[..., 3] == 0.0)
+        if first is None:
+            first = got
+        else:
+            assert np.array_equal(got, first), world                          # sharding does not change a bit
+        del got
+    d = g.OceanDevice(n)
+    try:
+        d.upload_spectrum(h0, om)
+        d.frame(t)
+        assert np.array_equal(d.read_displacement(), first)
+        d.time_frames(10)
+        ms = d.time_frames(20) / 20
+        print(f"N = 16384 ocean_frame on one GPU: {ms:.3f} ms per frame ({54 * n * n / ms / 1e6:.0f} GB/s on 54 B/texel)")
+    finally:
+        d.destroy()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,world,parts", [(2048, 4, 1), (2048, 2, 4), (4096, 8, 2), (512, 2, 2)])
 def test_gpu_fused_shard_equals_the_fused_frame_bit_for_bit(n, world, parts):
     """Sharding -- and cutting the exchange into pipelined parts -- must not change a single bit: the same kernels on
