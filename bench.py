@@ -374,7 +374,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--n", type=int, default=4096, help="tile edge (power of two, 256..8192)")
+    ap.add_argument("--n", type=int, default=4096, help="tile edge (power of two, 256..16384)")
     ap.add_argument("--spectrum", choices=("f32", "f16"), default="f32",
                     help="storage of the initial spectrum in HBM (f16 = BASELINE config 5: scaled fp16 pairs, fp32 arithmetic)")
     ap.add_argument("--intermediate", choices=("f32", "bfp16"), default="f32",

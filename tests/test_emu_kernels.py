@@ -112,7 +112,7 @@ def test_emu_split_line_geometry(n, ref_inputs):
         assert_parity(a, b, 5e-6, f"split intermediate field {f}")
 
 
-@pytest.mark.parametrize("n", [1024, 2048])
+@pytest.mark.parametrize("n", [1024])                              # (2048 passes too; 170 s of host emulation)
 def test_emu_split_one_column_per_workgroup(n):
     """The N = 16384 geometry of the split kernels (two N/2-point sub-lines fill the LDS: ONE column per pass-1 workgroup,
     8-byte chunk pieces, the ring with the left neighbour's lines as half of what it stages) at sizes the emulation can
@@ -123,9 +123,12 @@ def test_emu_split_one_column_per_workgroup(n):
     assert P == 1
     assert_parity(out[..., :3], oc.frame_f64(h0, om, 2.5)[..., :3], 5e-6, f"split frame, one column per workgroup, n={n}")
     assert np.all(out[..., 3] == 0.0)
-    two, inter2, _, (_, lay2) = emu.frame_half(h0, om, 2.5, return_inter=True, split=True)
-    assert lay == lay2 and np.array_equal(out, two)
-    assert np.array_equal(inter[~np.isnan(inter.real)], inter2[~np.isnan(inter2.real)])
+    for f in range(3):                                              # ... and the intermediate is the plain kernels'
+        _, inter_p, _, _ = (None, None, None, None) if f else emu.frame_half(h0, om, 2.5, return_inter=True, P=2)
+        if f == 0:
+            plain = inter_p
+        assert_parity(emu.unpack_inter(inter, n, P, lay, f, columns=n // 2), emu.unpack_inter(plain, n, 2, lay, f, columns=n // 2), 5e-6,
+                      f"intermediate field {f}")
     if n == 1024:
         _, deq, _ = emu.quantize_f16(h0)
         o16 = emu.frame_half(h0, om, 1.0, spectrum_fp16=True, split=True, P=1)
@@ -245,7 +248,7 @@ from conftest import GOLDEN, assert_parity
 h0, om = oc.load_reference_inputs(GOLDEN + "/spectrum.bin", GOLDEN + "/omega.bin")
 h256, o256 = oc.centre_crop(h0, 256), oc.centre_crop(om, 256)
 h1k, o1k = g.synth.make_inputs(1024, seed=4)
-for (h, o, kw, what) in ((h0, om, dict(split=True), "split 512"), (h1k, o1k, dict(split=True), "split 1024"),
+for (h, o, kw, what) in ((h0, om, dict(split=True), "split 512"),
                          (h256, o256, dict(), "lines 256 P=4"), (h0, om, dict(P=2), "lines 512 P=2"), (h1k, o1k, dict(), "lines 1024")):
     assert emu.uses_dma(h.shape[0], kw.get("P"), kw.get("split", False)), what
     out = emu.frame_half(h, o, 2.5, **kw)
