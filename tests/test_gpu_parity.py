@@ -529,6 +529,36 @@ def test_packed_displacement_for_the_gather(n, ref_inputs):
         d.destroy()
 
 
+def test_frame_time_distributions():
+    """SURVEY 8d's "median + p10/p90" (VERDICT r03 #2): ocean_time_frame_batches (plain loop, one stream event per batch) and
+    ocean_frame_times (per-dispatch events) agree with ocean_time_frames on what a frame costs, and reject bad arguments."""
+    n = 2048
+    d = g.OceanDevice(n)
+    try:
+        h0, om = g.synth.make_inputs(n, seed=2)
+        with pytest.raises(g.OceanError):
+            d.time_frame_batches(4, 5)                               # before upload: OCEAN_E_STATE
+        d.upload_spectrum(h0, om)
+        d.time_frames(200)                                            # clock ramp
+        total = d.time_frames(200) / 200
+        batches = d.time_frame_batches(20, 10)
+        assert len(batches) == 20 and all(b > 0 for b in batches)
+        per_frame = sorted(b / 10 for b in batches)
+        assert 0.8 * total < per_frame[10] < 1.25 * total, (total, per_frame)
+        p1, p2, period = d.frame_times(100)
+        assert len(p1) == len(p2) == len(period) == 100 and min(p1) > 0 and min(p2) > 0
+        med = lambda v: sorted(v)[len(v) // 2]
+        assert med(p1) + med(p2) < 1.3 * total and med(period) >= 0.95 * (med(p1) + med(p2))
+        with pytest.raises(g.OceanError):
+            d.frame_times(0)
+        with pytest.raises(g.OceanError):
+            d.time_frame_batches(0, 10)
+        d.frame(1.0)                                                  # the measurement loops leave the context usable
+        assert np.isfinite(d.read_displacement()).all()
+    finally:
+        d.destroy()
+
+
 def test_stale_stage_handle_of_a_reused_context_address_is_rejected():
     """a stage handle kept after its context is destroyed must not become valid again when a new context
     happens to be allocated at the same address (handles carry the generation of their context)."""
