@@ -1031,9 +1031,12 @@ template <int N, int PSEL = 0> struct Geo {
     static constexpr int E = 16;                                   // elements per thread
     // Elements per thread of fused pass 1.  At N <= 1024 a frame is launch- and latency-bound (a 512-point line with 16
     // elements per thread is half a wave): 8 elements per thread double the waves that share a workgroup's serial chain
-    // of loads and transforms (run r02_run12: N = 512 51.0k -> 67.1k frames/s, 256 63k -> 77k, 1024 38.9k -> 41.3k;
-    // 2048 unchanged; 32 and 64 elements at large N: slower).
-    static constexpr int E1 = (N <= 1024) ? 8 : 16;
+    // of loads and transforms (run r02_run12: N = 512 51.0k -> 67.1k frames/s, 256 63k -> 77k, 1024 38.9k -> 41.3k).
+    // N = 2048 is ONE dispatch round of 512 co-resident workgroups, as long as its slowest one: with the LDS-DMA loader
+    // (no staging registers: 8 waves per workgroup fit) 8 elements per thread take pass 1 from 29.7-31.0 to 28.5-28.9 us,
+    // 19.6-20.4k -> 20.7-20.8k frames/s (r04_run9-11; round 3 with the register loader: +3 %).  4096 and up: 16 (a line
+    // of 512 threads leaves two lines per workgroup; 32 and 64 elements: slower, EXPERIMENTS 4.4).
+    static constexpr int E1 = (N <= 2048) ? 8 : 16;
     static constexpr int E1S = 16;                                 // split kernels: lines of N / 2 points
     static constexpr int T = N / E;                                // threads per line
     static constexpr int ROW_LPW = (256 / T) > 1 ? (256 / T) : 1;  // rows per workgroup (staged)
