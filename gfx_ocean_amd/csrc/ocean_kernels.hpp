@@ -172,6 +172,42 @@ __device__ __forceinline__ void half_spectrum(int f, const c32 (&A)[E], const c3
     for (int e = 0; e < E; ++e) reg[e] = half_spectrum_at<N>(f, A[e], B[e], kxv, kscale, S * (j + e * T) + par);
 }
 
+// The same three spectra with the wave-vector normalisation applied ONCE (round 4; the kernels that transform the three fields
+// one after the other): height first (2 S(H) = A + B from the unscaled values), then A <- A / |k1|, B <- B / |k2| in place
+// (half_scale_AB: the one place the two quarter-rate v_rsq_f32 per element are paid), after which
+//     2 S(Dx) = i (k2.x B' - k1.x A'),   2 S(Dz) = i (k2.y B' - k1.y A')
+// are three packed instructions per element (k.x is the column's, wave-uniform; k.y a conversion and a multiply).  The
+// transform phases of pass 1 are VALU-issue-bound and the two normalisations were 2 x 2.3 of their 22 us per round at
+// N = 4096: frame 0.186 -> 0.181-0.182 ms, 5366-5374 -> 5488-5538 frames/s (r04_run18, A/B on one box); and the kernel drops
+// from 128 VGPRs with 6 spilled to 124 with none.  (A / |k| * k.x instead of A * (k.x / |k|): one rounding moved, 1 ulp.)
+template <int N>
+__device__ __forceinline__ c32 wave_vector_y(int y, float kscale) {
+    const int y2 = (N - y) & (N - 1);
+    return mk(wave_index_q1((uint32_t)y, N), wave_index_q1((uint32_t)y2, N)) * kscale;
+}
+template <int N, int E, int S = 1>
+__device__ __forceinline__ void half_scale_AB(c32 (&A)[E], c32 (&B)[E], c32 kxv, float kscale, int j, int par = 0) {
+    constexpr int T = N / (E * S);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const c32 kyv = wave_vector_y<N>(S * (j + e * T) + par, kscale);
+        const c32 l2 = vfma(kxv, kxv, kyv * kyv);
+        const c32 r = mk((l2.x > 1.0e-20f) ? rsqrtf(l2.x) : 0.0f, (l2.y > 1.0e-20f) ? rsqrtf(l2.y) : 0.0f);
+        A[e] = A[e] * xx(r);
+        B[e] = B[e] * yy(r);
+    }
+}
+template <int N, int E, int S = 1>
+__device__ __forceinline__ void half_spectrum_scaled(int f, const c32 (&A)[E], const c32 (&B)[E], c32 kxv, float kscale, int j,
+                                                     c32 (&reg)[E], int par = 0) {
+    constexpr int T = N / (E * S);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const c32 kv = (f == 0) ? kxv : wave_vector_y<N>(S * (j + e * T) + par, kscale);
+        reg[e] = crot(vfma(A[e], -xx(kv), B[e] * yy(kv)));          // i (k2 B' - k1 A')
+    }
+}
+
 // The initial spectrum in HBM: fp32 complex (8 B/texel), or -- BASELINE config 5 -- two fp16 with
 // a power-of-two scale (4 B/texel); arithmetic is fp32 either way.
 template <bool H16> struct Spec;
@@ -508,10 +544,19 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
     const c32* l1 = lds_grp + (2 * h + 1) * LinePitch<N>::elems;
 #pragma unroll
     for (int ff = 0; ff < (FPAR ? 1 : 3); ++ff) {
-        const int f = FPAR ? fg : ff;
+        // One field group per field (FPAR), or the three fields one after the other: height first, then A and B are
+        // normalised in place and disp_x, disp_z cost three packed instructions per element (half_scale_AB).
+        constexpr bool SHARED_R = !FPAR;
+        const int f = FPAR ? fg : ((ff == 0) ? 1 : ((ff == 1) ? 0 : 2));
         c32 reg[E];
         const int jf = FPAR ? j : opaque_lane(j);                  // (one field per thread: nothing to keep apart, and the twiddle loads may move up)
-        half_spectrum<N, E>(f, A, B, kxv, kscale, jf, reg);
+        if constexpr (SHARED_R) {
+            if (ff == 0) half_spectrum<N, E>(1, A, B, kxv, kscale, jf, reg);
+            else {
+                if (ff == 1) half_scale_AB<N, E>(A, B, kxv, kscale, jf);
+                half_spectrum_scaled<N, E>(f, A, B, kxv, kscale, jf, reg);
+            }
+        } else half_spectrum<N, E>(f, A, B, kxv, kscale, jf, reg);
         if (packs_nyquist) {
             const c32* z = nyq_spec + (size_t)f * N + jf;
 #pragma unroll
@@ -611,18 +656,23 @@ k_half_pass1_split(const void* __restrict__ h0T, float descale, const float* __r
     const c32* e1 = lds + (P == 2 ? 2 : 0) * LinePitch<M>::elems;  // (P == 1, N = 16384: one column per workgroup, e1 / o1 unused)
     const c32* o1 = lds + (P == 2 ? 3 : 1) * LinePitch<M>::elems;
 #pragma unroll
-    for (int f = 0; f < 3; ++f) {
+    for (int ff = 0; ff < 3; ++ff) {
+        const int f = (ff == 0) ? 1 : ((ff == 1) ? 0 : 2);          // height, then (A, B normalised in place) disp_x, disp_z
         c32 reg[E];
         const int jf = opaque_lane(j);
-        half_spectrum<N, E, 2>(f, A, B, kxv, kscale, jf, reg, par);
+        if (ff == 0) half_spectrum<N, E, 2>(1, A, B, kxv, kscale, jf, reg, par);
+        else {
+            if (ff == 1) half_scale_AB<N, E, 2>(A, B, kxv, kscale, jf, par);
+            half_spectrum_scaled<N, E, 2>(f, A, B, kxv, kscale, jf, reg, par);
+        }
         if (packs_nyquist) {
             const c32* z = nyq_spec + (size_t)f * N + 2 * jf + par;
 #pragma unroll
             for (int e = 0; e < E; ++e) reg[e] = cadd_i(reg[e], z[2 * e * TS]);   // + i * Sn
         }
-        if (f > 0) __syncthreads();
+        if (ff > 0) __syncthreads();
         fft_line_to_lds<M, E, 2>(reg, jf, tw, lds_line);           // tw holds e^{2 pi i k / N}: stride 2 for length N/2
-        OCEAN_TL(2 + 2 * f);
+        OCEAN_TL(2 + 2 * ff);
         const int tf = opaque_lane(tid);
         c32* dst = inter + (size_t)f * lay.fs + (size_t)((X * P) / CW) * lay.sx + chunk_row_offset(lay, tf / CR) + (tf % CR) * CW +
                    ((X * P) % CW);                                  // + the wave-uniform part of the chunk row below (see k_half_pass1)
@@ -675,7 +725,7 @@ k_half_pass1_split(const void* __restrict__ h0T, float descale, const float* __r
                 *ohi = make_float4(hi0.x, hi0.y, hi1.x, hi1.y);
             }
         }
-        OCEAN_TL(3 + 2 * f);
+        OCEAN_TL(3 + 2 * ff);
     }
 }
 

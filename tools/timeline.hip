@@ -118,7 +118,7 @@ int main(int argc, char** argv) {
                 printf("  block %d start %.1f end %.1f;", fin[i].second, (t[(size_t)fin[i].second * 16] - t0) * 0.01, fin[i].first);
             printf("\n");
         }
-        const char* names1[] = {"load+propagate", "spectrum+FFT f0", "chunk stores f0", "spectrum+FFT f1", "chunk stores f1", "spectrum+FFT f2", "chunk stores f2"};
+        const char* names1[] = {"load+propagate", "spectrum+FFT height", "chunk stores height", "normalise+spectrum+FFT disp_x", "chunk stores disp_x", "spectrum+FFT disp_z", "chunk stores disp_z"};   // (N <= 512: one field per wave group, in field order)
         const char* names2[] = {"gather h + LDS expand", "FFT h", "gather dx,dz + LDS expand", "(read LDS)", "FFT dx+i dz", "RGBA stores"};
         const int nph = (pass == 1) ? 7 : 6;
         for (int k = 0; k < nph; ++k) {
