@@ -390,7 +390,8 @@ def main():
                          "ocean_pack_displacement to (disp_x, height, disp_z) (12) or the height alone (4)")
     ap.add_argument("--gather-steps", type=int, default=30)
     ap.add_argument("--gather-timeout", type=float, default=120.0, help="seconds before a stuck gather leg is abandoned")
-    ap.add_argument("--profile-frames", type=int, default=20, help="frames averaged for the per-kernel durations")
+    ap.add_argument("--profile-frames", type=int, default=20, help="minimum number of frames of the per-dispatch-event loop behind the timed "
+                    "region that yields the per-kernel durations (it runs max(steps, distribution-frames, this) frames)")
     ap.add_argument("--distribution-frames", type=int, default=200,
                     help="frames of the untimed loop behind the timed region that yields config.frame_ms_{median,p10,p90} (SURVEY 8d)")
     ap.add_argument("--ramp-frames", type=int, default=100, help="untimed frames before anything is measured (GPU clock ramp)")
@@ -472,18 +473,8 @@ def main():
 
     # A cold GPU needs tens of milliseconds of work to reach its running clocks (measured on MI355X: the first ~25
     # frames of a run are ~10 % slower, and with W = 5 the timed K = 20 steps would be measured on the ramp).  So,
-    # untimed and BEFORE the timed region: `--ramp-frames` frames, then the per-kernel durations (live, HIP events
-    # bound to the dispatches on the stream the kernels run on), then the W warmup steps.
+    # untimed and BEFORE the timed region: `--ramp-frames` frames, then the W warmup steps.
     dev.time_frames(args.ramp_frames, t0=0.0, dt=1.0 / 60.0)        # clock ramp, untimed (see above)
-    acc = {}
-    for i in range(args.profile_frames):
-        for name, ms in dev.profile_frame(i / 60.0):
-            acc[name] = acc.get(name, 0.0) + ms
-
-    # The profiling loop synchronises after every frame, which lets the clocks drop again (measured r04_run19: the K = 20 timed
-    # frames ran at 0.1829 ms by their own GPU events, the same loop a moment later at 0.1808): a second untimed ramp right
-    # before the W warmup steps, so that the timed region sees the running clocks like any steady frame loop does.
-    dev.time_frames(args.ramp_frames, t0=0.0, dt=1.0 / 60.0)
     for i in range(args.warmup):
         dev.frame(i / 60.0)
     barrier()
@@ -496,10 +487,15 @@ def main():
     # Distribution ("median + p10/p90"), AFTER the timed region so that `value` is untouched: a plain back-to-back
     # loop with one stream event every 10 frames (ocean_time_frame_batches: the frame), and a loop whose dispatches carry their
     # own begin/end events (ocean_frame_times: the two kernels; those launches leave ~5 % more gaps, so not the frame).
+    # The two kernels' durations come from the second loop as well: back-to-back frames, begin/end events bound to every
+    # dispatch on the stream it runs on.  [Rounds 1-3 profiled single frames with a synchronisation behind each: the clocks
+    # drop between such frames and pass 1 read 94-100 us where the frame loop -- and rocprofv3's steady-state average of the
+    # same command -- has 87-90 (r04_run19/20); the same synchronisations also slowed the timed region that followed.]
     per_batch = 10
-    dist_frames = max(args.steps, args.distribution_frames)
+    dist_frames = max(args.steps, args.distribution_frames, args.profile_frames)
     batch_ms = dev.time_frame_batches(max(2, dist_frames // per_batch), per_batch)
     p1_ms, p2_ms, _ = dev.frame_times(dist_frames)
+    acc = {"k_half_pass1": sum(p1_ms) / len(p1_ms), "k_half_pass2": sum(p2_ms) / len(p2_ms)}
     spread = {"frames": len(batch_ms) * per_batch, "frames_per_batch": per_batch, "frame": percentiles([b / per_batch for b in batch_ms]),
               "pass1": percentiles(p1_ms), "pass2": percentiles(p2_ms)}
 
@@ -515,8 +511,7 @@ def main():
     if args.intermediate == "bfp16":
         contract = CONTRACT16_BYTES_PER_TEXEL[args.spectrum]
     kernels = []
-    for name, total in acc.items():
-        avg_ms = total / args.profile_frames
+    for name, avg_ms in acc.items():
         b = moved[pass_of(name)] * n * n
         cb = contract[pass_of(name)] * n * n
         kernels.append({"name": name, "avg_ms": avg_ms, "algorithmic_bytes": b, "GBps": b / avg_ms / 1e6,
@@ -559,10 +554,10 @@ def main():
                        "frame_time_distribution": dict(spread, method="behind the timed region: `frame` = per-frame time of consecutive 10-frame batches of a "
                                                        "plain back-to-back loop (one stream event per batch, one sync at the end); pass1 / pass2 = per-dispatch "
                                                        "begin/end events of a second loop (ocean_frame_times)"),
-                       "effective_warmup_frames": 2 * args.ramp_frames + 3 * args.profile_frames + args.warmup,
-                       "untimed_before_timed_region": f"{args.ramp_frames} clock-ramp frames + {3 * args.profile_frames} frames of "
-                                                      f"per-kernel profiling + {args.ramp_frames} clock-ramp frames again + {args.warmup} "
-                                                      f"warmup (`warmup` above is W as given; effective_warmup_frames counts everything untimed)"},
+                       "effective_warmup_frames": args.ramp_frames + args.warmup,
+                       "untimed_before_timed_region": f"{args.ramp_frames} clock-ramp frames + {args.warmup} warmup (`warmup` above is W as "
+                                                      f"given; effective_warmup_frames counts everything untimed); the per-kernel durations and "
+                                                      f"the frame-time distribution are measured BEHIND the timed region"},
             "roofline": roofline,
         }
 
