@@ -165,7 +165,12 @@ template <int N> struct Launch {
     template <bool H16> static constexpr auto pass1_kernel() { return k_half_pass1<N, H::E1, H::P, H16, H::dma, H::fpar>; }
     template <bool H16, bool I16> static constexpr auto pass1_split_kernel() { return k_half_pass1_split<N, H::E1S, H::P, H16, I16>; }
     template <bool SHARD> static constexpr auto pass2_kernel() { return k_half_pass2<N, H::E2, CHUNK_W, H::R2h, H::p2_group, H::ppar, SHARD>; }
-    template <bool SHARD, bool I16> static constexpr auto pass2_split_kernel() { return k_half_pass2_split<N, H::E, CHUNK_W, H::p2_group, SHARD, I16>; }
+    // Pass 2 at N >= 8192: real-output rows (three N/2-point transforms per row, half the LDS and half the threads of a row:
+    // k_half_pass2_real).  Measured against two N-point transforms per row (r04_run23, one box, two repetitions): pass 2 at
+    // 8192 440 -> 350 us, at 16384 2.60 -> 1.67-1.72 ms; at 4096 88-91 -> 97-98 us and at 2048 17.8 -> 22.6 us (a row of
+    // 128 or 64 threads is a longer serial chain than it saves), so the sizes below keep k_half_pass2.
+    static constexpr bool REAL2 = SPLIT;
+    template <bool SHARD, bool I16> static constexpr auto pass2_real_kernel() { return k_half_pass2_real<N, H::E, CHUNK_W, H::p2_group, SHARD, I16>; }
     static hipError_t prepare_fused() {
         hipError_t e = hipSuccess;
         auto lds = [&](auto kernel, int bytes) {
@@ -173,10 +178,10 @@ template <int N> struct Launch {
         };
         if constexpr (SPLIT) {
             lds(pass1_split_kernel<false, false>(), H::split_lds1); lds(pass1_split_kernel<true, false>(), H::split_lds1);
-            lds(pass2_split_kernel<false, false>(), H::split_lds2); lds(pass2_split_kernel<true, false>(), H::split_lds2);
+            lds(pass2_real_kernel<false, false>(), H::real_lds2); lds(pass2_real_kernel<true, false>(), H::real_lds2);
             if constexpr (I16_BUILT) {
                 lds(pass1_split_kernel<false, true>(), H::split_lds1);  lds(pass1_split_kernel<true, true>(), H::split_lds1);
-                lds(pass2_split_kernel<false, true>(), H::split_lds2);
+                lds(pass2_real_kernel<false, true>(), H::real_lds2);
             }
         } else {
             lds(pass1_kernel<false>(), H::half_lds1); lds(pass1_kernel<true>(), H::half_lds1);
@@ -216,14 +221,14 @@ template <int N> struct Launch {
     static void pass2(OceanContext* c, hipStream_t s, Timing t = Timing()) {
         const c32* inter = c->inter;
         const c32* tw = c->tw;
-        if constexpr (SPLIT) {
+        if constexpr (REAL2) {
             if constexpr (I16_BUILT) {
                 if (c->inter16) {
-                    launch(pass2_split_kernel<false, true>(), dim3(N), dim3(H::split_threads2), H::split_lds2, s, t, inter, c->out, tw, c->lay_h, (const float*)c->inter_scale);
+                    launch(pass2_real_kernel<false, true>(), dim3(N), dim3(H::real_threads2), H::real_lds2, s, t, inter, c->out, tw, c->lay_h, (const float*)c->inter_scale);
                     return;
                 }
             }
-            launch(pass2_split_kernel<false, false>(), dim3(N), dim3(H::split_threads2), H::split_lds2, s, t, inter, c->out, tw, c->lay_h, (const float*)nullptr);
+            launch(pass2_real_kernel<false, false>(), dim3(N), dim3(H::real_threads2), H::real_lds2, s, t, inter, c->out, tw, c->lay_h, (const float*)nullptr);
         } else {
             launch(pass2_kernel<false>(), dim3(H::half_grid2), dim3(H::half_threads2), H::half_lds2, s, t, inter, c->out, tw, c->lay_h);
         }
@@ -243,8 +248,8 @@ template <int N> struct Launch {
         const InterLayout lay = H::tile_layout(world, parts);
         const int rows = N / world;
         const c32* tw = c->tw;
-        if constexpr (SPLIT)
-            hipLaunchKernelGGL((pass2_split_kernel<true, false>()), dim3(rows), dim3(H::split_threads2), H::split_lds2, s, recv, out_rows, tw, lay, (const float*)nullptr);
+        if constexpr (REAL2)
+            hipLaunchKernelGGL((pass2_real_kernel<true, false>()), dim3(rows), dim3(H::real_threads2), H::real_lds2, s, recv, out_rows, tw, lay, (const float*)nullptr);
         else
             hipLaunchKernelGGL((pass2_kernel<true>()), dim3(rows / H::R2h), dim3(H::half_threads2), H::half_lds2, s, recv, out_rows, tw, lay);
     }

@@ -5,9 +5,10 @@
 //                  (shader/fft_col.comp:44-63) of the half spectrum's columns, reading the *transposed* static inputs (h0T,
 //                  omegaT; made once at upload) so that every line is contiguous -- at N >= 2048 streamed through LDS by
 //                  LDS-DMA (half_load_AB_dma); writes the intermediate as 4 x 4 chunks (128 bytes);
-//   k_half_pass2 / k_half_pass2_split: rebuild full rows from the half spectrum, two complex FFTs along x
+//   k_half_pass2 (N <= 4096): rebuild full rows from the half spectrum, two complex FFTs along x
 //                  (shader/fft_row.comp:44-63) for the three real channels, sign correction and RGBA pack
-//                  (shader/correction.comp:24-35), whole-row stores.
+//                  (shader/correction.comp:24-35), whole-row stores;
+//   k_half_pass2_real (N >= 8192): the same rows as three real-output transforms of N/2 complex points each.
 // The column transform runs first (a separable 2-D DFT commutes), so that the pass that owns whole rows is the one that
 // writes the row-major RGBA image.  One tile over several GPUs: the same kernels on column / row blocks (x_group0, SHARD).
 // The staged 1:1 kernels, the map's consumers and the row-block sharding kernels: ocean_staged_kernels.hpp.
@@ -16,6 +17,8 @@
 // No launches in this header: it is also compiled by the host emulation harness (tests/hipemu) that checks the index
 // algebra on the CPU.
 #pragma once
+#include <utility>
+
 #include "fft_core.hpp"
 
 namespace ocean {
@@ -902,25 +905,56 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
     }
 }
 
-// Pass 2 for the split geometry (N = 8192): the row is rebuilt in LDS as two interleaved half-length lines
-// (C[2m] and C[2m+1]), each transformed by N/(2E) threads in three passes, and the final radix-2 step is done by
-// the thread that owns outputs n and n + N/2 in the epilogue (see k_half_pass1_split).  One row per workgroup.
-template <int N, int E, int P1, int GRP = 1, bool SHARD = false, bool I16 = false>
-__global__ void __launch_bounds__(N / E, ((N / E) == 512) ? 2 : 1)
-k_half_pass2_split(const c32* __restrict__ inter, float4* __restrict__ out, const c32* __restrict__ tw, InterLayout lay,
-                   const float* __restrict__ inter_scale) {
+// Pass 2 with real-output rows.  Every field's row is real, so its N values are ONE complex transform of M = N/2 points
+// (x[2m] + i x[2m+1] = sum_{k<M} Z[k] e^{2 pi i k m / M}) of
+//     Z[k] = (X[k] + conj X[M-k]) + i (X[k] - conj X[M-k]) e^{2 pi i k / N},      k < M,
+// where X[0 .. M] is the half spectrum the intermediate holds (column 0 = the real pair X[0], X[M]).  Against
+// k_half_pass2 (two N-point transforms per row: the height's wastes its imaginary half): three M-point transforms, 3/4
+// of the butterflies, half the LDS per row (two rows share a CU at N = 16384, four at 8192) and half the threads per row;
+// a thread keeps 2E reals of two fields until the third arrives, which is what the 128-VGPR budget allows.  Shipped at
+// N >= 8192 (Launch<N>::REAL2 with the measurements; rows of 128 or 64 threads at N <= 4096 are slower than k_half_pass2).
+//   thread j holds X[j + e T] (T = M / E): its partner M - j - e T is element E-1-e of thread T - j -- one LDS round
+//   trip (write own, read mirrored); e^{2 pi i (j + e T)/N} = tw[j] * e^{2 pi i e/(2E)}: one table entry per thread,
+//   the rest compile-time constants;
+//   the transform's last pass lands in LDS (fft_line_to_lds), from where thread t takes texels t + s T, s < 2E (the
+//   float (t & 1) of element (t >> 1) + s T/2): a wave's store instruction writes one contiguous KiB of the row, as
+//   the other pass-2 kernels do, instead of 16-byte pieces 32 bytes apart.
+// The loads of the next field are in flight under the current transform (__syncthreads() waits for LDS only).
+template <int E, int e>
+__device__ __forceinline__ c32 real_row_input(c32 x, c32 p, c32 wji, c32 wjn) {
+    const c32 ev = vfma(p, mk(1.0f, -1.0f), x);                    // X[k] + conj X[M-k]
+    const c32 dv = vfma(p, mk(-1.0f, 1.0f), x);                    // X[k] - conj X[M-k]
+    const c32 r = cmul_r(dv, wji, wjn);                            // i (..) e^{2 pi i j / N}
+    if constexpr (e == 0) return ev + r;
+    else {
+        constexpr float c = W64<e * (32 / E)>::c, s = W64<e * (32 / E)>::s;   // e^{2 pi i e T / N} = e^{2 pi i e / (2E)}
+        return vfma(yy(r), mk(-s, c), vfma(xx(r), mk(c, s), ev));
+    }
+}
+template <int E, int... I>
+__device__ __forceinline__ void real_row_inputs(const c32* lo, const c32* hi, int k1, bool dc, c32 wji, c32 wjn, c32 (&reg)[E],
+                                                std::integer_sequence<int, I...>) {
+    // own and mirrored element both come back from LDS: nothing but the transform's registers lives across the round trip
+    // kx = 0: the slot holds the real pair (X[0], X[M]); its mirror index M is not in the buffer
+    const c32 a0 = lo[0], p0 = hi[0];
+    reg[0] = real_row_input<E, 0>(dc ? mk(a0.x, 0.0f) : a0, dc ? mk(a0.y, 0.0f) : p0, wji, wjn);
+    ((I == 0 ? (void)0 : (void)(reg[I] = real_row_input<E, I>(lo[I * k1], hi[-I * k1], wji, wjn))), ...);
+}
+template <int N, int E, int P1, int GRP = 1, bool SHARD = false, bool I16 = false, int WPS = 4>
+__global__ void __launch_bounds__((N / 2) / E, WPS)
+k_half_pass2_real(const c32* __restrict__ inter, float4* __restrict__ out, const c32* __restrict__ tw, InterLayout lay,
+                  const float* __restrict__ inter_scale) {
     static_assert(!(SHARD && I16), "the 16-bit intermediate is not combined with the sharded tile");
     constexpr int M = N / 2;
-    constexpr int T = N / E;                                       // threads per row
-    constexpr int TS = M / E;                                      // threads per sub-line
-    constexpr int EH = E / 2;
+    constexpr int T = M / E;                                       // threads per row
     constexpr int CR = CHUNK_R;
-    static_assert(P1 == CHUNK_W && T % P1 == 0 && (E % 2) == 0 && T == 2 * TS, "geometry");
+    constexpr int K1 = T + T / 16;                                 // lds_pad(i + T) - lds_pad(i)
+    static_assert(P1 == CHUNK_W && T % P1 == 0 && T % 16 == 0 && 32 % E == 0, "geometry");
+    // lds_pad(i + s T/2) - lds_pad(i) for the i < T/2 of the store mapping (T/2 a multiple of 16, or 8 with i < 8)
+    auto k2 = [](int s) { return s * (T / 2) + ((s * (T / 2)) >> 4); };
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    c32* lds = reinterpret_cast<c32*>(smem);
+    c32* line = reinterpret_cast<c32*>(smem);                      // LinePitch<M>::elems
     const int tid = threadIdx.x;
-    const int par = (TS >= 64) ? wave_uniform(tid / TS) : (tid / TS);   // the sub-line this thread transforms
-    const int j = tid % TS;
     constexpr int S = CR * GRP;                                    // workgroups sharing a chunk line (x GRP chunk rows): same XCD
     int rb = blockIdx.x;
     if ((gridDim.x % (8 * S)) == 0) {
@@ -928,149 +962,78 @@ k_half_pass2_split(const c32* __restrict__ inter, float4* __restrict__ out, cons
         rb = ((slot / S) * 8 + xcd) * S + (slot % S);
     }
     const int y = rb;
-    c32* line0 = lds;
-    c32* line1 = lds + LinePitch<M>::elems;
-    c32* my_line = par ? line1 : line0;
-
-    float keep_lo[EH], keep_hi[EH];
-    OCEAN_TL(0);
-    // The (disp_x, disp_z) loads are issued before the height transform (all three fields in flight at once): with two
-    // 512-thread workgroups per CU the gather is short of requests in flight, not of L2 -- pass 2 462-470 -> 426-429 us,
-    // 1084-1098 -> 1148-1149 frames/s at N = 8192 (r03_run21; the same idea costs 2-3 us at 4096, where four workgroups
-    // per CU already fill the queues: k_half_pass2).  A/B knob: -DOCEAN_P2S_PREFETCH=0.
-    constexpr bool PREFETCH = true;
-    c32 pre_x[EH], pre_z[EH];                                      // (I16: the raw int16 pairs in .x, their scales in .y)
-    if constexpr (PREFETCH) {
-        const size_t offy0 = chunk_row_offset(lay, y / CR) + (y % CR) * P1 + (tid % P1);
+    // Element offsets in 32 bits (the whole intermediate of N = 16384 is 3 * 2^27 elements of 8 bytes: byte offsets fit too),
+    // so that an address is one VGPR on top of the scalar base.
+    static_assert((uint64_t)3 * (N / 2) * N * sizeof(c32) + ((uint64_t)1 << 28) < ((uint64_t)1 << 32), "32-bit byte offsets");
+    const uint32_t sx = (uint32_t)lay.sx, fs = (uint32_t)lay.fs;
+    const uint32_t offy = (uint32_t)chunk_row_offset(lay, y / CR) + (uint32_t)((y % CR) * P1 + (tid % P1));
+    constexpr uint32_t SF = (uint32_t)(N / 64) * (N / 4);          // I16: one field's scales
+    // the E half-spectrum values kx = tid + e T of field f (I16: the raw int16 pair in .x, its scale in .y)
+    auto issue = [&](int f, c32 (&raw)[E]) {
+        const char* base = reinterpret_cast<const char*>(inter);
 #pragma unroll
-        for (int e = 0; e < EH; ++e) {
-            const int Xc = tid / P1 + e * (T / P1);
-            if constexpr (SHARD) {
-                const size_t o = offy0 + tile_slab_offset(lay, Xc);
-                pre_x[e] = inter[o];
-                pre_z[e] = inter[(size_t)2 * lay.fs + o];
+        for (int e = 0; e < E; ++e) {
+            const uint32_t Xc = (uint32_t)(tid / P1 + e * (T / P1));
+            if constexpr (SHARD) {                                 // chunk column Xc of the tile sits in a source rank's slab: tile_slab_offset
+                const uint32_t v = Xc >> lay.xs_shift;
+                const uint32_t slab = ((v & ((1u << lay.part_bits) - 1u)) << lay.rank_bits) | (v >> lay.part_bits);
+                const uint32_t o = (uint32_t)f * fs + offy + slab * (uint32_t)lay.src_stride + (Xc & ((1u << lay.xs_shift) - 1u)) * sx;
+                raw[e] = *reinterpret_cast<const c32*>(base + (size_t)(o * 8u));
             } else if constexpr (I16) {
-                const uint32_t* b32 = reinterpret_cast<const uint32_t*>(inter) + offy0 + (size_t)Xc * lay.sx;
-                const float* sc = inter_scale + (size_t)(y >> 6) * (N / 4) + (tid >> 1) + e * (T / 2);
-                constexpr size_t SF = (size_t)(N / 64) * (N / 4);
-                pre_x[e] = mk(__builtin_bit_cast(float, b32[0]), sc[0]);
-                pre_z[e] = mk(__builtin_bit_cast(float, b32[(size_t)2 * lay.fs]), sc[2 * SF]);
+                const uint32_t o = (uint32_t)f * fs + offy + Xc * sx;
+                const float* sc = inter_scale + ((uint32_t)f * SF + (uint32_t)(y >> 6) * (N / 4) + (uint32_t)(tid >> 1) + e * (T / 2));
+                raw[e] = mk(*reinterpret_cast<const float*>(base + (size_t)(o * 4u)), sc[0]);
             } else {
-                const size_t o = offy0 + (size_t)Xc * lay.sx;
-                pre_x[e] = inter[o];
-                pre_z[e] = inter[(size_t)2 * lay.fs + o];
+                const uint32_t o = (uint32_t)f * fs + offy + Xc * sx;
+                raw[e] = *reinterpret_cast<const c32*>(base + (size_t)(o * 8u));
             }
         }
-    }
+    };
+    float keep_h[2 * E], keep_x[2 * E];
+    const float sgn = (((tid + y) & 1) == 0) ? -0.5f : 0.5f;       // correction.comp:29 and the 1/2 of S(F); T is even
+    float4* orow = out + (size_t)y * N;
+    // one field: pair, transform, take the store mapping.  `after_pairing` issues the loads that replace raw's registers.
+    auto field = [&](int it, const c32 (&raw)[E], auto&& after_pairing) {
+        const int jf = opaque_lane(tid);
+        if (it > 0) __syncthreads();                               // the previous field's store-mapped reads are done
+        c32* lo = line + lds_pad(jf);
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {                         // 0: height, 1: (disp_x, disp_z)
-        const int tf = opaque_lane(tid);                           // loads: kx = tf + e*T, e < E/2
-        const size_t off = chunk_row_offset(lay, y / CR) + (size_t)(tf / P1) * lay.sx + (y % CR) * P1 + (tf % P1);
-        c32 a[EH], b[EH];
-        if constexpr (SHARD) {                                     // see k_half_pass2
-            const size_t offy = chunk_row_offset(lay, y / CR) + (y % CR) * P1 + (tf % P1);
-#pragma unroll
-            for (int e = 0; e < EH; ++e) {
-                const int Xc = tf / P1 + e * (T / P1);
-                const size_t o = offy + tile_slab_offset(lay, Xc);
-                if (pass == 0) a[e] = inter[(size_t)1 * lay.fs + o];
-                else if constexpr (PREFETCH) { a[e] = pre_x[e]; b[e] = pre_z[e]; }
-                else { a[e] = inter[o]; b[e] = inter[(size_t)2 * lay.fs + o]; }
-            }
-        } else if constexpr (I16) {
-            // int16 pairs at the fp32 layout's element offsets; the scale of (row block y / 64, column pair kx / 2)
-            const uint32_t* b32 = reinterpret_cast<const uint32_t*>(inter) + off;
-            const float* sc = inter_scale + (size_t)(y >> 6) * (N / 4) + (tf >> 1);
-            constexpr size_t SF = (size_t)(N / 64) * (N / 4);      // one field's scales
-#pragma unroll
-            for (int e = 0; e < EH; ++e) {
-                const size_t o = (size_t)e * (T / P1) * lay.sx;
-                if (pass == 0) a[e] = unpack_i16x2(b32[(size_t)1 * lay.fs + o], sc[SF + e * (T / 2)]);
-                else if constexpr (PREFETCH) {
-                    a[e] = unpack_i16x2(__builtin_bit_cast(uint32_t, pre_x[e].x), pre_x[e].y);
-                    b[e] = unpack_i16x2(__builtin_bit_cast(uint32_t, pre_z[e].x), pre_z[e].y);
-                } else {
-                    a[e] = unpack_i16x2(b32[o], sc[e * (T / 2)]);
-                    b[e] = unpack_i16x2(b32[(size_t)2 * lay.fs + o], sc[2 * SF + e * (T / 2)]);
-                }
-            }
+        for (int e = 0; e < E; ++e) {
+            if constexpr (I16) lo[e * K1] = unpack_i16x2(__builtin_bit_cast(uint32_t, raw[e].x), raw[e].y);
+            else lo[e * K1] = raw[e];
         }
-        else if (pass == 0) {
-            const c32* src = inter + (size_t)1 * lay.fs + off;
-#pragma unroll
-            for (int e = 0; e < EH; ++e) a[e] = src[(size_t)e * (T / P1) * lay.sx];
-        } else if constexpr (PREFETCH) {
-#pragma unroll
-            for (int e = 0; e < EH; ++e) { a[e] = pre_x[e]; b[e] = pre_z[e]; }
-        } else {
-            const c32* sx_ = inter + off;
-            const c32* sz_ = inter + (size_t)2 * lay.fs + off;
-#pragma unroll
-            for (int e = 0; e < EH; ++e) { a[e] = sx_[(size_t)e * (T / P1) * lay.sx]; b[e] = sz_[(size_t)e * (T / P1) * lay.sx]; }
-        }
-        if (pass > 0) __syncthreads();
-        // C[kx] goes to sub-line kx & 1 at index kx >> 1; kx = tf + e*T keeps its parity (T is even).  Its mirror
-        // C[N - kx] has the same parity and index N/2 - (kx >> 1) - (kx & 1).
-        const int kp = tf & 1, m0 = tf >> 1;
-        c32* base = kp ? line1 : line0;
-        c32* lo = base + lds_pad(m0);                              // + e * (T/2 + T/32)
-        c32* hi = base + lds_pad(M - m0 - kp);                     // - e * (T/2 + T/32)
-#pragma unroll
-        for (int e = 0; e < EH; ++e) {
-            c32 ck, cm;
-            if (pass == 0) {
-                ck = a[e];
-                cm = cconj(a[e]);
-            } else {
-                ck = cadd_i(a[e], b[e]);
-                cm = vfma(yx(b[e]), mk(1.0f, 1.0f), cconj(a[e]));
-            }
-            if (e == 0) {
-                const bool dc = (tf == 0);                         // kx = 0 -> (even, 0); its mirror slot is the Nyquist bin (even, N/4)
-                if (dc) {
-                    const c32 bb = (pass == 0) ? mk(0.0f, 0.0f) : b[e];
-                    ck = mk(a[e].x, bb.x);
-                    cm = mk(a[e].y, bb.y);
-                }
-                lo[0] = ck;
-                (dc ? (line0 + lds_pad(M / 2)) : hi)[0] = cm;
-            } else {
-                lo[e * (T / 2 + T / 32)] = ck;
-                hi[-e * (T / 2 + T / 32)] = cm;
-            }
-        }
-        __syncthreads();
-        OCEAN_TL(1 + 3 * pass);
+        line_sync<T>();
+        const c32 wj = tw[jf];                                     // e^{2 pi i j / N}
         c32 reg[E];
-        const int jf = opaque_lane(j);
-        const c32* g = my_line + lds_pad(jf);
+        real_row_inputs<E>(lo, line + lds_pad(M - jf), K1, jf == 0, crot(wj), -wj, reg, std::make_integer_sequence<int, E>{});
+        line_sync<T>();                                            // the mirrored reads are done before the transform scatters
+        after_pairing();
+        if (it == 0) OCEAN_TL(1);
+        fft_line_to_lds<M, E, 2, true>(reg, jf, tw, line);
+        if (it == 2) OCEAN_TL(5);
+        const float* src = reinterpret_cast<const float*>(line + lds_pad(jf >> 1)) + (jf & 1);
+        if (it == 0) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) reg[e] = g[e * (TS + TS / 16)];
-        __syncthreads();
-        fft_line_to_lds<M, E, 2>(reg, jf, tw, my_line);
-        OCEAN_TL(2 + 3 * pass);
-        // radix-2 combine: X[n] = E[n] + W^n O[n], X[n + N/2] = E[n] - W^n O[n]; n = tf + q*T
-        float4* orow = out + (size_t)y * N;
-        const float sgn = (((tf + y) & 1) == 0) ? -0.5f : 0.5f;    // correction.comp:29 and the 1/2 of S(F); T and N/2 are even
+            for (int s = 0; s < 2 * E; ++s) keep_h[s] = src[2 * k2(s)];
+        } else if (it == 1) {
 #pragma unroll
-        for (int q = 0; q < EH; ++q) {
-            const int n = tf + q * T;
-            const int pn = lds_pad(n);
-            const c32 w = tw[n];
-            const c32 t = cmul(line1[pn], w);
-            const c32 u = line0[pn];
-            const c32 xl = u + t, xh = u - t;
-            if (pass == 0) {
-                keep_lo[q] = xl.x;
-                keep_hi[q] = xh.x;
-            } else {
-                const c32 dl = xl * sgn, dh = xh * sgn;
-                store_float4_nt(orow + n, make_float4(dl.x, keep_lo[q] * sgn, dl.y, 0.0f));
-                store_float4_nt(orow + n + M, make_float4(dh.x, keep_hi[q] * sgn, dh.y, 0.0f));
-            }
+            for (int s = 0; s < 2 * E; ++s) keep_x[s] = src[2 * k2(s)];
+        } else {
+#pragma unroll
+            for (int s = 0; s < 2 * E; ++s)
+                store_float4_nt(orow + jf + s * T, make_float4(keep_x[s] * sgn, keep_h[s] * sgn, src[2 * k2(s)] * sgn, 0.0f));
         }
-        if (pass == 1) OCEAN_TL(6);
-    }
+    };
+    OCEAN_TL(0);
+    c32 raw_h[E], raw_x[E], raw_z[E];
+    issue(1, raw_h);
+    issue(0, raw_x);
+    field(0, raw_h, [&] { issue(2, raw_z); });
+    OCEAN_TL(2);
+    field(1, raw_x, [] {});
+    OCEAN_TL(4);
+    field(2, raw_z, [] {});
+    OCEAN_TL(6);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1149,12 +1112,13 @@ template <int N, int PSEL = 0> struct Geo {
     static constexpr int stage_threads = 4 * T;
     static constexpr int stage_lds = 4 * line_bytes;
     static constexpr int stage_grid = N / 4;
-    // split geometry (lines as two interleaved N/2 transforms; k_half_pass1_split / k_half_pass2_split): N = 8192 in the
+    // split geometry (lines as two interleaved N/2 transforms; k_half_pass1_split; pass 2 is k_half_pass2_real): N >= 8192 in the
     // product, any N >= 512 in the emulation
     static constexpr bool can_split = (P <= 2) && (N >= 512);
     static constexpr int split_lds1 = max_i(2 * P * LinePitch<N / 2>::elems * (int)sizeof(c32), DmaRingBytes<can_split, N, E1S, P, 2>::value);
-    static constexpr int split_lds2 = 2 * LinePitch<N / 2>::elems * (int)sizeof(c32);
-    static constexpr int split_threads2 = T;
+    // real-output pass 2 (k_half_pass2_real): one row of N/2 complex points per workgroup
+    static constexpr int real_threads2 = (N / 2) / E;
+    static constexpr int real_lds2 = LinePitch<N / 2>::elems * (int)sizeof(c32);
     // One tile sharded over `world` GPUs (ocean_tile_pass1 / ocean_tile_pass2): rank r owns the half-spectrum columns
     // [r N/(2 world), ..) in pass 1 and the rows [r N/world, ..) in pass 2.  The all-to-all buffers are
     //     [dest or src][block of B chunk rows][field][chunk column][chunk row in block][16 elements]

@@ -280,6 +280,33 @@ def test_fused_sharded_single_rank_and_loopback_in_the_emulation():
         sharded.FusedShardedTile(backs[0])                       # world 2 without a process group
 
 
+def test_fused_sharded_real_output_rows_in_the_emulation():
+    """The sharded variant of the real-output pass 2 (k_half_pass2_real<SHARD>, what ocean_tile_pass2 launches at N >= 8192)
+    at a size the emulation can run: both ranks of a world-2 tile in one process, the exchange in 1 and 2 pieces."""
+    import emu
+    n, t, world = 512, 0.75, 2
+    h0, om = g.synth.make_inputs(n, seed=6)
+    ref = oc.frame_f64(h0, om, t)
+    for parts in (1, 2):
+        backs = [emu.EmuTileBackend(n, r, world, psel=2, parts=parts, real2=True) for r in range(world)]
+        sends = [b.alloc_exchange() for b in backs]
+        recvs = [b.alloc_exchange() for b in backs]
+        outs = [b.alloc_out() for b in backs]
+        for b, s_ in zip(backs, sends):
+            b.upload(h0, om)
+            for k in range(parts):
+                b.pass1(t, 1000.0, s_[k], part=k)
+        for r in range(world):
+            for src in range(world):
+                for k in range(parts):
+                    recvs[r][k, src] = sends[src][k, r]
+        for b, r_, o in zip(backs, recvs, outs):
+            b.pass2(r_, o)
+        full = np.concatenate([o.numpy() for o in outs], axis=0)
+        nmax, rl2 = oc.parity_errors(full[..., :3], ref[..., :3])
+        assert nmax.max() < 1e-5 and rl2.max() < 1e-5 and np.all(full[..., 3] == 0.0), parts
+
+
 def _fused_loopback_frame(n, world, t, h0, om, f16=False, parts=1):
     """All ranks of ONE fused sharded tile on device 0, one context (the tile entry points keep no per-rank state); the
     all-to-all by hand with device-to-device copies.  Returns the assembled tile [y, x, 4]."""

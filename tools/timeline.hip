@@ -120,6 +120,7 @@ int main(int argc, char** argv) {
         }
         const char* names1[] = {"load+propagate", "spectrum+FFT height", "chunk stores height", "normalise+spectrum+FFT disp_x", "chunk stores disp_x", "spectrum+FFT disp_z", "chunk stores disp_z"};   // (N <= 512: one field per wave group, in field order)
         const char* names2[] = {"gather h + LDS expand", "FFT h", "gather dx,dz + LDS expand", "(read LDS)", "FFT dx+i dz", "RGBA stores"};
+        const char* names2r[] = {"loads h + pair through LDS", "transform h, take the store mapping", "pair + transform disp_x", "", "pair + transform disp_z", "RGBA stores"};   // k_half_pass2_real (N >= 8192)
         const int nph = (pass == 1) ? 7 : 6;
         for (int k = 0; k < nph; ++k) {
             std::vector<double> v;
@@ -132,7 +133,7 @@ int main(int argc, char** argv) {
                 for (int b = first; b < nb; ++b) if (complete(b)) v.push_back((t[(size_t)b * 16 + 4] - t[(size_t)b * 16 + 2]) * 0.01);
             }
             if (pass == 2 && k == 3) continue;
-            stats(pass == 1 ? names1[k] : names2[k], v);
+            stats(pass == 1 ? names1[k] : (N > 4096 ? names2r[k] : names2[k]), v);
         }
         std::vector<double> life, start;
         for (int b = first; b < nb; ++b) if (complete(b)) { life.push_back((t[(size_t)b * 16 + last] - t[(size_t)b * 16]) * 0.01); start.push_back((t[(size_t)b * 16] - t0) * 0.01); }
