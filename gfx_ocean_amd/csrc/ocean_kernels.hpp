@@ -654,10 +654,6 @@ k_half_pass1_split(const void* __restrict__ h0T, float descale, const float* __r
     OCEAN_TL(1);
     const c32 kxv = mk(wave_index_q1(x, N), wave_index_q1(x2, N)) * kscale;
 
-    const c32* e0 = lds;                                           // column 0: even, odd; column 1: even, odd
-    const c32* o0 = lds + LinePitch<M>::elems;
-    const c32* e1 = lds + (P == 2 ? 2 : 0) * LinePitch<M>::elems;  // (P == 1, N = 16384: one column per workgroup, e1 / o1 unused)
-    const c32* o1 = lds + (P == 2 ? 3 : 1) * LinePitch<M>::elems;
 #pragma unroll
     for (int ff = 0; ff < 3; ++ff) {
         const int f = (ff == 0) ? 1 : ((ff == 1) ? 0 : 2);          // height, then (A, B normalised in place) disp_x, disp_z
@@ -677,42 +673,44 @@ k_half_pass1_split(const void* __restrict__ h0T, float descale, const float* __r
         fft_line_to_lds<M, E, 2>(reg, jf, tw, lds_line);           // tw holds e^{2 pi i k / N}: stride 2 for length N/2
         OCEAN_TL(2 + 2 * ff);
         const int tf = opaque_lane(tid);
-        c32* dst = inter + (size_t)f * lay.fs + (size_t)((X * P) / CW) * lay.sx + chunk_row_offset(lay, tf / CR) + (tf % CR) * CW +
-                   ((X * P) % CW);                                  // + the wave-uniform part of the chunk row below (see k_half_pass1)
+        // The chunks of the split geometry are COLUMN-major inside (element (row r, column c) at c CR + r; SPLIT_CMAJOR):
+        // a workgroup owns P < CW columns of every chunk, and its part of a chunk is then P * 32 contiguous bytes -- a thread
+        // combines and stores two consecutive rows of one column (16 bytes), 2P adjacent lanes one piece -- instead of
+        // CR pieces of P * 8 bytes 32 bytes apart.  Measured (r04_run25, one box, two repetitions): pass 1 at 16384
+        // 1996-2001 -> 1766-1823 us (8-byte -> 32-byte pieces), at 8192 413-420 -> 414-428 us (16 -> 64: nothing); pass 2,
+        // whose lanes now read 8 bytes 32 bytes apart inside the same 128-byte lines, +1 %.
+        // Thread tf: chunk row g = tf / (2P) (+ the wave-uniform q THREADS / (2P) below: no carry between them in
+        // chunk_row_offset, see k_half_pass1), column cc = (tf / 2) % P, rows 2 rp, 2 rp + 1 of the chunk, rp = tf % 2.
+        const int rp = tf & 1, cc = (tf >> 1) & (P - 1), g = tf / (2 * P);
+        const c32* ev = lds + (2 * cc) * LinePitch<M>::elems;      // the column's even and odd sub-lines
+        const c32* od = ev + LinePitch<M>::elems;
+        c32* dst = inter + (size_t)f * lay.fs + (size_t)((X * P) / CW) * lay.sx + chunk_row_offset(lay, g) + (((X * P) % CW) + cc) * CR + 2 * rp;
+        constexpr int ROWS = (2 * THREADS) / P;                    // rows of every column one iteration covers
 #pragma unroll
-        for (int q0 = 0; q0 < M / THREADS; ++q0) {
+        for (int q0 = 0; q0 < M / ROWS; ++q0) {
             const int q = q0;
-            const int k = tf + q * THREADS;                        // rows k and k + M
-            const c32 w = tw[k];
-            const c32 wr = crot(w);
-            const int pk = lds_pad(k);
-            if constexpr (P == 1) {
-                // One column per workgroup (N = 16384: two 8192-point sub-lines fill the LDS): 8-byte elements, a quarter of
-                // a chunk row each; the four column workgroups of a chunk column run in adjacent slots of one XCD.
-                const c32 t0 = cmul_r(o0[pk], w, wr);
-                const c32 u0 = e0[pk];
-                dst[chunk_row_offset(lay, q * (THREADS / CR))] = u0 + t0;
-                dst[chunk_row_offset(lay, q * (THREADS / CR) + M / CR)] = u0 - t0;
-                continue;
-            }
-            const c32 t0 = cmul_r(o0[pk], w, wr), t1 = cmul_r(o1[pk], w, wr);
-            const c32 u0 = e0[pk], u1 = e1[pk];
-            const c32 lo0 = u0 + t0, hi0 = u0 - t0, lo1 = u1 + t1, hi1 = u1 - t1;
-            float4* olo = reinterpret_cast<float4*>(dst + chunk_row_offset(lay, q * (THREADS / CR)));
-            float4* ohi = reinterpret_cast<float4*>(dst + chunk_row_offset(lay, q * (THREADS / CR) + M / CR));
+            const int k = CR * g + 2 * rp + q * ROWS;              // rows k, k + 1 and k + M, k + M + 1
+            const float4 w2 = *reinterpret_cast<const float4*>(tw + k);   // e^{2 pi i k / N}, e^{2 pi i (k + 1) / N}
+            const c32 wa = mk(w2.x, w2.y), wb = mk(w2.z, w2.w);
+            const int pk = lds_pad(k);                             // k is even: k + 1 has the same k >> 4
+            const c32 ta = cmul_r(od[pk], wa, crot(wa)), tb = cmul_r(od[pk + 1], wb, crot(wb));
+            const c32 ua = ev[pk], ub = ev[pk + 1];
+            const c32 loa = ua + ta, hia = ua - ta, lob = ub + tb, hib = ub - tb;
+            float4* olo = reinterpret_cast<float4*>(dst + chunk_row_offset(lay, q * (ROWS / CR)));
+            float4* ohi = reinterpret_cast<float4*>(dst + chunk_row_offset(lay, q * (ROWS / CR) + M / CR));
             if constexpr (I16) {
-                // one scale for this wave's two store blocks (rows k .. k+63 and k+M ..: the same columns, the same
-                // magnitudes); the 8-byte row pieces go to the element offsets of the fp32 layout, 4 bytes per element
-                const c32 a0 = mk(fabsf(lo0.x), fabsf(lo0.y)), a1 = mk(fabsf(lo1.x), fabsf(lo1.y));
-                const c32 b0 = mk(fabsf(hi0.x), fabsf(hi0.y)), b1 = mk(fabsf(hi1.x), fabsf(hi1.y));
+                // one scale for this wave's two store blocks (64 rows x 2 columns: rows k .. k+63 and k+M .., the same columns,
+                // the same magnitudes); int16 pairs at the element offsets of the fp32 layout, 4 bytes per element
+                const c32 a0 = mk(fabsf(loa.x), fabsf(loa.y)), a1 = mk(fabsf(lob.x), fabsf(lob.y));
+                const c32 b0 = mk(fabsf(hia.x), fabsf(hia.y)), b1 = mk(fabsf(hib.x), fabsf(hib.y));
                 const float m = wave_max_nonneg(fmaxf(fmaxf(fmaxf(a0.x, a0.y), fmaxf(a1.x, a1.y)), fmaxf(fmaxf(b0.x, b0.y), fmaxf(b1.x, b1.y))));
                 float scale, inv;
                 block_scale_i16(m, scale, inv);
                 uint32_t* base32 = reinterpret_cast<uint32_t*>(inter);
                 uint2* qlo = reinterpret_cast<uint2*>(base32 + (reinterpret_cast<c32*>(olo) - inter));
                 uint2* qhi = reinterpret_cast<uint2*>(base32 + (reinterpret_cast<c32*>(ohi) - inter));
-                *qlo = make_uint2(pack_i16x2(lo0, inv), pack_i16x2(lo1, inv));
-                *qhi = make_uint2(pack_i16x2(hi0, inv), pack_i16x2(hi1, inv));
+                *qlo = make_uint2(pack_i16x2(loa, inv), pack_i16x2(lob, inv));
+                *qhi = make_uint2(pack_i16x2(hia, inv), pack_i16x2(hib, inv));
                 if ((tf & 63) == 0) {                              // one lane per wave: the two blocks' entries
                     float* sc = inter_scale + ((size_t)f * (N / 64) + (size_t)(k >> 6)) * (N / 4) + Xg;
                     sc[0] = scale;
@@ -720,13 +718,8 @@ k_half_pass1_split(const void* __restrict__ h0T, float descale, const float* __r
                 }
                 continue;
             }
-            if constexpr (P == CW) {                               // whole chunk rows (2-column chunks): streamed
-                store_float4_nt(olo, make_float4(lo0.x, lo0.y, lo1.x, lo1.y));
-                store_float4_nt(ohi, make_float4(hi0.x, hi0.y, hi1.x, hi1.y));
-            } else {
-                *olo = make_float4(lo0.x, lo0.y, lo1.x, lo1.y);    // half a chunk row: meets its other half in L2
-                *ohi = make_float4(hi0.x, hi0.y, hi1.x, hi1.y);
-            }
+            *olo = make_float4(loa.x, loa.y, lob.x, lob.y);        // P of a chunk's CW columns: meets the others in L2 (plain
+            *ohi = make_float4(hia.x, hia.y, hib.x, hib.y);        // stores; streamed 32-byte pieces: pass 1 x 2.3-3 at 16384)
         }
         OCEAN_TL(3 + 2 * ff);
     }
@@ -966,7 +959,7 @@ k_half_pass2_real(const c32* __restrict__ inter, float4* __restrict__ out, const
     // so that an address is one VGPR on top of the scalar base.
     static_assert((uint64_t)3 * (N / 2) * N * sizeof(c32) + ((uint64_t)1 << 28) < ((uint64_t)1 << 32), "32-bit byte offsets");
     const uint32_t sx = (uint32_t)lay.sx, fs = (uint32_t)lay.fs;
-    const uint32_t offy = (uint32_t)chunk_row_offset(lay, y / CR) + (uint32_t)((y % CR) * P1 + (tid % P1));
+    const uint32_t offy = (uint32_t)chunk_row_offset(lay, y / CR) + (uint32_t)((tid % P1) * CR + (y % CR));   // column-major chunks (k_half_pass1_split)
     constexpr uint32_t SF = (uint32_t)(N / 64) * (N / 4);          // I16: one field's scales
     // the E half-spectrum values kx = tid + e T of field f (I16: the raw int16 pair in .x, its scale in .y)
     auto issue = [&](int f, c32 (&raw)[E]) {

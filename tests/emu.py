@@ -96,15 +96,16 @@ def inter_layout(n, P, layout="p2", pad=32):
     return _layout(n, n, P, layout, pad)
 
 
-def unpack_inter(inter, n, P, lay, f, columns=None):
-    """Intermediate field f -> natural [y, x] array (columns < n for the half-spectrum path)."""
+def unpack_inter(inter, n, P, lay, f, columns=None, cmajor=False):
+    """Intermediate field f -> natural [y, x] array (columns < n for the half-spectrum path).  cmajor: the chunks of the
+    split geometry (k_half_pass1_split -> k_half_pass2_real) are column-major inside."""
     sx, sy, fs = lay[:3]
     columns = columns or n
     cw, cr = chunk()
     X, Y, r, c = np.meshgrid(np.arange(columns // cw), np.arange(n // cr), np.arange(cr), np.arange(cw), indexing="ij")
     if len(lay) == 4:                                   # block layout of the half-spectrum path
         b = lay[3]
-        idx = f * fs + (Y >> b) * sy + X * sx + (Y & ((1 << b) - 1)) * (cw * cr) + r * cw + c
+        idx = f * fs + (Y >> b) * sy + X * sx + (Y & ((1 << b) - 1)) * (cw * cr) + ((c * cr + r) if cmajor else (r * cw + c))
     else:
         idx = f * fs + X * sx + Y * sy + r * cw + c
     out = np.empty((n, columns), np.complex64)
@@ -148,7 +149,7 @@ def quantize_f16(h0):
 
 
 def frame_half(h0, omega, time, L=1000.0, layout="p2", return_inter=False, spectrum_fp16=False, P=None, split=False, bshift=None,
-               inter16=False, real2=False):
+               inter16=False):
     """split=True: every line as two interleaved N/2 transforms (the N = 8192 geometry, P = 2; with P=1 the N = 16384 geometry:
     one column per pass-1 workgroup); inter16=True (split, P = 2 only): the 16-bit block-floating intermediate (OCEAN_INTER_BFP16)."""
     n = h0.shape[0]
@@ -168,7 +169,7 @@ def frame_half(h0, omega, time, L=1000.0, layout="p2", return_inter=False, spect
     tw = twiddles(n)
     assert split or not inter16
     scales = np.full(3 * (n // 64) * (n // 4), np.nan, np.float32) if inter16 else None
-    psel = ((23 if inter16 else (21 if P == 1 else 22)) if split else int(P)) + (100 if real2 else 0)   # + 100: k_half_pass2_real
+    psel = (23 if inter16 else (21 if P == 1 else 22)) if split else int(P)
     assert lib().emu_frame_half(n, psel, _p(h0T), int(spectrum_fp16), descale, _p(omT), _p(inter),
                                 _p(nyq), _p(out), _p(tw), sx, sy, fs, bshift, time, L, _p(scales) if inter16 else None) == 0
     if return_inter:
@@ -270,9 +271,8 @@ class EmuTileBackend:
     """Backend of gfx_ocean_amd.sharded.FusedShardedTile that runs the fused kernels of ocean_tile_pass1 / ocean_tile_pass2
     on the CPU (numpy buffers wrapped as torch CPU tensors for gloo).  Test infrastructure only."""
 
-    def __init__(self, n, rank, world, psel=None, parts=1, real2=False):
-        import torch
-        self.real2 = bool(real2)                                   # pass 2 = k_half_pass2_real (the product's at N >= 8192)
+    def __init__(self, n, rank, world, psel=None, parts=1):
+        import torch                                               # psel 22 / 21: the split geometry (the product's at N = 8192 / 16384)
         self.torch = torch
         self.n, self.rank, self.world, self.rows, self.parts = n, rank, world, n // world, parts
         self.tw = twiddles(n)
@@ -299,7 +299,7 @@ class EmuTileBackend:
                               _p(send_part.numpy()), _p(self.nyq), None, _p(self.tw), float(time), float(domain_size)) == 0
 
     def pass2(self, recv, out):
-        assert lib().emu_tile(self.n, 2, self.psel + (100 if self.real2 else 0), self.rank, self.world, 0, self.parts, None, 0, 1.0, None, _p(recv.numpy()), None,
+        assert lib().emu_tile(self.n, 2, self.psel, self.rank, self.world, 0, self.parts, None, 0, 1.0, None, _p(recv.numpy()), None,
                               _p(out.numpy()), _p(self.tw), 0.0, 0.0) == 0
 
     def exchange(self, dist, recv_part, send_part):

@@ -58,11 +58,7 @@ template <int N, int PSEL> static int run_half_p(const void* h0T, int f16, float
                         [&] { k_half_pass1<N, G::E1, G::P, true, G::dma, G::fpar>(h0T, descale, omT, inter, nyq, tw, lay, time, L, 0); });
     else emu_launch(G::half_grid1, G::half_threads1,
                     [&] { k_half_pass1<N, G::E1, G::P, false, G::dma, G::fpar>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L, 0); });
-    if (real2) {
-        if constexpr (G::real_threads2 % 16 == 0)
-            emu_launch(N, G::real_threads2, [&] { k_half_pass2_real<N, G::E, CHUNK_W, G::p2_group>(inter, out, tw, lay, nullptr); });
-        else return -7;
-    } else
+    if (real2) return -7;                               // (k_half_pass2_real reads the split geometry's column-major chunks)
     emu_launch(G::half_grid2, G::half_threads2,
                [&] { k_half_pass2<N, G::E2, CHUNK_W, G::R2h, G::p2_group, G::ppar>(inter, out, tw, lay); });
     return 0;
@@ -120,20 +116,38 @@ template <int N, int PSEL> static int run_tile_pass2(int world, int parts, const
     using G = Geo<N, PSEL>;
     if (!G::tile_supported(world, parts)) return -5;
     const InterLayout lay = G::tile_layout(world, parts);
-    if (real2) {
-        if constexpr (G::real_threads2 % 16 == 0)
-            emu_launch(N / world, G::real_threads2, [&] { k_half_pass2_real<N, G::E, CHUNK_W, G::p2_group, true>(recv, out, tw, lay, nullptr); });
-        else return -7;
-        return 0;
-    }
+    (void)real2;
     emu_launch((N / world) / G::R2h, G::half_threads2,
                [&] { k_half_pass2<N, G::E2, CHUNK_W, G::R2h, G::p2_group, G::ppar, true>(recv, out, tw, lay); });
     return 0;
 }
+// ... with the split geometry (what ocean_tile_pass1 / ocean_tile_pass2 launch at N >= 8192: k_half_pass1_split, k_half_pass2_real<SHARD>)
+template <int N, int PS> static int run_tile_split(int what, int rank, int world, int part, int parts, const void* h0T, int f16, float descale, const float* omT,
+                                                   c32* buf, c32* nyq, float4* out, const c32* tw, float time, float L) {
+    using G = Geo<N, PS>;
+    if constexpr (!G::can_split || G::real_threads2 % 16 != 0) return -7;
+    else {
+        if (!G::tile_supported(world, parts)) return -5;
+        const InterLayout lay = G::tile_layout(world, parts);
+        if (what == 1) {
+            const int groups = (N / 2 / world / parts) / G::P;
+            const int x_group0 = (rank * parts + part) * groups;
+            if (f16) emu_launch(groups, G::split_threads1, [&] { k_half_pass1_split<N, G::E1S, G::P, true, false>(h0T, descale, omT, buf, nyq, tw, lay, time, L, x_group0, nullptr); });
+            else emu_launch(groups, G::split_threads1, [&] { k_half_pass1_split<N, G::E1S, G::P, false, false>(h0T, 1.0f, omT, buf, nyq, tw, lay, time, L, x_group0, nullptr); });
+        } else {
+            emu_launch(N / world, G::real_threads2, [&] { k_half_pass2_real<N, G::E, CHUNK_W, G::p2_group, true>(buf, out, tw, lay, nullptr); });
+        }
+        return 0;
+    }
+}
 template <int N> static int run_tile(int what, int psel, int rank, int world, int part, int parts, const void* h0T, int f16, float descale, const float* omT,
                                      c32* buf, c32* nyq, float4* out, const c32* tw, float time, float L) {
-    const bool real2 = psel >= 100;
-    psel %= 100;
+    if (psel == 22) return run_tile_split<N, 2>(what, rank, world, part, parts, h0T, f16, descale, omT, buf, nyq, out, tw, time, L);
+    if (psel == 21) {
+        if constexpr (N >= 1024) return run_tile_split<N, 1>(what, rank, world, part, parts, h0T, f16, descale, omT, buf, nyq, out, tw, time, L);
+        else return -3;
+    }
+    const bool real2 = false;
     if (psel == 1) return what == 1 ? run_tile_pass1<N, 1>(rank, world, part, parts, h0T, f16, descale, omT, buf, nyq, tw, time, L) : run_tile_pass2<N, 1>(world, parts, buf, out, tw, real2);
     if (psel == 2) return what == 1 ? run_tile_pass1<N, 2>(rank, world, part, parts, h0T, f16, descale, omT, buf, nyq, tw, time, L) : run_tile_pass2<N, 2>(world, parts, buf, out, tw, real2);
     if constexpr (CHUNK_W % Geo<N, 0>::P != 0) return -4;

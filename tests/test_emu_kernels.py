@@ -107,7 +107,7 @@ def test_emu_split_line_geometry(n, ref_inputs):
     assert np.all(out[..., 3] == 0.0)
     plain, inter_p, _, _ = emu.frame_half(h0, om, 2.5, return_inter=True, P=2)
     for f in range(3):
-        a = emu.unpack_inter(inter, n, P, lay, f, columns=n // 2)
+        a = emu.unpack_inter(inter, n, P, lay, f, columns=n // 2, cmajor=True)
         b = emu.unpack_inter(inter_p, n, 2, lay, f, columns=n // 2)
         assert_parity(a, b, 5e-6, f"split intermediate field {f}")
 
@@ -127,7 +127,7 @@ def test_emu_split_one_column_per_workgroup(n):
         _, inter_p, _, _ = (None, None, None, None) if f else emu.frame_half(h0, om, 2.5, return_inter=True, P=2)
         if f == 0:
             plain = inter_p
-        assert_parity(emu.unpack_inter(inter, n, P, lay, f, columns=n // 2), emu.unpack_inter(plain, n, 2, lay, f, columns=n // 2), 5e-6,
+        assert_parity(emu.unpack_inter(inter, n, P, lay, f, columns=n // 2, cmajor=True), emu.unpack_inter(plain, n, 2, lay, f, columns=n // 2), 5e-6,
                       f"intermediate field {f}")
     if n == 1024:
         _, deq, _ = emu.quantize_f16(h0)

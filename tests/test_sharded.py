@@ -281,14 +281,15 @@ def test_fused_sharded_single_rank_and_loopback_in_the_emulation():
 
 
 def test_fused_sharded_real_output_rows_in_the_emulation():
-    """The sharded variant of the real-output pass 2 (k_half_pass2_real<SHARD>, what ocean_tile_pass2 launches at N >= 8192)
-    at a size the emulation can run: both ranks of a world-2 tile in one process, the exchange in 1 and 2 pieces."""
+    """The kernels ocean_tile_pass1 / ocean_tile_pass2 launch at N >= 8192 (k_half_pass1_split with a column-group offset,
+    k_half_pass2_real<SHARD>; column-major chunks) at a size the emulation can run: both ranks of a world-2 tile in one
+    process, the exchange in 1 and 2 pieces."""
     import emu
     n, t, world = 512, 0.75, 2
     h0, om = g.synth.make_inputs(n, seed=6)
     ref = oc.frame_f64(h0, om, t)
     for parts in (1, 2):
-        backs = [emu.EmuTileBackend(n, r, world, psel=2, parts=parts, real2=True) for r in range(world)]
+        backs = [emu.EmuTileBackend(n, r, world, psel=22, parts=parts) for r in range(world)]
         sends = [b.alloc_exchange() for b in backs]
         recvs = [b.alloc_exchange() for b in backs]
         outs = [b.alloc_out() for b in backs]
