@@ -23,9 +23,13 @@
 
 namespace ocean {
 
-// Fused kernels at N <= this take the base twiddle of every pass from v_sin/v_cos instead of the table (fft_core.hpp
-// base_twiddle; the reference evaluates cos/sin per butterfly, shader/fft_row.comp:32-33): the latency-bound sizes.
-constexpr int HWTW_MAX_N = 1024;
+// The fused kernels take the base twiddle of every pass from v_sin / v_cos instead of the table (fft_core.hpp base_twiddle;
+// the reference evaluates cos/sin per butterfly, shader/fft_row.comp:32-33): their workgroups run in lock-step phases, and a
+// dependent table read behind every barrier of a transform is exposed latency.  First the latency-bound sizes (round 3:
+// N <= 1024); measured again in round 4 after the other such reads were gone (r04_run28/29, one box each, two repetitions):
+// N = 2048 +2.5-3 % frames/s, 4096 +1.4 % (pass 2 89.2-89.5 -> 86.0-86.5 us), 8192 pass 1 -3 %, 16384 pass 2 -8 %.
+// (The staged kernels keep the table: they are the 1:1 restatement.)
+constexpr bool FUSED_HWTW = true;
 
 // shader/propagate.comp:6 -- `const float pi = 3.1415926;` (fp32 0x40490FDA)
 #define OCEAN_PI_F 3.1415926f
@@ -573,7 +577,7 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
             // ends in registers, X[j + e T], and every lane stores its 8-byte elements straight into the chunks (a
             // quarter of a chunk row each; the four column workgroups of a chunk column run on one XCD and the
             // cache-resident intermediate merges there).
-            fft_line<N, E, 1, true, (N <= HWTW_MAX_N)>(reg, jf, tw, lds_line);   // the threads of a line are consecutive lanes
+            fft_line<N, E, 1, true, FUSED_HWTW>(reg, jf, tw, lds_line);   // the threads of a line are consecutive lanes
             OCEAN_TL(2 + 2 * (FPAR ? f : ff));
             c32* dcol = inter + (size_t)f * lay.fs + (size_t)(X / CW) * lay.sx + (X % CW);
 #pragma unroll
@@ -584,7 +588,7 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
             OCEAN_TL(3 + 2 * (FPAR ? f : ff));
             continue;
         }
-        fft_line_to_lds<N, E, 1, true, (N <= HWTW_MAX_N)>(reg, jf, tw, lds_line);
+        fft_line_to_lds<N, E, 1, true, FUSED_HWTW>(reg, jf, tw, lds_line);
         OCEAN_TL(2 + 2 * (FPAR ? f : ff));
         // chunk row Y = i / CR + q * (2T / CR): the thread's part and the (wave-uniform, scalar) part of the address add
         // up because 2T / CR is a power of two > i / CR (no carry between them in chunk_row_offset)
@@ -670,9 +674,17 @@ k_half_pass1_split(const void* __restrict__ h0T, float descale, const float* __r
             for (int e = 0; e < E; ++e) reg[e] = cadd_i(reg[e], z[2 * e * TS]);   // + i * Sn
         }
         if (ff > 0) __syncthreads();
-        fft_line_to_lds<M, E, 2>(reg, jf, tw, lds_line);           // tw holds e^{2 pi i k / N}: stride 2 for length N/2
-        OCEAN_TL(2 + 2 * ff);
         const int tf = opaque_lane(tid);
+        // The combine's twiddles e^{2 pi i k / N}, k = k0 + q ROWS: ONE table read per field, in flight under the transform,
+        // the rest by the constants e^{2 pi i q ROWS / N} = e^{2 pi i q / 8} (a read per q behind the transform's last
+        // barrier: pass 1 401-407 -> 386-387 us at 8192, 1719-1916 -> 1643-1673 us at 16384, r04_run27).  Not with the 16-bit
+        // intermediate, whose kernel has no four registers left (12 spilled).
+        constexpr bool TWROT = !I16;
+        float4 w2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if constexpr (TWROT) w2 = *reinterpret_cast<const float4*>(tw + (CR * (tf / (2 * P)) + 2 * (tf & 1)));
+        // length N/2 inside an N-point context: twiddle stride 2
+        fft_line_to_lds<M, E, 2, false, FUSED_HWTW>(reg, jf, tw, lds_line);
+        OCEAN_TL(2 + 2 * ff);
         // The chunks of the split geometry are COLUMN-major inside (element (row r, column c) at c CR + r; SPLIT_CMAJOR):
         // a workgroup owns P < CW columns of every chunk, and its part of a chunk is then P * 32 contiguous bytes -- a thread
         // combines and stores two consecutive rows of one column (16 bytes), 2P adjacent lanes one piece -- instead of
@@ -690,8 +702,15 @@ k_half_pass1_split(const void* __restrict__ h0T, float descale, const float* __r
         for (int q0 = 0; q0 < M / ROWS; ++q0) {
             const int q = q0;
             const int k = CR * g + 2 * rp + q * ROWS;              // rows k, k + 1 and k + M, k + M + 1
-            const float4 w2 = *reinterpret_cast<const float4*>(tw + k);   // e^{2 pi i k / N}, e^{2 pi i (k + 1) / N}
-            const c32 wa = mk(w2.x, w2.y), wb = mk(w2.z, w2.w);
+            if constexpr (!TWROT) w2 = *reinterpret_cast<const float4*>(tw + k);   // e^{2 pi i k / N}, e^{2 pi i (k + 1) / N}
+            c32 wa = mk(w2.x, w2.y), wb = mk(w2.z, w2.w);
+            if constexpr (TWROT) {
+                static_assert(8 * ROWS == N, "the rotation constants are eighth roots");
+                constexpr float h = 0.70710678118654752f;
+                if (q == 1) { wa = vfma(yy(wa), mk(-h, h), xx(wa) * mk(h, h)); wb = vfma(yy(wb), mk(-h, h), xx(wb) * mk(h, h)); }        // e^{i pi/4}
+                if (q == 2) { wa = crot(wa); wb = crot(wb); }                                                                     // i
+                if (q == 3) { wa = vfma(yy(wa), mk(-h, -h), xx(wa) * mk(-h, h)); wb = vfma(yy(wb), mk(-h, -h), xx(wb) * mk(-h, h)); }   // e^{3 i pi/4}
+            }
             const int pk = lds_pad(k);                             // k is even: k + 1 has the same k >> 4
             const c32 ta = cmul_r(od[pk], wa, crot(wa)), tb = cmul_r(od[pk + 1], wb, crot(wb));
             const c32 ua = ev[pk], ub = ev[pk + 1];
@@ -864,7 +883,7 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
 #pragma unroll
         for (int e = 0; e < E; ++e) reg[e] = g[e * (T + T / 16)];
         __syncthreads();
-        fft_line<N, E, 1, true, (N <= HWTW_MAX_N)>(reg, jf, tw, lds_line);   // (ll, j): the threads of a row are consecutive lanes
+        fft_line<N, E, 1, true, FUSED_HWTW>(reg, jf, tw, lds_line);   // (ll, j): the threads of a row are consecutive lanes
         OCEAN_TL(2 + 3 * pass);
         if constexpr (PPAR) {                                      // group 0 hands its row of heights to group 1
             if (pass == 0) {
@@ -983,6 +1002,7 @@ k_half_pass2_real(const c32* __restrict__ inter, float4* __restrict__ out, const
         }
     };
     float keep_h[2 * E], keep_x[2 * E];
+    const c32 wj = tw[tid];                                        // e^{2 pi i j / N}: once, for the three fields
     const float sgn = (((tid + y) & 1) == 0) ? -0.5f : 0.5f;       // correction.comp:29 and the 1/2 of S(F); T is even
     float4* orow = out + (size_t)y * N;
     // one field: pair, transform, take the store mapping.  `after_pairing` issues the loads that replace raw's registers.
@@ -996,13 +1016,12 @@ k_half_pass2_real(const c32* __restrict__ inter, float4* __restrict__ out, const
             else lo[e * K1] = raw[e];
         }
         line_sync<T>();
-        const c32 wj = tw[jf];                                     // e^{2 pi i j / N}
         c32 reg[E];
         real_row_inputs<E>(lo, line + lds_pad(M - jf), K1, jf == 0, crot(wj), -wj, reg, std::make_integer_sequence<int, E>{});
         line_sync<T>();                                            // the mirrored reads are done before the transform scatters
         after_pairing();
         if (it == 0) OCEAN_TL(1);
-        fft_line_to_lds<M, E, 2, true>(reg, jf, tw, line);
+        fft_line_to_lds<M, E, 2, true, FUSED_HWTW>(reg, jf, tw, line);
         if (it == 2) OCEAN_TL(5);
         const float* src = reinterpret_cast<const float*>(line + lds_pad(jf >> 1)) + (jf & 1);
         if (it == 0) {
