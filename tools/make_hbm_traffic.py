@@ -22,8 +22,9 @@ def counters(d, counter):
                     continue
                 name = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("ocean::", "")
                 short = name.split("<")[0]
-                if short.endswith("_split"):
-                    short = short[:-len("_split")]
+                for suffix in ("_split", "_real"):                 # the N >= 8192 kernels of the same two passes
+                    if short.endswith(suffix):
+                        short = short[:-len(suffix)]
                 a = acc.setdefault(short, [0.0, 0, name])
                 a[0] += float(row["Counter_Value"])
                 a[1] += 1
