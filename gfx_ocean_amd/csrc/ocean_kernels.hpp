@@ -536,11 +536,6 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
     const uint32_t x = (uint32_t)(Xg * P + c);                     // kx in [0, N/2)
     const uint32_t x2 = (N - x) & (N - 1);
     c32 A[E], B[E];
-#ifdef OCEAN_X_STAGGER
-    if constexpr (N == 2048) {
-        if ((int)blockIdx.x >= (int)gridDim.x / 2) { for (int i = 0; i < OCEAN_X_STAGGER; ++i) __builtin_amdgcn_s_sleep(32); }
-    }
-#endif
     OCEAN_TL(0);
     if constexpr (DMA) {
         static_assert(DmaRing<N, E, P, H16, 1>::bytes <= 160 * 1024, "the DMA ring fits the LDS");
