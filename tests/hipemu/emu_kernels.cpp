@@ -52,26 +52,25 @@ template <int N> static int run_fft_lines(int col, c32* data, const c32* tw) {
     return 0;
 }
 template <int N, int PSEL> static int run_half_p(const void* h0T, int f16, float descale, const float* omT, c32* inter, c32* nyq,
-                                                 float4* out, const c32* tw, InterLayout lay, float time, float L, bool real2) {
+                                                 float4* out, const c32* tw, InterLayout lay, float time, float L) {
     using G = Geo<N, PSEL>;
     if (f16) emu_launch(G::half_grid1, G::half_threads1,
                         [&] { k_half_pass1<N, G::E1, G::P, true, G::dma, G::fpar>(h0T, descale, omT, inter, nyq, tw, lay, time, L, 0); });
     else emu_launch(G::half_grid1, G::half_threads1,
                     [&] { k_half_pass1<N, G::E1, G::P, false, G::dma, G::fpar>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L, 0); });
-    if (real2) return -7;                               // (k_half_pass2_real reads the split geometry's column-major chunks)
     emu_launch(G::half_grid2, G::half_threads2,
                [&] { k_half_pass2<N, G::E2, CHUNK_W, G::R2h, G::p2_group, G::ppar>(inter, out, tw, lay); });
     return 0;
 }
 template <int N, bool I16, int PS = 2> static int run_half_split(const void* h0T, int f16, float descale, const float* omT, c32* inter, c32* nyq,
-                                                     float4* out, const c32* tw, InterLayout lay, float time, float L, float* scales, bool real2) {
+                                                     float4* out, const c32* tw, InterLayout lay, float time, float L, float* scales) {
     using G = Geo<N, PS>;
     static_assert(G::can_split, "split geometry");
     if (f16) emu_launch(G::half_grid1, G::split_threads1,
                         [&] { k_half_pass1_split<N, G::E1S, G::P, true, I16>(h0T, descale, omT, inter, nyq, tw, lay, time, L, 0, scales); });
     else emu_launch(G::half_grid1, G::split_threads1,
                     [&] { k_half_pass1_split<N, G::E1S, G::P, false, I16>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L, 0, scales); });
-    (void)real2;                                        // the split geometry's pass 2 IS the real-output kernel (N >= 8192 in the product)
+    // the split geometry's pass 2 is the real-output kernel, which reads its column-major chunks (N >= 8192 in the product)
     if constexpr (G::real_threads2 % 16 == 0)
         emu_launch(N, G::real_threads2, [&] { k_half_pass2_real<N, G::E, CHUNK_W, G::p2_group, false, I16>(inter, out, tw, lay, scales); });
     else return -7;
@@ -79,22 +78,20 @@ template <int N, bool I16, int PS = 2> static int run_half_split(const void* h0T
 }
 template <int N> static int run_half(int psel, const void* h0T, int f16, float descale, const float* omT, c32* inter, c32* nyq,
                                      float4* out, const c32* tw, InterLayout lay, float time, float L, float* scales) {
-    const bool real2 = psel >= 100;                     // + 100: pass 2 = k_half_pass2_real
-    psel %= 100;
     if (psel == 21) {                                   // P = 1 with the split geometry (the N = 16384 kernels: one column per workgroup)
-        if constexpr (N >= 1024) return run_half_split<N, false, 1>(h0T, f16, descale, omT, inter, nyq, out, tw, lay, time, L, nullptr, real2);   // (whole waves)
+        if constexpr (N >= 1024) return run_half_split<N, false, 1>(h0T, f16, descale, omT, inter, nyq, out, tw, lay, time, L, nullptr);   // (whole waves)
         else return -3;
     }
     if (psel == 22 || psel == 23) {                     // P = 2 with the split geometry; 23: + the 16-bit intermediate
         if constexpr (N >= 512) {
-            if (psel == 23) return scales ? run_half_split<N, true>(h0T, f16, descale, omT, inter, nyq, out, tw, lay, time, L, scales, real2) : -6;
-            return run_half_split<N, false>(h0T, f16, descale, omT, inter, nyq, out, tw, lay, time, L, nullptr, real2);
+            if (psel == 23) return scales ? run_half_split<N, true>(h0T, f16, descale, omT, inter, nyq, out, tw, lay, time, L, scales) : -6;
+            return run_half_split<N, false>(h0T, f16, descale, omT, inter, nyq, out, tw, lay, time, L, nullptr);
         } else return -3;
     }
-    if (psel == 2) return run_half_p<N, 2>(h0T, f16, descale, omT, inter, nyq, out, tw, lay, time, L, real2);
-    if (psel == 1) return run_half_p<N, 1>(h0T, f16, descale, omT, inter, nyq, out, tw, lay, time, L, real2);
+    if (psel == 2) return run_half_p<N, 2>(h0T, f16, descale, omT, inter, nyq, out, tw, lay, time, L);
+    if (psel == 1) return run_half_p<N, 1>(h0T, f16, descale, omT, inter, nyq, out, tw, lay, time, L);
     if constexpr (CHUNK_W % Geo<N, 0>::P != 0) return -4;
-    else return run_half_p<N, 0>(h0T, f16, descale, omT, inter, nyq, out, tw, lay, time, L, real2);
+    else return run_half_p<N, 0>(h0T, f16, descale, omT, inter, nyq, out, tw, lay, time, L);
 }
 
 // one tile sharded over `world` ranks, second generation (ocean_tile_pass1 / ocean_tile_pass2 of csrc/ocean_api.hip: same
@@ -112,11 +109,10 @@ template <int N, int PSEL> static int run_tile_pass1(int rank, int world, int pa
                     [&] { k_half_pass1<N, G::E1, G::P, false, G::dma, G::fpar>(h0T, 1.0f, omT, send, nyq, tw, lay, time, L, x_group0); });
     return 0;
 }
-template <int N, int PSEL> static int run_tile_pass2(int world, int parts, const c32* recv, float4* out, const c32* tw, bool real2) {
+template <int N, int PSEL> static int run_tile_pass2(int world, int parts, const c32* recv, float4* out, const c32* tw) {
     using G = Geo<N, PSEL>;
     if (!G::tile_supported(world, parts)) return -5;
     const InterLayout lay = G::tile_layout(world, parts);
-    (void)real2;
     emu_launch((N / world) / G::R2h, G::half_threads2,
                [&] { k_half_pass2<N, G::E2, CHUNK_W, G::R2h, G::p2_group, G::ppar, true>(recv, out, tw, lay); });
     return 0;
@@ -147,11 +143,10 @@ template <int N> static int run_tile(int what, int psel, int rank, int world, in
         if constexpr (N >= 1024) return run_tile_split<N, 1>(what, rank, world, part, parts, h0T, f16, descale, omT, buf, nyq, out, tw, time, L);
         else return -3;
     }
-    const bool real2 = false;
-    if (psel == 1) return what == 1 ? run_tile_pass1<N, 1>(rank, world, part, parts, h0T, f16, descale, omT, buf, nyq, tw, time, L) : run_tile_pass2<N, 1>(world, parts, buf, out, tw, real2);
-    if (psel == 2) return what == 1 ? run_tile_pass1<N, 2>(rank, world, part, parts, h0T, f16, descale, omT, buf, nyq, tw, time, L) : run_tile_pass2<N, 2>(world, parts, buf, out, tw, real2);
+    if (psel == 1) return what == 1 ? run_tile_pass1<N, 1>(rank, world, part, parts, h0T, f16, descale, omT, buf, nyq, tw, time, L) : run_tile_pass2<N, 1>(world, parts, buf, out, tw);
+    if (psel == 2) return what == 1 ? run_tile_pass1<N, 2>(rank, world, part, parts, h0T, f16, descale, omT, buf, nyq, tw, time, L) : run_tile_pass2<N, 2>(world, parts, buf, out, tw);
     if constexpr (CHUNK_W % Geo<N, 0>::P != 0) return -4;
-    else return what == 1 ? run_tile_pass1<N, 0>(rank, world, part, parts, h0T, f16, descale, omT, buf, nyq, tw, time, L) : run_tile_pass2<N, 0>(world, parts, buf, out, tw, real2);
+    else return what == 1 ? run_tile_pass1<N, 0>(rank, world, part, parts, h0T, f16, descale, omT, buf, nyq, tw, time, L) : run_tile_pass2<N, 0>(world, parts, buf, out, tw);
 }
 
 // staged path with the chunked hand-off: rows (natural -> chunked), cols (in place, chunked), correction / un-chunk
