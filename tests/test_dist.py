@@ -208,9 +208,9 @@ def test_algorithmic_bytes_do_not_exceed_the_committed_counters():
             k = rec["kernels"][name]
             alg = moved[bench.pass_of(name)] * n * n
             assert alg <= k["hbm_bytes"] * 1.005, (path, name, alg, k["hbm_bytes"])
-            # (N = 16384, one column per pass-1 workgroup: half of what a workgroup stages are its left neighbour's lines --
-            # 1.09x with the column-major chunks of r04_run25; with 8-byte store pieces it was 1.28x)
-            waste_ok = 0.9
+            # N = 16384, one column per pass-1 workgroup: half of what a workgroup stages are its left neighbour's lines, which
+            # the L2 serves most but not all of the time -- 1.09-1.12x (r04_run31 / 37; with 8-byte store pieces it was 1.28x)
+            waste_ok = 0.9 if n <= 8192 else 0.85
             assert alg >= waste_ok * k["hbm_bytes"], (path, name, alg, k["hbm_bytes"])
             seen += 1
     assert seen >= 2
