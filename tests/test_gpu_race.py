@@ -96,11 +96,11 @@ def test_create_destroy_soak():
 
 
 _JITTER_WORKER = r"""
-import json, sys
+import json, os, sys
 sys.path.insert(0, sys.argv[1])
 import gfx_ocean_amd as g
 res = {}
-for n in (256, 512, 1024, 2048, 4096, 8192):
+for n in [int(v) for v in os.environ.get("OCEAN_RACE_SIZES", "256,512,1024,2048,4096,8192").split(",")]:
     for f16 in (False, True):
         h0, om = g.synth.make_inputs(n, seed=n + 1)
         r = g.OceanRenderer(n)
