@@ -675,13 +675,14 @@ k_half_pass1_split(const void* __restrict__ h0T, float descale, const float* __r
         }
         if (ff > 0) __syncthreads();
         const int tf = opaque_lane(tid);
-        // The combine's twiddles e^{2 pi i k / N}, k = k0 + q ROWS: ONE table read per field, in flight under the transform,
-        // the rest by the constants e^{2 pi i q ROWS / N} = e^{2 pi i q / 8} (a read per q behind the transform's last
+        // The combine's twiddles e^{2 pi i k / N}, k = k0 + q ROWS (+ 1): ONE table read per field, in flight under the transform,
+        // the rest by tw[1] and the constants e^{2 pi i q ROWS / N} = e^{2 pi i q / 8} (a read per q behind the transform's last
         // barrier: pass 1 401-407 -> 386-387 us at 8192, 1719-1916 -> 1643-1673 us at 16384, r04_run27).  Not with the 16-bit
-        // intermediate, whose kernel has no four registers left (12 spilled).
+        // intermediate, whose kernel has no two registers left (8 spilled).
         constexpr bool TWROT = !I16;
         float4 w2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if constexpr (TWROT) w2 = *reinterpret_cast<const float4*>(tw + (CR * (tf / (2 * P)) + 2 * (tf & 1)));
+        c32 w0 = mk(0.0f, 0.0f);                                   // e^{2 pi i k0 / N}; its neighbour k0 + 1 by tw[1] (a scalar)
+        if constexpr (TWROT) w0 = tw[CR * (tf / (2 * P)) + 2 * (tf & 1)];
         // length N/2 inside an N-point context: twiddle stride 2
         fft_line_to_lds<M, E, 2, false, FUSED_HWTW>(reg, jf, tw, lds_line);
         OCEAN_TL(2 + 2 * ff);
@@ -703,7 +704,7 @@ k_half_pass1_split(const void* __restrict__ h0T, float descale, const float* __r
             const int q = q0;
             const int k = CR * g + 2 * rp + q * ROWS;              // rows k, k + 1 and k + M, k + M + 1
             if constexpr (!TWROT) w2 = *reinterpret_cast<const float4*>(tw + k);   // e^{2 pi i k / N}, e^{2 pi i (k + 1) / N}
-            c32 wa = mk(w2.x, w2.y), wb = mk(w2.z, w2.w);
+            c32 wa = TWROT ? w0 : mk(w2.x, w2.y), wb = TWROT ? cmul(w0, tw[1]) : mk(w2.z, w2.w);
             if constexpr (TWROT) {
                 static_assert(8 * ROWS == N, "the rotation constants are eighth roots");
                 constexpr float h = 0.70710678118654752f;
