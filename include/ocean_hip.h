@@ -146,7 +146,9 @@ uint32_t ocean_quirks(const OceanContext* ctx);
  * parity figure of this library refers to).  OCEAN_INTER_BFP16 is SURVEY 8d's "B_frame16" for BASELINE config 5: int16
  * (re, im) mantissas with one power-of-two scale per block of 64 rows x 2 columns in a side array -- 12 instead of
  * 24 B/texel through the intermediate; 2.7-3.1e-5 normalised max against the fp32 intermediate at N = 8192 (tolerance
- * 1e-4; tools/inter16_numerics.py).  Opt-in, never the default; N = 8192 only (OCEAN_E_UNSUPPORTED_N otherwise). */
+ * 1e-4; tools/inter16_numerics.py).  Opt-in, never the default; N = 8192 only (OCEAN_E_UNSUPPORTED_N otherwise).
+ * Halves the intermediate's footprint (403 instead of 805 MB); since the real-output row pass (ABI unchanged) it is no
+ * longer faster than the default: 1327 against 1390-1425 frames/s with the fp16-stored spectrum. */
 #define OCEAN_INTER_F32 0
 #define OCEAN_INTER_BFP16 1
 int32_t ocean_set_intermediate(OceanContext* ctx, int32_t mode);
