@@ -656,8 +656,15 @@ int32_t ocean_normals(OceanContext* ctx, int32_t source_channel, void* stream) {
     DeviceGuard guard(ctx->device);
     const size_t n2 = (size_t)ctx->n * ctx->n;
     if (!ctx->normals) HIP_TRY(ctx, hipMalloc((void**)&ctx->normals, n2 * sizeof(float4)));
-    hipLaunchKernelGGL(k_normals, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, pick(ctx, stream), ctx->out,
-                       ctx->normals, ctx->n, source_channel);
+    const int rows = normals_rows(ctx->n);
+    const dim3 grid((unsigned)((ctx->n / 256) * (ctx->n / rows)));
+    hipStream_t s = pick(ctx, stream);
+    switch (rows) {
+        case 1: hipLaunchKernelGGL(k_normals<1>, grid, dim3(256), 0, s, ctx->out, ctx->normals, ctx->n, source_channel); break;
+        case 2: hipLaunchKernelGGL(k_normals<2>, grid, dim3(256), 0, s, ctx->out, ctx->normals, ctx->n, source_channel); break;
+        case 4: hipLaunchKernelGGL(k_normals<4>, grid, dim3(256), 0, s, ctx->out, ctx->normals, ctx->n, source_channel); break;
+        default: hipLaunchKernelGGL(k_normals<8>, grid, dim3(256), 0, s, ctx->out, ctx->normals, ctx->n, source_channel); break;
+    }
     return check_launch(ctx, "k_normals launch");
 }
 int32_t ocean_read_normals(OceanContext* ctx, float* host_xyz0) {

@@ -117,26 +117,40 @@ k_correct(const c32* __restrict__ height, const c32* __restrict__ disp_x, const 
 // texel centres: finite differences of one channel of the displacement map with Tile wrap
 // (src/render.rs:398), height_scale 180 (:19), diff = 2/N (the shader's literal 512 -> N).
 // channel 0 = disp_x is what the reference differentiates (quirk Q5); 1 = height is the
-// physically meant source.  One thread per texel; the four neighbours are L1/L2 hits.
+// physically meant source.
+// A workgroup owns 256 columns x ROWS rows; a thread walks down its column with the rows above and below in registers,
+// so a row is fetched once per workgroup (plus two halo rows per ROWS) instead of three times by three workgroups, and
+// the x neighbours are hits in the lines the centre load brought.  Streamed stores.  grid = (N / 256) * (N / ROWS);
+// N >= 256.  Against one thread per texel (r04_run44/45): N = 4096 112.5 -> 88.4 us (6.1 TB/s on the 32 B/texel it moves),
+// 2048 27.0 -> 25.0 us, 8192 395 us.  ROWS per size (measured 4 / 8 / 16; the small sizes need the workgroups):
+constexpr int normals_rows(int n) { return (n >= 8192) ? 8 : ((n >= 2048) ? 4 : ((n >= 1024) ? 2 : 1)); }
+template <int ROWS>
 __global__ void __launch_bounds__(256)
 k_normals(const float4* __restrict__ rgba, float4* __restrict__ normals, int n, int channel) {
     const uint32_t un = (uint32_t)n;
-    const uint32_t index = blockIdx.x * 256u + threadIdx.x;
-    if (index >= un * un) return;
-    const uint32_t x = index % un, y = index / un;
-    const uint32_t xm = (x + un - 1u) % un, xp = (x + 1u) % un, ym = (y + un - 1u) % un, yp = (y + 1u) % un;
+    const uint32_t col_blocks = un / 256u;
+    const uint32_t x = (blockIdx.x % col_blocks) * 256u + threadIdx.x, y0 = (blockIdx.x / col_blocks) * ROWS;
+    const uint32_t xm = (x + un - 1u) % un, xp = (x + 1u) % un;
     const float* f = reinterpret_cast<const float*>(rgba) + channel;
-    const float x0 = f[((size_t)y * un + xm) * 4], x1 = f[((size_t)y * un + xp) * 4];
-    const float z0 = f[((size_t)ym * un + x) * 4], z1 = f[((size_t)yp * un + x) * 4];
     const float d = 2.0f / (float)n;                               // :52
-    // na = normalize(-d, (x1-x0)/180, 0), nb = normalize(0, (z1-z0)/180, d)      :64-65
-    const float ay = (x1 - x0) / 180.0f, by = (z1 - z0) / 180.0f;
-    const float la = sqrtf(d * d + ay * ay), lb = sqrtf(by * by + d * d);
-    const float nax = -d / la, nay = ay / la, nby = by / lb, nbz = d / lb;
-    // cross(na, nb) with na.z = nb.x = 0                                           :66
-    const float cx = nay * nbz, cy = -nax * nbz, cz = nax * nby;
-    const float lc = sqrtf(cx * cx + cy * cy + cz * cz);
-    normals[index] = make_float4(cx / lc, cy / lc, cz / lc, 0.0f);
+    float above = f[((size_t)((y0 + un - 1u) % un) * un + x) * 4], centre = f[((size_t)y0 * un + x) * 4];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const uint32_t y = y0 + (uint32_t)r;
+        const float below = f[((size_t)((y + 1u) % un) * un + x) * 4];
+        const float x0 = f[((size_t)y * un + xm) * 4], x1 = f[((size_t)y * un + xp) * 4];
+        const float z0 = above, z1 = below;
+        // na = normalize(-d, (x1-x0)/180, 0), nb = normalize(0, (z1-z0)/180, d)      :64-65
+        const float ay = (x1 - x0) / 180.0f, by = (z1 - z0) / 180.0f;
+        const float la = sqrtf(d * d + ay * ay), lb = sqrtf(by * by + d * d);
+        const float nax = -d / la, nay = ay / la, nby = by / lb, nbz = d / lb;
+        // cross(na, nb) with na.z = nb.x = 0                                           :66
+        const float cx = nay * nbz, cy = -nax * nbz, cz = nax * nby;
+        const float lc = sqrtf(cx * cx + cy * cy + cz * cz);
+        store_float4_nt(normals + (size_t)y * un + x, make_float4(cx / lc, cy / lc, cz / lc, 0.0f));
+        above = centre;
+        centre = below;
+    }
 }
 
 // SURVEY 8f #2 -- the vertex stage's consumer of the map (shader/ocean.vert:21-25) as a compute kernel: the

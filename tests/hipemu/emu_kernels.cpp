@@ -266,8 +266,12 @@ int emu_positions(int n, const float* rgba, float* positions, int verts, float o
     return 0;
 }
 int emu_normals(int n, const float* rgba, float* normals, int channel) {
-    const int grid = (n * n + 255) / 256;
-    emu_launch(grid, 256, [&] { k_normals((const float4*)rgba, (float4*)normals, n, channel); });
+    const int rows = normals_rows(n);                   // as ocean_normals of csrc/ocean_api.hip
+    const int grid = (n / 256) * (n / rows);
+    if (rows == 1) emu_launch(grid, 256, [&] { k_normals<1>((const float4*)rgba, (float4*)normals, n, channel); });
+    else if (rows == 2) emu_launch(grid, 256, [&] { k_normals<2>((const float4*)rgba, (float4*)normals, n, channel); });
+    else if (rows == 4) emu_launch(grid, 256, [&] { k_normals<4>((const float4*)rgba, (float4*)normals, n, channel); });
+    else emu_launch(grid, 256, [&] { k_normals<8>((const float4*)rgba, (float4*)normals, n, channel); });
     return 0;
 }
 int emu_propagate(int n, const float* h0, const float* omega, float* h, float* dx, float* dz, float time, float L, unsigned quirks) {
