@@ -311,7 +311,7 @@ def test_linearity_and_impulse_1024():
         r.dispose()
 
 
-@pytest.mark.parametrize("n,channel", [(512, 0), (512, 1), (2048, 0), (2048, 1)])
+@pytest.mark.parametrize("n,channel", [(512, 0), (512, 1), (1024, 0), (2048, 0), (2048, 1), (8192, 1)])   # rows per workgroup: 1, 2, 4, 8
 def test_normal_field(r512, ref_inputs, n, channel):
     """normals of the displacement map (shader/ocean.frag:50-66, quirk Q5 for channel 0) at the
     reference's size and at BASELINE config 3's (N = 2048: height + displacement + normal)."""
@@ -331,7 +331,7 @@ def test_normal_field(r512, ref_inputs, n, channel):
         # and end to end against the fp64 oracle of the whole path: normals are O(1), tolerance absolute;
         # d(normal)/d(field) ~ N/360, so a 1e-6 field error becomes ~1e-4 at 512 and ~5e-4 at 2048
         ref64 = oc.normals_f64(oc.frame_f64(h0, om, 2.0), channel)
-        assert np.abs(got[..., :3] - ref64[..., :3]).max() <= (1e-3 if n == 512 else 4e-3)
+        assert np.abs(got[..., :3] - ref64[..., :3]).max() <= (1e-3 if n == 512 else 4e-3) * max(1, n // 2048)
         assert np.allclose(np.linalg.norm(got[..., :3], axis=-1), 1.0, atol=1e-5)
         assert np.all(got[..., 3] == 0.0)
     finally:
