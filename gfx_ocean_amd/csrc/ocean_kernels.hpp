@@ -927,7 +927,7 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
 // a thread keeps 2E reals of two fields until the third arrives, which is what the 128-VGPR budget allows.  Shipped at
 // N >= 8192 (Launch<N>::REAL2 with the measurements; rows of 128 or 64 threads at N <= 4096 are slower than k_half_pass2).
 //   thread j holds X[j + e T] (T = M / E): its partner M - j - e T is element E-1-e of thread T - j -- one LDS round
-//   trip (write own, read mirrored); e^{2 pi i (j + e T)/N} = tw[j] * e^{2 pi i e/(2E)}: one table entry per thread,
+//   trip (write own, read own and mirrored back); e^{2 pi i (j + e T)/N} = tw[j] * e^{2 pi i e/(2E)}: one table entry per thread,
 //   the rest compile-time constants;
 //   the transform's last pass lands in LDS (fft_line_to_lds), from where thread t takes texels t + s T, s < 2E (the
 //   float (t & 1) of element (t >> 1) + s T/2): a wave's store instruction writes one contiguous KiB of the row, as
