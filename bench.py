@@ -43,10 +43,22 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s me
 #   pass2: read 12, write RGBA32F 16
 # (Round 3 priced every N at 10 B of h0: at 8192 the "algorithmic" bytes then EXCEEDED the counted ones, VERDICT r03 weak #2;
 #  tests/test_dist.py checks algorithmic <= counted against every committed PMC file.)
-def moved_bytes_per_texel(n, spectrum="f32", intermediate="f32"):
+#   with the normal field (--normals, BASELINE config 3): pass 2 also writes the source channel as a dense fp32 plane (+4), and
+#   the normal-field kernel reads that plane (4) and writes float4 normals (16): 20 moved; its ALGORITHMIC minimum -- what
+#   `frac` of that kernel is priced on -- is 4 read + 12 written (NORMALS_ALGORITHMIC_BYTES_PER_TEXEL)
+def moved_bytes_per_texel(n, spectrum="f32", intermediate="f32", normals=False):
     h0 = (8.0 if n >= 4096 else 10.0) * (0.5 if spectrum == "f16" else 1.0)
     inter = 6.0 if intermediate == "bfp16" else 12.0     # bfp16 (opt-in, N = 8192): int16 pairs (+ 3 MB of block scales, not counted)
-    return {"pass1": h0 + 4.0 + inter, "pass2": inter + 16.0}
+    moved = {"pass1": h0 + 4.0 + inter, "pass2": inter + 16.0}
+    if normals:
+        moved["pass2"] += 4.0
+        moved["normals"] = 20.0
+    return moved
+
+
+NORMALS_ALGORITHMIC_BYTES_PER_TEXEL = 16.0   # 4 R (one channel) + 12 W (x, y, z)
+NORMALS_CONTRACT_BYTES_PER_TEXEL = 32.0      # "a cheap 5th streaming kernel: +16 B read, +12/16 B write per texel"
+NORMALS_CHANNELS = {"disp_x": 0, "height": 1, "disp_z": 2}   # disp_x = what the reference differentiates (quirk Q5)
 
 
 # The contract accounting of SURVEY.md 8d (three complex 2-D transforms per frame, B_frame = 76 N^2; 72 N^2 with
@@ -58,7 +70,7 @@ CONTRACT16_BYTES_PER_TEXEL = {"f32": {"pass1": 24.0, "pass2": 28.0}, "f16": {"pa
 
 
 def pass_of(kernel_name):
-    return "pass1" if "pass1" in kernel_name else "pass2"
+    return "pass1" if "pass1" in kernel_name else ("normals" if "normals" in kernel_name else "pass2")
 
 
 def aggregate(values_ms, n_gpus, steps):
@@ -68,11 +80,15 @@ def aggregate(values_ms, n_gpus, steps):
     return {"ms_per_step": ms_per_step, "value": n_gpus * 1000.0 / ms_per_step}
 
 
-def measured_traffic(n, kernel_name, spectrum="f32", intermediate="f32"):
+def traffic_suffix(spectrum="f32", intermediate="f32", normals=False):
+    return ("" if spectrum == "f32" else "_f16") + ("" if intermediate == "f32" else "_bfp16") + ("_normals" if normals else "")
+
+
+def measured_traffic(n, kernel_name, spectrum="f32", intermediate="f32", normals=False):
     """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and
     WRITE_SIZE are collected in separate runs of this same command, never inside the timed bench;
     gfx950 correction 2*FETCH_SIZE + WRITE_SIZE -- DESIGN.md 7).  None if no pass exists for this N."""
-    suffix = ("" if spectrum == "f32" else "_f16") + ("" if intermediate == "f32" else "_bfp16")
+    suffix = traffic_suffix(spectrum, intermediate, normals)
     path = os.path.join(ROOT, "profiles", f"hbm_traffic_n{n}{suffix}.json")
     try:
         with open(path) as f:
@@ -83,10 +99,10 @@ def measured_traffic(n, kernel_name, spectrum="f32", intermediate="f32"):
     return v["hbm_bytes"] if v else None
 
 
-def traffic_source(n, spectrum="f32", intermediate="f32"):
+def traffic_source(n, spectrum="f32", intermediate="f32", normals=False):
     """Where `roofline.traffic` comes from: never from the timed run (counters perturb timing and need rocprofv3
     around the process) but from a committed PMC pass of this same command."""
-    suffix = ("" if spectrum == "f32" else "_f16") + ("" if intermediate == "f32" else "_bfp16")
+    suffix = traffic_suffix(spectrum, intermediate, normals)
     rel = os.path.join("profiles", f"hbm_traffic_n{n}{suffix}.json")
     try:
         with open(os.path.join(ROOT, rel)) as f:
@@ -380,6 +396,10 @@ def main():
     ap.add_argument("--intermediate", choices=("f32", "bfp16"), default="f32",
                     help="precision of the intermediate between the two launches: f32 (default, what every parity figure refers to) or "
                          "bfp16 (opt-in, N = 8192: int16 mantissas + one power-of-two scale per 64 x 2 block; ~3e-5 normalised max)")
+    ap.add_argument("--normals", choices=("off",) + tuple(NORMALS_CHANNELS), default="off",
+                    help="BASELINE config 3 (\"height + displacement + normal\"): every frame is followed, inside the timed region, by the "
+                         "normal field of the finished map (shader/ocean.frag:50-66 at texel centres) differentiated from this channel; "
+                         "disp_x is what the reference differentiates (quirk Q5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", dest="gather", action="store_true", default=None,
                     help="time frames followed by an RCCL gather of every tile's RGBA map to rank 0 (BASELINE config 4; "
@@ -464,6 +484,9 @@ def main():
     dev.upload_spectrum(h0, omega, spectrum_fp16=(args.spectrum == "f16"))
     if args.intermediate == "bfp16":
         dev.set_intermediate(g.INTER_BFP16)
+    with_normals = args.normals != "off"
+    if with_normals:
+        dev.set_frame_normals(NORMALS_CHANNELS[args.normals])       # from here on a frame is three launches: pass 1, pass 2 (+ plane), normals
 
     def barrier():
         dev.sync()
@@ -492,12 +515,15 @@ def main():
     # drop between such frames and pass 1 read 94-100 us where the frame loop -- and rocprofv3's steady-state average of the
     # same command -- has 87-90 (r04_run19/20); the same synchronisations also slowed the timed region that followed.]
     per_batch = 10
-    dist_frames = max(args.steps, args.distribution_frames, args.profile_frames)
-    batch_ms = dev.time_frame_batches(max(2, dist_frames // per_batch), per_batch)
-    p1_ms, p2_ms, _ = dev.frame_times(dist_frames)
+    dist_frames = min(4096, max(args.steps, args.distribution_frames, args.profile_frames))   # (the C API's bound on both loops)
+    batch_ms = dev.time_frame_batches(min(4096, max(2, dist_frames // per_batch)), per_batch)
+    p1_ms, p2_ms, nrm_ms, _ = dev.frame_times_ex(dist_frames)
     acc = {"k_half_pass1": sum(p1_ms) / len(p1_ms), "k_half_pass2": sum(p2_ms) / len(p2_ms)}
     spread = {"frames": len(batch_ms) * per_batch, "frames_per_batch": per_batch, "frame": percentiles([b / per_batch for b in batch_ms]),
               "pass1": percentiles(p1_ms), "pass2": percentiles(p2_ms)}
+    if with_normals:
+        acc["k_normals_plane"] = sum(nrm_ms) / len(nrm_ms)
+        spread["normals"] = percentiles(nrm_ms)
 
     if dist is not None:
         t = torch.tensor([wall_ms], dtype=torch.float64, device="cuda")
@@ -507,27 +533,38 @@ def main():
         all_ms = [wall_ms]
     agg = aggregate(all_ms, n_gpus, args.steps)
 
-    moved, contract = moved_bytes_per_texel(n, args.spectrum, args.intermediate), CONTRACT_BYTES_PER_TEXEL[args.spectrum]
+    moved, contract = moved_bytes_per_texel(n, args.spectrum, args.intermediate, with_normals), dict(CONTRACT_BYTES_PER_TEXEL[args.spectrum])
     if args.intermediate == "bfp16":
-        contract = CONTRACT16_BYTES_PER_TEXEL[args.spectrum]
+        contract = dict(CONTRACT16_BYTES_PER_TEXEL[args.spectrum])
+    if with_normals:
+        contract["normals"] = NORMALS_CONTRACT_BYTES_PER_TEXEL
     kernels = []
     for name, avg_ms in acc.items():
         b = moved[pass_of(name)] * n * n
         cb = contract[pass_of(name)] * n * n
         # `name` is the pass; the template rocprofv3 lists for it at this size (Launch<N> in csrc/ocean_api.hip)
-        device_kernel = name + (("_split" if name.endswith("1") else "_real") if n > 4096 else "")
-        kernels.append({"name": name, "device_kernel": device_kernel, "avg_ms": avg_ms, "algorithmic_bytes": b, "GBps": b / avg_ms / 1e6,
-                        "frac": b / avg_ms / 1e6 / HBM_PEAK_GBS, "contract_bytes": cb, "contract_GBps": cb / avg_ms / 1e6,
-                        "contract_frac": cb / avg_ms / 1e6 / HBM_PEAK_GBS, "traffic": measured_traffic(n, name, args.spectrum, args.intermediate)})
+        device_kernel = name if "normals" in name else name + (("_split" if name.endswith("1") else "_real") if n > 4096 else "")
+        rec = {"name": name, "device_kernel": device_kernel, "avg_ms": avg_ms, "algorithmic_bytes": b, "GBps": b / avg_ms / 1e6,
+               "frac": b / avg_ms / 1e6 / HBM_PEAK_GBS, "contract_bytes": cb, "contract_GBps": cb / avg_ms / 1e6,
+               "contract_frac": cb / avg_ms / 1e6 / HBM_PEAK_GBS,
+               "traffic": measured_traffic(n, name, args.spectrum, args.intermediate, with_normals)}
+        if "normals" in name:      # priced on the pass's algorithmic minimum (4 R + 12 W); what the kernel moves (4 R + 16 W) beside it
+            ab = NORMALS_ALGORITHMIC_BYTES_PER_TEXEL * n * n
+            rec.update({"moved_bytes": b, "moved_GBps": rec["GBps"], "algorithmic_bytes": ab, "GBps": ab / avg_ms / 1e6,
+                        "frac": ab / avg_ms / 1e6 / HBM_PEAK_GBS})
+        kernels.append(rec)
     dom = max(kernels, key=lambda k: k["avg_ms"])
     frame_ms = event_ms / args.steps
     fb, fcb = sum(moved.values()) * n * n, sum(contract.values()) * n * n
     roofline = {"bound": "hbm", "kernel": dom["name"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": dom["frac"], "traffic": dom["traffic"], "traffic_source": traffic_source(n, args.spectrum, args.intermediate),
+                "frac": dom["frac"], "traffic": dom["traffic"], "traffic_source": traffic_source(n, args.spectrum, args.intermediate, with_normals),
                 "algorithmic_bytes_per_launch": dom["algorithmic_bytes"], "avg_launch_ms": dom["avg_ms"],
                 "accounting": f"achieved = bytes the shipped half-spectrum algorithm must move ({moved['pass1']:.0f} + "
-                              f"{moved['pass2']:.0f} B/texel) / kernel time; contract_* = SURVEY 8d's three-complex-"
-                              f"transform accounting ({contract['pass1']:.0f} + {contract['pass2']:.0f} B/texel) / the same time",
+                              f"{moved['pass2']:.0f} B/texel" + (f" + {moved['normals']:.0f} for the normal field, whose kernel is priced "
+                              f"on its algorithmic minimum of {NORMALS_ALGORITHMIC_BYTES_PER_TEXEL:.0f}" if with_normals else "") +
+                              f") / kernel time; contract_* = SURVEY 8d's three-complex-"
+                              f"transform accounting ({contract['pass1']:.0f} + {contract['pass2']:.0f} B/texel" +
+                              (f" + {contract['normals']:.0f}, SURVEY 8f #1" if with_normals else "") + ") / the same time",
                 "contract_achieved": dom["contract_GBps"], "contract_frac": dom["contract_frac"],
                 "kernels": kernels,
                 "frame": {"algorithmic_bytes": fb, "GBps": fb / frame_ms / 1e6, "frac": fb / frame_ms / 1e6 / HBM_PEAK_GBS,
@@ -544,11 +581,14 @@ def main():
             "value": agg["value"], "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": agg["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"N={n} tile per GPU, {spec_txt}, fused frame (2 launches: propagate + column pass, "
-                                   f"row pass + correction), height+disp_x+disp_z; half-spectrum real-output algorithm: "
+            "config": {"workload": f"N={n} tile per GPU, {spec_txt}, fused frame (" +
+                                   (f"3 launches: propagate + column pass, row pass + correction, normal field from {args.normals}), "
+                                    f"height+disp_x+disp_z+normal" if with_normals else
+                                    "2 launches: propagate + column pass, row pass + correction), height+disp_x+disp_z") +
+                                   f"; half-spectrum real-output algorithm: "
                                    f"{sum(moved.values()):.0f} B/texel moved ({sum(contract.values()):.0f} B/texel on the "
                                    f"three-complex-transform accounting of SURVEY 8d); seed N+rank",
-                       "n": n, "spectrum": args.spectrum, "intermediate": args.intermediate, "tiles": n_gpus,
+                       "n": n, "spectrum": args.spectrum, "intermediate": args.intermediate, "normals": args.normals, "tiles": n_gpus,
                        "parallelism": f"tile-parallel x{n_gpus}, no data-path collective",
                        "gpu_event_ms_per_step": frame_ms,
                        "frame_ms_median": spread["frame"]["median_ms"], "frame_ms_p10": spread["frame"]["p10_ms"],

@@ -23,10 +23,10 @@ SYMBOLS = [
     "ocean_propagation_destroy", "ocean_correction_init", "ocean_correction_destroy", "ocean_propagate",
     "ocean_fft_rows", "ocean_fft_cols", "ocean_correct", "ocean_frame", "ocean_frame_ex", "ocean_sync",
     "ocean_set_quirks", "ocean_quirks", "ocean_set_intermediate", "ocean_intermediate",
-    "ocean_normals", "ocean_read_normals", "ocean_positions", "ocean_read_positions",
+    "ocean_normals", "ocean_read_normals", "ocean_set_frame_normals", "ocean_frame_normals", "ocean_normals_device_ptr", "ocean_positions", "ocean_read_positions",
     "ocean_checksum_displacement", "ocean_packed_bytes", "ocean_pack_displacement",
     "ocean_read_displacement", "ocean_read_field", "ocean_write_field", "ocean_displacement_device_ptr",
-    "ocean_bind_displacement", "ocean_stream", "ocean_time_frames", "ocean_time_frame_batches", "ocean_frame_times", "ocean_profile_frame", "ocean_profile_staged",
+    "ocean_bind_displacement", "ocean_stream", "ocean_time_frames", "ocean_time_frame_batches", "ocean_frame_times", "ocean_frame_times_ex", "ocean_profile_frame", "ocean_profile_staged",
     "ocean_shard_create", "ocean_shard_destroy", "ocean_shard_last_error", "ocean_shard_upload", "ocean_shard_rows",
     "ocean_shard_cols", "ocean_shard_sync", "ocean_shard_stream",
     "ocean_tile_exchange_bytes", "ocean_tile_pass1", "ocean_tile_pass2",
@@ -110,6 +110,9 @@ def load_library():
         "ocean_intermediate": (i32, [vp]),
         "ocean_normals": (i32, [vp, i32, vp]),
         "ocean_read_normals": (i32, [vp, vp]),
+        "ocean_set_frame_normals": (i32, [vp, i32]),
+        "ocean_frame_normals": (i32, [vp]),
+        "ocean_normals_device_ptr": (vp, [vp]),
         "ocean_positions": (i32, [vp, i32, f32, f32, vp]),
         "ocean_read_positions": (i32, [vp, vp]),
         "ocean_checksum_displacement": (i32, [vp, vp, ctypes.POINTER(ctypes.c_uint64)]),
@@ -124,6 +127,7 @@ def load_library():
         "ocean_time_frames": (i32, [vp, i32, f32, f32, ctypes.POINTER(f32)]),
         "ocean_time_frame_batches": (i32, [vp, i32, i32, f32, f32, ctypes.POINTER(f32)]),
         "ocean_frame_times": (i32, [vp, i32, f32, f32, ctypes.POINTER(f32), ctypes.POINTER(f32), ctypes.POINTER(f32)]),
+        "ocean_frame_times_ex": (i32, [vp, i32, f32, f32, ctypes.POINTER(f32), ctypes.POINTER(f32), ctypes.POINTER(f32), ctypes.POINTER(f32)]),
         "ocean_profile_frame": (i32, [vp, f32, i32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(f32),
                                       ctypes.POINTER(i32)]),
         "ocean_profile_staged": (i32, [vp, f32, i32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(f32),

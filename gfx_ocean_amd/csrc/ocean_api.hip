@@ -84,6 +84,10 @@ struct OceanContext {
     float4* out_own = nullptr;  // displacement map (src/render.rs:820-869), linear RGBA32F
     float4* out = nullptr;      // = out_own or the caller's buffer (ocean_bind_displacement)
     float4* normals = nullptr;    // allocated on first ocean_normals call
+    // The frame with the normal field (ocean_set_frame_normals; BASELINE config 3 "height + displacement + normal"):
+    // pass 2 also stores the source channel as a dense fp32 plane, which k_normals_plane differentiates behind it.
+    int frame_normals = -1;       // source channel 0..2, or -1: the frame is the map alone
+    float* plane = nullptr;       // N x N floats, allocated by ocean_set_frame_normals
     float4* positions = nullptr;  // ocean_positions: verts x verts float4, (re)allocated on demand
     int32_t position_verts = 0;
     unsigned long long* checksum_acc = nullptr;   // ocean_checksum_displacement
@@ -164,13 +168,13 @@ template <int N> struct Launch {
     // the shipped kernel instances of this size (fp32 / fp16-stored spectrum; split: + the opt-in 16-bit intermediate)
     template <bool H16> static constexpr auto pass1_kernel() { return k_half_pass1<N, H::E1, H::P, H16, H::dma, H::fpar>; }
     template <bool H16, bool I16> static constexpr auto pass1_split_kernel() { return k_half_pass1_split<N, H::E1S, H::P, H16, I16>; }
-    template <bool SHARD> static constexpr auto pass2_kernel() { return k_half_pass2<N, H::E2, CHUNK_W, H::R2h, H::p2_group, H::ppar, SHARD>; }
+    template <bool SHARD, bool PLANE = false> static constexpr auto pass2_kernel() { return k_half_pass2<N, H::E2, CHUNK_W, H::R2h, H::p2_group, H::ppar, SHARD, PLANE>; }
     // Pass 2 at N >= 8192: real-output rows (three N/2-point transforms per row, half the LDS and half the threads of a row:
     // k_half_pass2_real).  Measured against two N-point transforms per row (r04_run23, one box, two repetitions): pass 2 at
     // 8192 440 -> 350 us, at 16384 2.60 -> 1.67-1.72 ms; at 4096 88-91 -> 97-98 us and at 2048 17.8 -> 22.6 us (a row of
     // 128 or 64 threads is a longer serial chain than it saves), so the sizes below keep k_half_pass2.
     static constexpr bool REAL2 = SPLIT;
-    template <bool SHARD, bool I16> static constexpr auto pass2_real_kernel() { return k_half_pass2_real<N, H::E, CHUNK_W, H::p2_group, SHARD, I16>; }
+    template <bool SHARD, bool I16, bool PLANE = false> static constexpr auto pass2_real_kernel() { return k_half_pass2_real<N, H::E, CHUNK_W, H::p2_group, SHARD, I16, 4, PLANE>; }
     static hipError_t prepare_fused() {
         hipError_t e = hipSuccess;
         auto lds = [&](auto kernel, int bytes) {
@@ -179,13 +183,15 @@ template <int N> struct Launch {
         if constexpr (SPLIT) {
             lds(pass1_split_kernel<false, false>(), H::split_lds1); lds(pass1_split_kernel<true, false>(), H::split_lds1);
             lds(pass2_real_kernel<false, false>(), H::real_lds2); lds(pass2_real_kernel<true, false>(), H::real_lds2);
+            lds(pass2_real_kernel<false, false, true>(), H::real_lds2);
             if constexpr (I16_BUILT) {
                 lds(pass1_split_kernel<false, true>(), H::split_lds1);  lds(pass1_split_kernel<true, true>(), H::split_lds1);
-                lds(pass2_real_kernel<false, true>(), H::real_lds2);
+                lds(pass2_real_kernel<false, true>(), H::real_lds2); lds(pass2_real_kernel<false, true, true>(), H::real_lds2);
             }
         } else {
             lds(pass1_kernel<false>(), H::half_lds1); lds(pass1_kernel<true>(), H::half_lds1);
             lds(pass2_kernel<false>(), H::half_lds2); lds(pass2_kernel<true>(), H::half_lds2);
+            lds(pass2_kernel<false, true>(), H::half_lds2);
         }
         return e;
     }
@@ -218,19 +224,30 @@ template <int N> struct Launch {
     static void pass1(OceanContext* c, float time, float domain, hipStream_t s, Timing t = Timing()) {
         pass1_on(c, time, domain, c->inter, c->lay_h, H::half_grid1, 0, s, t);
     }
+    // Pass 2 into the context's map; with the normal field switched on (ocean_set_frame_normals) the PLANE instances, which
+    // also store the source channel as the dense plane k_normals_plane reads.
     static void pass2(OceanContext* c, hipStream_t s, Timing t = Timing()) {
         const c32* inter = c->inter;
         const c32* tw = c->tw;
+        const bool plane = c->frame_normals >= 0;
+        float* pl = c->plane;
+        const int ch = c->frame_normals;
         if constexpr (REAL2) {
+            const dim3 g(N), b(H::real_threads2);
             if constexpr (I16_BUILT) {
                 if (c->inter16) {
-                    launch(pass2_real_kernel<false, true>(), dim3(N), dim3(H::real_threads2), H::real_lds2, s, t, inter, c->out, tw, c->lay_h, (const float*)c->inter_scale);
+                    const float* sc = c->inter_scale;
+                    if (plane) launch(pass2_real_kernel<false, true, true>(), g, b, H::real_lds2, s, t, inter, c->out, tw, c->lay_h, sc, pl, ch);
+                    else launch(pass2_real_kernel<false, true>(), g, b, H::real_lds2, s, t, inter, c->out, tw, c->lay_h, sc, (float*)nullptr, 0);
                     return;
                 }
             }
-            launch(pass2_real_kernel<false, false>(), dim3(N), dim3(H::real_threads2), H::real_lds2, s, t, inter, c->out, tw, c->lay_h, (const float*)nullptr);
+            if (plane) launch(pass2_real_kernel<false, false, true>(), g, b, H::real_lds2, s, t, inter, c->out, tw, c->lay_h, (const float*)nullptr, pl, ch);
+            else launch(pass2_real_kernel<false, false>(), g, b, H::real_lds2, s, t, inter, c->out, tw, c->lay_h, (const float*)nullptr, (float*)nullptr, 0);
         } else {
-            launch(pass2_kernel<false>(), dim3(H::half_grid2), dim3(H::half_threads2), H::half_lds2, s, t, inter, c->out, tw, c->lay_h);
+            const dim3 g(H::half_grid2), b(H::half_threads2);
+            if (plane) launch(pass2_kernel<false, true>(), g, b, H::half_lds2, s, t, inter, c->out, tw, c->lay_h, pl, ch);
+            else launch(pass2_kernel<false>(), g, b, H::half_lds2, s, t, inter, c->out, tw, c->lay_h, (float*)nullptr, 0);
         }
     }
     // ---- one tile sharded over `world` GPUs (ocean_tile_pass1 / ocean_tile_pass2): the same kernels on this rank's
@@ -249,9 +266,9 @@ template <int N> struct Launch {
         const int rows = N / world;
         const c32* tw = c->tw;
         if constexpr (REAL2)
-            hipLaunchKernelGGL((pass2_real_kernel<true, false>()), dim3(rows), dim3(H::real_threads2), H::real_lds2, s, recv, out_rows, tw, lay, (const float*)nullptr);
+            hipLaunchKernelGGL((pass2_real_kernel<true, false>()), dim3(rows), dim3(H::real_threads2), H::real_lds2, s, recv, out_rows, tw, lay, (const float*)nullptr, (float*)nullptr, 0);
         else
-            hipLaunchKernelGGL((pass2_kernel<true>()), dim3(rows / H::R2h), dim3(H::half_threads2), H::half_lds2, s, recv, out_rows, tw, lay);
+            hipLaunchKernelGGL((pass2_kernel<true>()), dim3(rows / H::R2h), dim3(H::half_threads2), H::half_lds2, s, recv, out_rows, tw, lay, (float*)nullptr, 0);
     }
     static void stage_rows(OceanContext* c, int f, hipStream_t s) {
         if constexpr (G::stage_chunked)
@@ -348,15 +365,41 @@ void launch_cols(OceanContext* c, int f, hipStream_t s) {
     OCEAN_DISPATCH(c->n, L::cols(c, c->field[f], s));
     c->chk_valid[f] = false;
 }
+// The normal field of the current map (shader/ocean.frag:50-66 at texel centres) into c->normals.
+// From the RGBA map (any path: 16 + 16 B/texel) ...
+void launch_normals_rgba(OceanContext* c, int channel, hipStream_t s, Timing t = Timing()) {
+    const int rows = normals_rows(c->n);
+    const dim3 grid((unsigned)((c->n / 256) * (c->n / rows))), b(256);
+    const float4* rgba = c->out;
+    switch (rows) {
+        case 1: launch(k_normals<1>, grid, b, 0, s, t, rgba, c->normals, c->n, channel); break;
+        case 2: launch(k_normals<2>, grid, b, 0, s, t, rgba, c->normals, c->n, channel); break;
+        case 4: launch(k_normals<4>, grid, b, 0, s, t, rgba, c->normals, c->n, channel); break;
+        default: launch(k_normals<8>, grid, b, 0, s, t, rgba, c->normals, c->n, channel); break;
+    }
+}
+// ... or from the source-channel plane the fused pass 2 has just stored (4 + 16 B/texel).
+void launch_normals_plane(OceanContext* c, hipStream_t s, Timing t = Timing()) {
+    const int rows = normals_plane_rows(c->n);
+    const dim3 grid((unsigned)((c->n / 256) * (c->n / rows) / 4)), b(256);
+    const float* plane = c->plane;
+    switch (rows) {
+        case 2: launch(k_normals_plane<2>, grid, b, 0, s, t, plane, c->normals, c->n); break;
+        case 4: launch(k_normals_plane<4>, grid, b, 0, s, t, plane, c->normals, c->n); break;
+        default: launch(k_normals_plane<8>, grid, b, 0, s, t, plane, c->normals, c->n); break;
+    }
+}
 void launch_frame(OceanContext* c, float time, float domain, hipStream_t s) {
     if (c->quirks != OCEAN_QUIRKS_REFERENCE) {      // the fused kernels implement the reference's arithmetic only
         launch_propagate(c, time, domain, s);
         for (int f = 0; f < 3; ++f) launch_rows(c, f, s);
         for (int f = 0; f < 3; ++f) launch_cols(c, f, s);
         launch_correct(c, s);
+        if (c->frame_normals >= 0) launch_normals_rgba(c, c->frame_normals, s);
         return;
     }
     OCEAN_DISPATCH(c->n, { L::pass1(c, time, domain, s); L::pass2(c, s); });
+    if (c->frame_normals >= 0) launch_normals_plane(c, s);
 }
 
 int32_t check_launch(OceanContext* c, const char* what) {
@@ -369,7 +412,7 @@ void free_all(OceanContext* c) {
     auto f = [](void* p) { if (p) (void)hipFree(p); };
     f(c->h0); f(c->omega); f(c->field[0]); f(c->field[1]); f(c->field[2]);
     f(c->cfield[0]); f(c->cfield[1]); f(c->cfield[2]);
-    f(c->h0T); f(c->omegaT); f(c->inter); f(c->nyq); f(c->tw); f(c->out_own); f(c->normals); f(c->positions); f(c->checksum_acc); f(c->inter_scale);
+    f(c->h0T); f(c->omegaT); f(c->inter); f(c->nyq); f(c->tw); f(c->out_own); f(c->normals); f(c->plane); f(c->positions); f(c->checksum_acc); f(c->inter_scale);
     if (c->ev_a) (void)hipEventDestroy(c->ev_a);
     if (c->ev_b) (void)hipEventDestroy(c->ev_b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -656,17 +699,23 @@ int32_t ocean_normals(OceanContext* ctx, int32_t source_channel, void* stream) {
     DeviceGuard guard(ctx->device);
     const size_t n2 = (size_t)ctx->n * ctx->n;
     if (!ctx->normals) HIP_TRY(ctx, hipMalloc((void**)&ctx->normals, n2 * sizeof(float4)));
-    const int rows = normals_rows(ctx->n);
-    const dim3 grid((unsigned)((ctx->n / 256) * (ctx->n / rows)));
-    hipStream_t s = pick(ctx, stream);
-    switch (rows) {
-        case 1: hipLaunchKernelGGL(k_normals<1>, grid, dim3(256), 0, s, ctx->out, ctx->normals, ctx->n, source_channel); break;
-        case 2: hipLaunchKernelGGL(k_normals<2>, grid, dim3(256), 0, s, ctx->out, ctx->normals, ctx->n, source_channel); break;
-        case 4: hipLaunchKernelGGL(k_normals<4>, grid, dim3(256), 0, s, ctx->out, ctx->normals, ctx->n, source_channel); break;
-        default: hipLaunchKernelGGL(k_normals<8>, grid, dim3(256), 0, s, ctx->out, ctx->normals, ctx->n, source_channel); break;
-    }
+    launch_normals_rgba(ctx, source_channel, pick(ctx, stream));
     return check_launch(ctx, "k_normals launch");
 }
+int32_t ocean_set_frame_normals(OceanContext* ctx, int32_t source_channel) {
+    if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    if (source_channel < -1 || source_channel > 2) return fail(ctx, OCEAN_E_INVALID_ARG, "source_channel must be -1 (off), 0, 1 or 2");
+    if (source_channel >= 0) {
+        DeviceGuard guard(ctx->device);
+        const size_t n2 = (size_t)ctx->n * ctx->n;
+        if (!ctx->normals) HIP_TRY(ctx, hipMalloc((void**)&ctx->normals, n2 * sizeof(float4)));
+        if (!ctx->plane) HIP_TRY(ctx, hipMalloc((void**)&ctx->plane, n2 * sizeof(float)));
+    }
+    ctx->frame_normals = source_channel;
+    return OCEAN_OK;
+}
+int32_t ocean_frame_normals(const OceanContext* ctx) { return valid(ctx) ? ctx->frame_normals : OCEAN_E_INVALID_ARG; }
+void* ocean_normals_device_ptr(OceanContext* ctx) { return valid(ctx) ? (void*)ctx->normals : nullptr; }
 int32_t ocean_read_normals(OceanContext* ctx, float* host_xyz0) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
     if (!host_xyz0) return fail(ctx, OCEAN_E_INVALID_ARG, "NULL output");
@@ -924,7 +973,8 @@ static int32_t profile_common(OceanContext* ctx, float time, int32_t cap, const 
 // (an event per FRAME adds ~5 % of gaps: measured r04_run3, 193 against 185.5 us at N = 4096; one per 10 frames does not).
 int32_t ocean_time_frame_batches(OceanContext* ctx, int32_t batches, int32_t frames_per_batch, float t0, float dt, float* batch_ms) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
-    if (batches <= 0 || batches > 4096 || frames_per_batch <= 0 || !batch_ms) return fail(ctx, OCEAN_E_INVALID_ARG, "batches in [1, 4096], frames_per_batch > 0, batch_ms non-NULL");
+    if (batches <= 0 || batches > 4096 || frames_per_batch <= 0 || frames_per_batch > 4096 || !batch_ms)
+        return fail(ctx, OCEAN_E_INVALID_ARG, "batches and frames_per_batch in [1, 4096], batch_ms non-NULL");
     if (!ctx->uploaded) return fail(ctx, OCEAN_E_STATE, "ocean_upload_spectrum has not been called");
     DeviceGuard guard(ctx->device);
     struct Events {
@@ -934,7 +984,7 @@ int32_t ocean_time_frame_batches(OceanContext* ctx, int32_t batches, int32_t fra
     for (int i = 0; i <= batches; ++i) { hipEvent_t x; HIP_TRY(ctx, hipEventCreate(&x)); bag.e.push_back(x); }
     HIP_TRY(ctx, hipEventRecord(bag.e[0], ctx->stream));
     for (int b = 0; b < batches; ++b) {
-        for (int i = 0; i < frames_per_batch; ++i) launch_frame(ctx, t0 + dt * (float)(b * frames_per_batch + i), ctx->default_domain, ctx->stream);
+        for (int i = 0; i < frames_per_batch; ++i) launch_frame(ctx, t0 + dt * (float)((int64_t)b * frames_per_batch + i), ctx->default_domain, ctx->stream);
         HIP_TRY(ctx, hipEventRecord(bag.e[b + 1], ctx->stream));
     }
     HIP_TRY(ctx, hipEventSynchronize(bag.e[batches]));
@@ -946,12 +996,15 @@ int32_t ocean_time_frame_batches(OceanContext* ctx, int32_t batches, int32_t fra
 //   pass1_ms[i], pass2_ms[i]: the two kernels of frame i;   period_ms[i] = begin(pass 1 of frame i + 1) - begin(pass 1 of
 //   frame i), the last entry begin(pass 1) -> end(pass 2) -- in THIS loop, whose event-carrying launches leave larger gaps
 //   than plain ones (ocean_time_frame_batches is the undisturbed loop).
-int32_t ocean_frame_times(OceanContext* ctx, int32_t frames, float t0, float dt, float* pass1_ms, float* pass2_ms, float* period_ms) {
+int32_t ocean_frame_times_ex(OceanContext* ctx, int32_t frames, float t0, float dt, float* pass1_ms, float* pass2_ms, float* normals_ms,
+                             float* period_ms) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
     if (frames <= 0 || frames > 4096) return fail(ctx, OCEAN_E_INVALID_ARG, "frames must be in [1, 4096]");
     if (!ctx->uploaded) return fail(ctx, OCEAN_E_STATE, "ocean_upload_spectrum has not been called");
     if (ctx->quirks != OCEAN_QUIRKS_REFERENCE)
         return fail(ctx, OCEAN_E_STATE, "the fused kernels implement the reference quirks only (ocean_set_quirks)");
+    const bool nrm = ctx->frame_normals >= 0;
+    if (normals_ms && !nrm) return fail(ctx, OCEAN_E_STATE, "normals_ms asked for, but the frame carries no normal field (ocean_set_frame_normals)");
     DeviceGuard guard(ctx->device);
     struct Events {
         std::vector<hipEvent_t> e;
@@ -961,22 +1014,28 @@ int32_t ocean_frame_times(OceanContext* ctx, int32_t frames, float t0, float dt,
         }
         ~Events() { for (hipEvent_t x : e) (void)hipEventDestroy(x); }
     } bag;
-    HIP_TRY(ctx, bag.add((size_t)frames * 4));
+    const size_t per = nrm ? 6 : 4;                                 // begin / end of every dispatch of a frame
+    HIP_TRY(ctx, bag.add((size_t)frames * per));
     hipStream_t s = ctx->stream;
     for (int i = 0; i < frames; ++i) {
-        hipEvent_t* k = bag.e.data() + (size_t)i * 4;
+        hipEvent_t* k = bag.e.data() + (size_t)i * per;
         const float time = t0 + dt * (float)i;
         OCEAN_DISPATCH(ctx->n, L::pass1(ctx, time, ctx->default_domain, s, Timing{k[0], k[1]}));
         OCEAN_DISPATCH(ctx->n, L::pass2(ctx, s, Timing{k[2], k[3]}));
+        if (nrm) launch_normals_plane(ctx, s, Timing{k[4], k[5]});
     }
     HIP_TRY(ctx, hipStreamSynchronize(s));
     for (int i = 0; i < frames; ++i) {
-        hipEvent_t* k = bag.e.data() + (size_t)i * 4;
+        hipEvent_t* k = bag.e.data() + (size_t)i * per;
         if (pass1_ms) HIP_TRY(ctx, hipEventElapsedTime(&pass1_ms[i], k[0], k[1]));
         if (pass2_ms) HIP_TRY(ctx, hipEventElapsedTime(&pass2_ms[i], k[2], k[3]));
-        if (period_ms) HIP_TRY(ctx, hipEventElapsedTime(&period_ms[i], k[0], (i + 1 < frames) ? k[4] : k[3]));
+        if (normals_ms) HIP_TRY(ctx, hipEventElapsedTime(&normals_ms[i], k[4], k[5]));
+        if (period_ms) HIP_TRY(ctx, hipEventElapsedTime(&period_ms[i], k[0], (i + 1 < frames) ? k[per] : k[per - 1]));
     }
     return check_launch(ctx, "ocean_frame_times");
+}
+int32_t ocean_frame_times(OceanContext* ctx, int32_t frames, float t0, float dt, float* pass1_ms, float* pass2_ms, float* period_ms) {
+    return ocean_frame_times_ex(ctx, frames, t0, dt, pass1_ms, pass2_ms, nullptr, period_ms);
 }
 int32_t ocean_profile_frame(OceanContext* ctx, float time, int32_t cap, const char** names, float* ms, int32_t* out_n) {
     return profile_common(ctx, time, cap, names, ms, out_n, false);

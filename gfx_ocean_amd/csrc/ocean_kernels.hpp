@@ -766,9 +766,13 @@ template <int N, int R2> struct Pitch2 { static constexpr int elems = LdsLine<N>
 // 0.9 + transform 0.9 us, then gather 0.4 + transform 1.65 us, one after the other, on a CU with two waves.)
 // SHARD: this launch transforms the gridDim.x * R2 rows of ONE rank of a tile sharded over several GPUs; `inter` is the
 // receive buffer of the all-to-all (InterLayout::xs_shift / src_stride), `out` the rank's block of rows.
-template <int N, int E, int P1, int R2, int GRP = 1, bool PPAR = false, bool SHARD = false>
+// PLANE (the frame with the normal field, ocean_set_frame_normals): the epilogue also stores channel `plane_channel` of the
+// finished map -- the very floats it puts into the RGBA texels -- as a dense fp32 plane, plane[y N + x], which is what the
+// normal-field kernel differentiates (k_normals_plane: 4 instead of 16 bytes read per texel; ocean_staged_kernels.hpp).
+template <int N, int E, int P1, int R2, int GRP = 1, bool PPAR = false, bool SHARD = false, bool PLANE = false>
 __global__ void __launch_bounds__((N / E) * R2 * (PPAR ? 2 : 1), (E == 16) ? 4 : 2)
-k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32* __restrict__ tw, InterLayout lay) {
+k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32* __restrict__ tw, InterLayout lay,
+             float* __restrict__ plane, int plane_channel) {
     constexpr int T = N / E;
     constexpr int GT = T * R2;                                     // threads of one transform group (= the workgroup without PPAR)
     constexpr int EH = E / 2;                                      // elements of the half spectrum per thread
@@ -911,7 +915,9 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
                 const int xo = j + e * T;
                 const float s = (((xo + y) & 1) == 0) ? -0.5f : 0.5f;   // correction.comp:29 and the 1/2 of S(F)
                 const c32 d = reg[e] * s;
-                store_float4_nt(orow + xo, make_float4(d.x, keep_h[e] * s, d.y, 0.0f));
+                const float hs = keep_h[e] * s;
+                store_float4_nt(orow + xo, make_float4(d.x, hs, d.y, 0.0f));
+                if constexpr (PLANE) plane[(size_t)y * N + xo] = (plane_channel == 0) ? d.x : ((plane_channel == 1) ? hs : d.y);
             }
             OCEAN_TL(6);
         }
@@ -953,10 +959,10 @@ __device__ __forceinline__ void real_row_inputs(const c32* lo, const c32* hi, in
     reg[0] = real_row_input<E, 0>(dc ? mk(a0.x, 0.0f) : a0, dc ? mk(a0.y, 0.0f) : p0, wji, wjn);
     ((I == 0 ? (void)0 : (void)(reg[I] = real_row_input<E, I>(lo[I * k1], hi[-I * k1], wji, wjn))), ...);
 }
-template <int N, int E, int P1, int GRP = 1, bool SHARD = false, bool I16 = false, int WPS = 4>
+template <int N, int E, int P1, int GRP = 1, bool SHARD = false, bool I16 = false, int WPS = 4, bool PLANE = false>
 __global__ void __launch_bounds__((N / 2) / E, WPS)
 k_half_pass2_real(const c32* __restrict__ inter, float4* __restrict__ out, const c32* __restrict__ tw, InterLayout lay,
-                  const float* __restrict__ inter_scale) {
+                  const float* __restrict__ inter_scale, float* __restrict__ plane, int plane_channel) {
     static_assert(!(SHARD && I16), "the 16-bit intermediate is not combined with the sharded tile");
     constexpr int M = N / 2;
     constexpr int T = M / E;                                       // threads per row
@@ -1033,8 +1039,11 @@ k_half_pass2_real(const c32* __restrict__ inter, float4* __restrict__ out, const
             for (int s = 0; s < 2 * E; ++s) keep_x[s] = src[2 * k2(s)];
         } else {
 #pragma unroll
-            for (int s = 0; s < 2 * E; ++s)
-                store_float4_nt(orow + jf + s * T, make_float4(keep_x[s] * sgn, keep_h[s] * sgn, src[2 * k2(s)] * sgn, 0.0f));
+            for (int s = 0; s < 2 * E; ++s) {
+                const float vx = keep_x[s] * sgn, vh = keep_h[s] * sgn, vz = src[2 * k2(s)] * sgn;
+                store_float4_nt(orow + jf + s * T, make_float4(vx, vh, vz, 0.0f));
+                if constexpr (PLANE) plane[(size_t)y * N + jf + s * T] = (plane_channel == 0) ? vx : ((plane_channel == 1) ? vh : vz);   // (k_half_pass2)
+            }
         }
     };
     OCEAN_TL(0);

@@ -118,11 +118,35 @@ k_correct(const c32* __restrict__ height, const c32* __restrict__ disp_x, const 
 // (src/render.rs:398), height_scale 180 (:19), diff = 2/N (the shader's literal 512 -> N).
 // channel 0 = disp_x is what the reference differentiates (quirk Q5); 1 = height is the
 // physically meant source.
+//
+// The arithmetic.  With ax = x1 - x0, az = z1 - z0, d = 2/N, s = 180:
+//     na = normalize(-d, ax/s, 0),  nb = normalize(0, az/s, d)                      :64-65
+//     n  = normalize(cross(na, nb)) = (ax/s, d, -az/s) / |(ax/s, d, -az/s)|          :66
+// (the two inner normalisations scale the cross product by 1/(|na'| |nb'|) and drop out of the outer one).  Evaluated in
+// that closed form -- n = (ax, s d, -az) * rsqrt(ax^2 + az^2 + (s d)^2): one v_rsq_f32, no division -- instead of the
+// literal three normalize() with a square root and three IEEE divisions each, which made the kernel VALU-issue-bound
+// (9 divisions + 3 square roots = ~180 issue slots per texel: 19 of the 25 us at N = 2048; round 5).  Fewer roundings
+// than the literal form: closer to the fp64 value (tests/test_gpu_parity.py::test_normal_field holds both to the literal
+// fp32 restatement within 1e-5 absolute; GLSL's own normalize() is implementation-defined, usually v * inversesqrt(dot(v, v))).
+__device__ __forceinline__ float4 normal_from_differences(float ax, float az, float sd) {
+#ifdef OCEAN_NORMALS_LITERAL                                         // A/B only (tools/build_variants.py): the literal evaluation
+    const float d = sd / 180.0f;
+    const float ay = ax / 180.0f, by = az / 180.0f;
+    const float la = sqrtf(d * d + ay * ay), lb = sqrtf(by * by + d * d);
+    const float nax = -d / la, nay = ay / la, nby = by / lb, nbz = d / lb;
+    const float cx = nay * nbz, cy = -nax * nbz, cz = nax * nby;
+    const float lc = sqrtf(cx * cx + cy * cy + cz * cz);
+    return make_float4(cx / lc, cy / lc, cz / lc, 0.0f);
+#else
+    const float r = rsqrtf(fmaf(ax, ax, fmaf(az, az, sd * sd)));
+    return make_float4(ax * r, sd * r, -az * r, 0.0f);
+#endif
+}
 // A workgroup owns 256 columns x ROWS rows; a thread walks down its column with the rows above and below in registers,
 // so a row is fetched once per workgroup (plus two halo rows per ROWS) instead of three times by three workgroups, and
 // the x neighbours are hits in the lines the centre load brought.  Streamed stores.  grid = (N / 256) * (N / ROWS);
-// N >= 256.  Against one thread per texel (r04_run44/45): N = 4096 112.5 -> 88.4 us (6.1 TB/s on the 32 B/texel it moves),
-// 2048 27.0 -> 25.0 us, 8192 395 us.  ROWS per size (measured 4 / 8 / 16; the small sizes need the workgroups):
+// N >= 256.  Reads whole RGBA texels for one channel: 16 + 16 B/texel (the frame with normals uses k_normals_plane).
+// ROWS per size (measured 4 / 8 / 16; the small sizes need the workgroups):
 constexpr int normals_rows(int n) { return (n >= 8192) ? 8 : ((n >= 2048) ? 4 : ((n >= 1024) ? 2 : 1)); }
 template <int ROWS>
 __global__ void __launch_bounds__(256)
@@ -132,24 +156,60 @@ k_normals(const float4* __restrict__ rgba, float4* __restrict__ normals, int n, 
     const uint32_t x = (blockIdx.x % col_blocks) * 256u + threadIdx.x, y0 = (blockIdx.x / col_blocks) * ROWS;
     const uint32_t xm = (x + un - 1u) % un, xp = (x + 1u) % un;
     const float* f = reinterpret_cast<const float*>(rgba) + channel;
-    const float d = 2.0f / (float)n;                               // :52
+    const float sd = 360.0f / (float)n;                            // height_scale * diff = 180 * 2 / N   (:19, :52)
     float above = f[((size_t)((y0 + un - 1u) % un) * un + x) * 4], centre = f[((size_t)y0 * un + x) * 4];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         const uint32_t y = y0 + (uint32_t)r;
         const float below = f[((size_t)((y + 1u) % un) * un + x) * 4];
         const float x0 = f[((size_t)y * un + xm) * 4], x1 = f[((size_t)y * un + xp) * 4];
-        const float z0 = above, z1 = below;
-        // na = normalize(-d, (x1-x0)/180, 0), nb = normalize(0, (z1-z0)/180, d)      :64-65
-        const float ay = (x1 - x0) / 180.0f, by = (z1 - z0) / 180.0f;
-        const float la = sqrtf(d * d + ay * ay), lb = sqrtf(by * by + d * d);
-        const float nax = -d / la, nay = ay / la, nby = by / lb, nbz = d / lb;
-        // cross(na, nb) with na.z = nb.x = 0                                           :66
-        const float cx = nay * nbz, cy = -nax * nbz, cz = nax * nby;
-        const float lc = sqrtf(cx * cx + cy * cy + cz * cz);
-        store_float4_nt(normals + (size_t)y * un + x, make_float4(cx / lc, cy / lc, cz / lc, 0.0f));
+        store_float4_nt(normals + (size_t)y * un + x, normal_from_differences(x1 - x0, below - above, sd));
         above = centre;
         centre = below;
+    }
+}
+// The same field from the dense fp32 plane of the source channel that pass 2 of the fused frame stores next to the map
+// (k_half_pass2<.., PLANE>): 4 + 16 instead of 16 + 16 B/texel.  A wave owns 256 adjacent columns x ROWS rows: lane l holds
+// columns l, l + 64, l + 128, l + 192 of the segment (every load instruction of the wave is one contiguous 256-byte piece
+// of a plane row, every store instruction one contiguous KiB of a normals row) and walks down the rows with the rows above
+// and below in registers; the x neighbours are 4-byte hits in the lines the centre loads brought.  Bands of rows go to the
+// XCDs in contiguous ranges, so that a band's two halo rows are L2 hits.  grid = (N / 256) * (N / ROWS) / 4 workgroups of
+// four waves; N >= 256, N / ROWS >= 4.
+// Same arithmetic on the same floats as k_normals: bit-identical normals (tests/test_gpu_parity.py).
+constexpr int normals_plane_rows(int n) { return (n >= 2048) ? 8 : ((n >= 1024) ? 4 : 2); }
+template <int ROWS>
+__global__ void __launch_bounds__(256)
+k_normals_plane(const float* __restrict__ plane, float4* __restrict__ normals, int n) {
+    const uint32_t un = (uint32_t)n, mask = un - 1u, segs = un / 256u;
+    const uint32_t gw = (uint32_t)xcd_contiguous((int)blockIdx.x, (int)gridDim.x) * 4u + (threadIdx.x >> 6);   // wave of the grid
+    const uint32_t x0 = (gw % segs) * 256u + (threadIdx.x & 63u), y0 = (gw / segs) * ROWS;
+    const float sd = 360.0f / (float)n;                            // height_scale * diff = 180 * 2 / N
+    float above[4], centre[4];
+    {
+        const float* pa = plane + (size_t)((y0 + un - 1u) & mask) * un + x0;
+        const float* pc = plane + (size_t)y0 * un + x0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { above[k] = pa[64 * k]; centre[k] = pc[64 * k]; }
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const uint32_t y = y0 + (uint32_t)r;
+        const float* pb = plane + (size_t)((y + 1u) & mask) * un + x0;
+        const float* prow = plane + (size_t)y * un;
+        float below[4], left[4], right[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            below[k] = pb[64 * k];
+            left[k] = prow[(x0 + 64u * k + un - 1u) & mask];
+            right[k] = prow[(x0 + 64u * k + 1u) & mask];
+        }
+        float4* o = normals + (size_t)y * un + x0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            store_float4_nt(o + 64 * k, normal_from_differences(right[k] - left[k], below[k] - above[k], sd));
+            above[k] = centre[k];
+            centre[k] = below[k];
+        }
     }
 }
 

@@ -118,7 +118,22 @@ class OceanDevice:
         self._check(lib.ocean_read_normals(self._ctx, out.ctypes.data))
         return out
 
-    # -- readback / injection ----------------------------------------------------------------------
+    def set_frame_normals(self, source_channel):
+        """The frame with its normal field as one workload (BASELINE config 3): channel 0..2 on, None / -1 off.  While on,
+        every frame is followed by the normal-field kernel, fed by a dense plane of the source channel that pass 2 stores
+        (ocean_set_frame_normals)."""
+        self._check(load_library().ocean_set_frame_normals(self._ctx, -1 if source_channel is None else int(source_channel)))
+
+    @property
+    def frame_normals(self) -> int:
+        return int(load_library().ocean_frame_normals(self._ctx))
+
+    def read_normals(self) -> np.ndarray:
+        """The normal field the last frame (set_frame_normals) or normals() call left in HBM -> float32 [N, N, 4]."""
+        n = self.resolution
+        out = np.empty((n, n, 4), dtype=np.float32)
+        self._check(load_library().ocean_read_normals(self._ctx, out.ctypes.data))
+        return out
 
     # -- SURVEY 8f #2: vertex-stage positions (shader/ocean.vert:21-25) ----------------------------------
     def positions(self, verts: int = 128, offset=(0.0, 0.0), stream=None) -> np.ndarray:
@@ -195,6 +210,15 @@ class OceanDevice:
         arr = [(ctypes.c_float * int(frames))() for _ in range(3)]
         self._check(load_library().ocean_frame_times(self._ctx, int(frames), float(t0), float(dt), *arr))
         return tuple([float(v) for v in a] for a in arr)
+
+    def frame_times_ex(self, frames: int, t0: float = 0.0, dt: float = 1.0 / 60.0):
+        """(pass1_ms, pass2_ms, normals_ms, period_ms) per frame; normals_ms is None unless the frame carries the normal
+        field (ocean_frame_times_ex)."""
+        nrm = self.frame_normals >= 0
+        arr = [(ctypes.c_float * int(frames))() for _ in range(4)]
+        args = [arr[0], arr[1], arr[2] if nrm else None, arr[3]]
+        self._check(load_library().ocean_frame_times_ex(self._ctx, int(frames), float(t0), float(dt), *args))
+        return tuple(None if a is None else [float(v) for v in a] for a in args)
 
     def _profile(self, fn, time):
         cap = 16

@@ -35,10 +35,14 @@
 extern "C" {
 #endif
 
-/* 2: + ocean_set_intermediate, ocean_intermediate, ocean_tile_exchange_bytes, ocean_tile_pass1, ocean_tile_pass2 (additive);
- *    readbacks wait for the whole device once a dispatch has been put on a caller stream
- * 3: + ocean_frame_times, ocean_time_frame_batches (additive); ocean_sync and ocean_context_destroy honour caller streams like the readbacks */
-#define OCEAN_ABI_VERSION 3
+/* ABI history (additive throughout: no entry point has changed its signature or meaning)
+ * 2: + ocean_checksum_displacement, ocean_pack_displacement, ocean_packed_bytes, the ocean_shard_* family;
+ *    + ocean_set_intermediate, ocean_intermediate, ocean_tile_exchange_bytes, ocean_tile_pass1, ocean_tile_pass2 (shipped under
+ *    the same number in round 3); readbacks wait for the whole device once a dispatch has been put on a caller stream
+ * 3: + ocean_frame_times, ocean_time_frame_batches; ocean_sync and ocean_context_destroy honour caller streams like the readbacks
+ * 4: + ocean_set_frame_normals, ocean_frame_normals, ocean_normals_device_ptr, ocean_frame_times_ex (the frame with the normal
+ *    field as one workload); ocean_time_frame_batches also bounds frames_per_batch (<= 4096) */
+#define OCEAN_ABI_VERSION 4
 
 /* ---- status codes ------------------------------------------------------------------------- */
 #define OCEAN_OK 0
@@ -160,6 +164,16 @@ int32_t ocean_intermediate(const OceanContext* ctx);
  * 1 = height.  Result: float4[N*N] = (n.x, n.y, n.z, 0), read with ocean_read_normals. */
 int32_t ocean_normals(OceanContext* ctx, int32_t source_channel, void* stream);
 int32_t ocean_read_normals(OceanContext* ctx, float* host_xyz0 /* N*N*4 */);
+/* The frame WITH its normal field as one workload (BASELINE config 3: "height + displacement + normal"; north_star lists the
+ * normal field among the path's outputs).  source_channel 0..2 switches it on, -1 (the default) off.  While on, every frame
+ * this context launches -- ocean_frame, ocean_frame_ex, the ocean_time_* / ocean_frame_times* loops -- is followed on the
+ * same stream by the normal-field kernel: the fused pass 2 additionally stores the source channel as a dense fp32 plane
+ * (4 B/texel, the very floats it writes into the map), and the kernel differentiates that plane instead of the RGBA texels
+ * (4 + 16 instead of 16 + 16 B/texel); with non-reference quirks (staged dispatches) it reads the map like ocean_normals.
+ * Same arithmetic, bit-identical normals either way.  Allocates N*N*20 bytes on first use. */
+int32_t ocean_set_frame_normals(OceanContext* ctx, int32_t source_channel);
+int32_t ocean_frame_normals(const OceanContext* ctx);               /* -1..2; < -1: error status */
+void* ocean_normals_device_ptr(OceanContext* ctx);                  /* float4[N*N] in HBM, NULL before the first use */
 
 /* the vertex stage's use of the map (shader/ocean.vert:21-25) as a compute pass: a verts x verts
  * patch grid (src/render.rs:494-508; the reference's HALF_RESOLUTION is 128) with a_Pos = (x, 0, z) and
@@ -200,7 +214,7 @@ void* ocean_stream(OceanContext* ctx);                            /* the context
 /* ---- measurement (HIP events on the stream the kernels run on) -------------------------------- */
 /* Runs `frames` frames (time = t0 + i*dt) on the context stream between two events; *out_ms = total. */
 int32_t ocean_time_frames(OceanContext* ctx, int32_t frames, float t0, float dt, float* out_ms);
-/* `batches` (<= 4096) x `frames_per_batch` fused frames back to back with one stream event between batches and one sync at
+/* `batches` (<= 4096) x `frames_per_batch` (<= 4096) fused frames back to back with one stream event between batches and one sync at
  * the end: batch_ms[b] = duration of batch b.  The distribution SURVEY 8d asks for (median, p10 / p90 of a frame in an
  * undisturbed loop); the reference's only timing is an EMA of the vsync-bound frame delta (src/lib.rs:146-148). */
 int32_t ocean_time_frame_batches(OceanContext* ctx, int32_t batches, int32_t frames_per_batch, float t0, float dt,
@@ -212,6 +226,10 @@ int32_t ocean_time_frame_batches(OceanContext* ctx, int32_t batches, int32_t fra
  * N = 4096), so the frame's own distribution comes from ocean_time_frame_batches. */
 int32_t ocean_frame_times(OceanContext* ctx, int32_t frames, float t0, float dt, float* pass1_ms, float* pass2_ms,
                           float* period_ms);
+/* ... and normals_ms[i] = the normal-field kernel of frame i when the frame carries one (ocean_set_frame_normals; otherwise
+ * normals_ms must be NULL: OCEAN_E_STATE); the period's last entry then ends with that kernel. */
+int32_t ocean_frame_times_ex(OceanContext* ctx, int32_t frames, float t0, float dt, float* pass1_ms, float* pass2_ms,
+                             float* normals_ms, float* period_ms);
 /* Per-kernel durations of ONE frame (begin/end timestamps of each dispatch, as rocprofv3 reports them; the
  * frame runs behind two untimed ones): names/ms arrays of capacity `cap`; returns count via *out_n. */
 int32_t ocean_profile_frame(OceanContext* ctx, float time, int32_t cap, const char** names, float* ms,

@@ -149,7 +149,7 @@ def quantize_f16(h0):
 
 
 def frame_half(h0, omega, time, L=1000.0, layout="p2", return_inter=False, spectrum_fp16=False, P=None, split=False, bshift=None,
-               inter16=False):
+               inter16=False, plane_channel=None):
     """split=True: every line as two interleaved N/2 transforms (the N = 8192 geometry, P = 2; with P=1 the N = 16384 geometry:
     one column per pass-1 workgroup); inter16=True (split, P = 2 only): the 16-bit block-floating intermediate (OCEAN_INTER_BFP16)."""
     n = h0.shape[0]
@@ -170,10 +170,27 @@ def frame_half(h0, omega, time, L=1000.0, layout="p2", return_inter=False, spect
     assert split or not inter16
     scales = np.full(3 * (n // 64) * (n // 4), np.nan, np.float32) if inter16 else None
     psel = (23 if inter16 else (21 if P == 1 else 22)) if split else int(P)
+    # pass 2 runs as its PLANE instance (the frame with the normal field): the source channel as a dense fp32 plane
+    plane = np.full((n, n), np.nan, np.float32)
+    lib().emu_set_plane.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib().emu_set_plane(_p(plane), int(plane_channel or 0))
     assert lib().emu_frame_half(n, psel, _p(h0T), int(spectrum_fp16), descale, _p(omT), _p(inter),
                                 _p(nyq), _p(out), _p(tw), sx, sy, fs, bshift, time, L, _p(scales) if inter16 else None) == 0
+    lib().emu_set_plane(None, 0)
+    if plane_channel is not None:
+        return out, plane
     if return_inter:
         return out, inter, nyq, (P, (sx, sy, fs, bshift))
+    return out
+
+
+def normals_plane(plane):
+    """k_normals_plane: the normal field from the dense source-channel plane of the fused pass 2."""
+    plane = np.ascontiguousarray(plane, np.float32)
+    n = plane.shape[0]
+    out = np.full((n, n, 4), np.nan, np.float32)
+    lib().emu_normals_plane.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    assert lib().emu_normals_plane(n, _p(plane), _p(out)) == 0
     return out
 
 

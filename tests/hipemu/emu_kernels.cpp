@@ -51,6 +51,9 @@ template <int N> static int run_fft_lines(int col, c32* data, const c32* tw) {
     else emu_launch(G::row_grid, G::row_threads, [&] { k_fft_lines<N, G::E, G::ROW_LPW, false>(data, tw); });
     return 0;
 }
+// (pass 2 always runs as its PLANE instance here: the map must not depend on it, and emu_plane checks the plane)
+static float* plane = nullptr;
+static int plane_channel = 0;
 template <int N, int PSEL> static int run_half_p(const void* h0T, int f16, float descale, const float* omT, c32* inter, c32* nyq,
                                                  float4* out, const c32* tw, InterLayout lay, float time, float L) {
     using G = Geo<N, PSEL>;
@@ -59,7 +62,7 @@ template <int N, int PSEL> static int run_half_p(const void* h0T, int f16, float
     else emu_launch(G::half_grid1, G::half_threads1,
                     [&] { k_half_pass1<N, G::E1, G::P, false, G::dma, G::fpar>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L, 0); });
     emu_launch(G::half_grid2, G::half_threads2,
-               [&] { k_half_pass2<N, G::E2, CHUNK_W, G::R2h, G::p2_group, G::ppar>(inter, out, tw, lay); });
+               [&] { k_half_pass2<N, G::E2, CHUNK_W, G::R2h, G::p2_group, G::ppar, false, true>(inter, out, tw, lay, plane, plane_channel); });
     return 0;
 }
 template <int N, bool I16, int PS = 2> static int run_half_split(const void* h0T, int f16, float descale, const float* omT, c32* inter, c32* nyq,
@@ -72,7 +75,7 @@ template <int N, bool I16, int PS = 2> static int run_half_split(const void* h0T
                     [&] { k_half_pass1_split<N, G::E1S, G::P, false, I16>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L, 0, scales); });
     // the split geometry's pass 2 is the real-output kernel, which reads its column-major chunks (N >= 8192 in the product)
     if constexpr (G::real_threads2 % 16 == 0)
-        emu_launch(N, G::real_threads2, [&] { k_half_pass2_real<N, G::E, CHUNK_W, G::p2_group, false, I16>(inter, out, tw, lay, scales); });
+        emu_launch(N, G::real_threads2, [&] { k_half_pass2_real<N, G::E, CHUNK_W, G::p2_group, false, I16, 4, true>(inter, out, tw, lay, scales, plane, plane_channel); });
     else return -7;
     return 0;
 }
@@ -114,7 +117,7 @@ template <int N, int PSEL> static int run_tile_pass2(int world, int parts, const
     if (!G::tile_supported(world, parts)) return -5;
     const InterLayout lay = G::tile_layout(world, parts);
     emu_launch((N / world) / G::R2h, G::half_threads2,
-               [&] { k_half_pass2<N, G::E2, CHUNK_W, G::R2h, G::p2_group, G::ppar, true>(recv, out, tw, lay); });
+               [&] { k_half_pass2<N, G::E2, CHUNK_W, G::R2h, G::p2_group, G::ppar, true>(recv, out, tw, lay, nullptr, 0); });
     return 0;
 }
 // ... with the split geometry (what ocean_tile_pass1 / ocean_tile_pass2 launch at N >= 8192: k_half_pass1_split, k_half_pass2_real<SHARD>)
@@ -131,7 +134,7 @@ template <int N, int PS> static int run_tile_split(int what, int rank, int world
             if (f16) emu_launch(groups, G::split_threads1, [&] { k_half_pass1_split<N, G::E1S, G::P, true, false>(h0T, descale, omT, buf, nyq, tw, lay, time, L, x_group0, nullptr); });
             else emu_launch(groups, G::split_threads1, [&] { k_half_pass1_split<N, G::E1S, G::P, false, false>(h0T, 1.0f, omT, buf, nyq, tw, lay, time, L, x_group0, nullptr); });
         } else {
-            emu_launch(N / world, G::real_threads2, [&] { k_half_pass2_real<N, G::E, CHUNK_W, G::p2_group, true>(buf, out, tw, lay, nullptr); });
+            emu_launch(N / world, G::real_threads2, [&] { k_half_pass2_real<N, G::E, CHUNK_W, G::p2_group, true>(buf, out, tw, lay, nullptr, nullptr, 0); });
         }
         return 0;
     }
@@ -272,6 +275,16 @@ int emu_normals(int n, const float* rgba, float* normals, int channel) {
     else if (rows == 2) emu_launch(grid, 256, [&] { k_normals<2>((const float4*)rgba, (float4*)normals, n, channel); });
     else if (rows == 4) emu_launch(grid, 256, [&] { k_normals<4>((const float4*)rgba, (float4*)normals, n, channel); });
     else emu_launch(grid, 256, [&] { k_normals<8>((const float4*)rgba, (float4*)normals, n, channel); });
+    return 0;
+}
+// where the fused pass 2 of the following emu_frame_half calls stores its source-channel plane (n * n floats; must be set)
+int emu_set_plane(float* p, int channel) { plane = p; plane_channel = channel; return 0; }
+int emu_normals_plane(int n, const float* src_plane, float* normals) {
+    const int rows = normals_plane_rows(n);             // as launch_normals_plane of csrc/ocean_api.hip
+    const int grid = (n / 256) * (n / rows) / 4;
+    if (rows == 2) emu_launch(grid, 256, [&] { k_normals_plane<2>(src_plane, (float4*)normals, n); });
+    else if (rows == 4) emu_launch(grid, 256, [&] { k_normals_plane<4>(src_plane, (float4*)normals, n); });
+    else emu_launch(grid, 256, [&] { k_normals_plane<8>(src_plane, (float4*)normals, n); });
     return 0;
 }
 int emu_propagate(int n, const float* h0, const float* omega, float* h, float* dx, float* dz, float time, float L, unsigned quirks) {

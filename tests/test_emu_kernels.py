@@ -85,6 +85,18 @@ def test_emu_normals(ref_inputs_256, channel):
     assert np.allclose(np.linalg.norm(got[..., :3], axis=-1), 1.0, atol=1e-6) and np.all(got[..., 3] == 0)
 
 
+@pytest.mark.parametrize("n,channel,split", [(256, 0, False), (256, 1, False), (512, 2, False), (1024, 0, False), (512, 0, True), (1024, 1, True)])
+def test_emu_frame_with_normal_plane(n, channel, split, ref_inputs, ref_inputs_256):
+    """The frame with the normal field (ocean_set_frame_normals): the PLANE instances of both pass-2 kernels store the very floats of
+    the map's source channel, and k_normals_plane (every rows-per-wave variant) gives the normals of k_normals bit for bit."""
+    h0, om = ref_inputs_256 if n == 256 else (ref_inputs if n == 512 else g.synth.make_inputs(n, seed=11))
+    rgba, plane = emu.frame_half(h0, om, 2.0, plane_channel=channel, split=split)
+    assert np.array_equal(plane, rgba[..., channel])
+    got = emu.normals_plane(plane)
+    assert np.array_equal(got, emu.normals(rgba, channel))
+    assert np.abs(got - oc.normals_literal(rgba, channel)).max() <= 2e-6
+
+
 def test_emu_split_line_geometry_block_layout(ref_inputs):
     """The split kernels (N = 8192 geometry) with the intermediate in blocks of 8 chunk rows."""
     h0, om = ref_inputs

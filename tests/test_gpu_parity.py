@@ -339,6 +339,59 @@ def test_normal_field(r512, ref_inputs, n, channel):
             r.dispose()
 
 
+@pytest.mark.parametrize("n,channel,fp16", [(256, 0, False), (512, 1, False), (1024, 2, False), (2048, 0, False), (2048, 1, False),
+                                            (4096, 0, False), (8192, 0, True), (8192, 1, False)])
+def test_frame_with_normal_field(n, channel, fp16):
+    """BASELINE config 3 as ONE workload (ocean_set_frame_normals): pass 2 also stores the source channel as a dense plane and the
+    normal-field kernel differentiates that plane.  The map is the frame's bit for bit, and the normals are ocean_normals'
+    (k_normals on the RGBA map) bit for bit -- every rows-per-wave variant, both pass-2 kernels."""
+    h0, om = g.synth.make_inputs(n, seed=21)
+    d = g.OceanDevice(n)
+    try:
+        d.upload_spectrum(h0, om, spectrum_fp16=fp16)
+        d.frame(2.0)
+        want_sum = d.checksum()
+        want = d.normals(channel)                                # k_normals from the RGBA map
+        d.set_frame_normals(channel)
+        assert d.frame_normals == channel
+        d.frame(2.0)
+        assert d.checksum() == want_sum             # the PLANE instance writes the same map
+        got = d.read_normals()
+        assert np.array_equal(got, want)
+        rgba = d.read_displacement()
+        assert np.abs(got - oc.normals_literal(rgba, channel)).max() <= 1e-5
+        d.frame(3.0)                                             # another frame, another field
+        got3 = d.read_normals()
+        d.set_frame_normals(None)
+        assert d.frame_normals == -1
+        assert np.array_equal(got3, d.normals(channel)) and not np.array_equal(got3, got)
+        p1, p2, nrm, per = d.frame_times_ex(3)
+        assert nrm is None and len(p1) == 3
+    finally:
+        d.destroy()
+
+
+def test_frame_with_normal_field_staged_quirks_and_errors():
+    """With non-reference quirks the frame is the staged dispatches, and the normal field comes from the map itself."""
+    n = 512
+    h0, om = g.synth.make_inputs(n, seed=22)
+    d = g.OceanDevice(n)
+    try:
+        d.upload_spectrum(h0, om)
+        with pytest.raises(g.OceanError):
+            d.set_frame_normals(3)
+        d.set_quirks(0)
+        d.set_frame_normals(1)
+        d.frame(1.0)
+        got = d.read_normals()
+        assert np.array_equal(got, d.normals(1))
+        d.set_quirks(g.QUIRKS_REFERENCE)
+        p1, p2, nrm, per = d.frame_times_ex(4)
+        assert len(nrm) == 4 and all(v > 0 for v in nrm)
+    finally:
+        d.destroy()
+
+
 @pytest.mark.parametrize("verts,offset", [(128, (0.0, 0.0)), (128, (127.0, 127.0)), (257, (0.0, 0.0))])
 def test_vertex_positions(r512, ref_inputs, verts, offset):
     """the vertex stage's positions (shader/ocean.vert:21-25; patch grid and offsets of
