@@ -39,14 +39,14 @@ def test_device_checksum_matches_numpy_and_sees_one_bit():
 
 
 CASES = [(256, False), (512, False), (512, True), (1024, False), (2048, False), (2048, True), (4096, False),
-         (4096, True), (8192, False), (8192, True)]
+         (4096, True), (8192, False), (8192, True), (16384, False)]   # 16384: the ring's three-slot, uneven-vmcnt geometry
 
 
 @pytest.mark.parametrize("n,f16", CASES)
 def test_200_consecutive_frames_are_bit_identical(n, f16):
     """Fused and staged: frame(t) interleaved with frames at other times (so that stale LDS / intermediate contents
     would differ), checksummed on the device after every repetition."""
-    reps_fused, reps_staged = 200, (200 if n <= 2048 else (60 if n == 4096 else 24))
+    reps_fused, reps_staged = (200 if n <= 8192 else 60), (200 if n <= 2048 else (60 if n == 4096 else (24 if n == 8192 else 0)))
     h0, om = g.synth.make_inputs(n, seed=n + 1)
     r = g.OceanRenderer(n)
     try:
@@ -55,13 +55,14 @@ def test_200_consecutive_frames_are_bit_identical(n, f16):
         t = 2.75
         d.frame(t)
         want = d.checksum()
-        assert want == host_checksum(d.read_displacement())
+        if n <= 8192:                                                 # (the device checksum against numpy; 4 GiB of map at 16384: not needed again)
+            assert want == host_checksum(d.read_displacement())
         for i in range(reps_fused):
             if i % 3 == 1:
                 d.frame(0.01 * i)                                     # another frame in between, not synchronised
             d.frame(t)
             assert d.checksum() == want, f"fused frame {i} differs (N={n}, f16={f16})"
-        if not f16:                                                   # the staged path reads the fp32 (dequantised) spectrum either way
+        if not f16 and reps_staged:                                   # the staged path reads the fp32 (dequantised) spectrum either way
             r.render(t)
             want_s = d.checksum()
             for i in range(reps_staged):
@@ -100,13 +101,13 @@ import json, os, sys
 sys.path.insert(0, sys.argv[1])
 import gfx_ocean_amd as g
 res = {}
-for n in [int(v) for v in os.environ.get("OCEAN_RACE_SIZES", "256,512,1024,2048,4096,8192").split(",")]:
-    for f16 in (False, True):
+for n in [int(v) for v in os.environ.get("OCEAN_RACE_SIZES", "256,512,1024,2048,4096,8192,16384").split(",")]:
+    for f16 in ((False, True) if n <= 8192 else (False,)):      # 16384: the ring with three slots and uneven per-wave vmcnt budgets
         h0, om = g.synth.make_inputs(n, seed=n + 1)
         r = g.OceanRenderer(n)
         r.upload(h0, om, spectrum_fp16=f16)
         sums = set()
-        for i in range(int(sys.argv[2])):
+        for i in range(int(sys.argv[2]) if n <= 8192 else max(2, int(sys.argv[2]) // 2)):
             r.render_fused(2.75)
             sums.add(r.device.checksum())
         key = f"{n}:{int(f16)}"

@@ -411,7 +411,7 @@ def test_gpu_fused_shard_16384_every_rank_against_the_c_oracle():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,world,parts", [(2048, 4, 1), (2048, 2, 4), (4096, 8, 2), (512, 2, 2)])
+@pytest.mark.parametrize("n,world,parts", [(2048, 4, 1), (2048, 2, 4), (4096, 8, 2), (512, 2, 2), (16384, 2, 2)])
 def test_gpu_fused_shard_equals_the_fused_frame_bit_for_bit(n, world, parts):
     """Sharding -- and cutting the exchange into pipelined parts -- must not change a single bit: the same kernels on
     the same columns and rows, only the addresses of the intermediate differ."""
