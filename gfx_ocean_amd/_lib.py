@@ -22,6 +22,7 @@ SYMBOLS = [
     "ocean_fft_init", "ocean_fft_destroy", "ocean_propagation_init",
     "ocean_propagation_destroy", "ocean_correction_init", "ocean_correction_destroy", "ocean_propagate",
     "ocean_fft_rows", "ocean_fft_cols", "ocean_correct", "ocean_frame", "ocean_frame_ex", "ocean_sync",
+    "ocean_frame_batch", "ocean_batch_device_ptr", "ocean_read_batch_displacement", "ocean_time_frame_batch",
     "ocean_set_quirks", "ocean_quirks", "ocean_set_intermediate", "ocean_intermediate",
     "ocean_normals", "ocean_read_normals", "ocean_set_frame_normals", "ocean_frame_normals", "ocean_normals_device_ptr", "ocean_positions", "ocean_read_positions",
     "ocean_checksum_displacement", "ocean_packed_bytes", "ocean_pack_displacement",
@@ -104,6 +105,10 @@ def load_library():
         "ocean_frame": (i32, [vp, f32, vp]),
         "ocean_frame_ex": (i32, [vp, ctypes.POINTER(PropagateLocalsC), vp]),
         "ocean_sync": (i32, [vp]),
+        "ocean_frame_batch": (i32, [vp, f32, f32, i32, vp, ctypes.c_int64, vp]),
+        "ocean_batch_device_ptr": (vp, [vp]),
+        "ocean_read_batch_displacement": (i32, [vp, i32, vp]),
+        "ocean_time_frame_batch": (i32, [vp, i32, i32, f32, f32, ctypes.POINTER(f32)]),
         "ocean_set_quirks": (i32, [vp, ctypes.c_uint32]),
         "ocean_quirks": (ctypes.c_uint32, [vp]),
         "ocean_set_intermediate": (i32, [vp, i32]),

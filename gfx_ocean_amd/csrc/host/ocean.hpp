@@ -41,6 +41,27 @@ public:
         check(ocean_upload_spectrum(ctx_, reinterpret_cast<const float*>(h0.data()), omega.data()));
     }
     void frame(float time, void* stream = nullptr) { check(ocean_frame(ctx_, time, stream)); }
+    // K time steps t0 + dt * i of this tile, one launch pair at N <= 1024 (library-owned maps; ocean_frame_batch)
+    void frame_batch(float t0, float dt, int count, void* stream = nullptr) { check(ocean_frame_batch(ctx_, t0, dt, count, nullptr, 0, stream)); }
+    std::vector<float> read_batch_displacement(int index) {
+        std::vector<float> out((size_t)resolution() * resolution() * 4);
+        check(ocean_read_batch_displacement(ctx_, index, out.data()));
+        return out;
+    }
+    // the frame with its normal field (shader/ocean.frag:50-66) as one workload: channel 0..2 on, -1 off
+    void set_frame_normals(int source_channel) { check(ocean_set_frame_normals(ctx_, source_channel)); }
+    std::vector<float> read_normals() {
+        std::vector<float> out((size_t)resolution() * resolution() * 4);
+        check(ocean_read_normals(ctx_, out.data()));
+        return out;
+    }
+    // measurement (HIP events on the context stream)
+    float time_frames(int frames, float t0 = 0.0f, float dt = 1.0f / 60.0f) { float ms = 0; check(ocean_time_frames(ctx_, frames, t0, dt, &ms)); return ms; }
+    std::vector<float> time_frame_batches(int batches, int frames_per_batch, float t0 = 0.0f, float dt = 1.0f / 60.0f) {
+        std::vector<float> ms((size_t)(batches > 0 ? batches : 0));
+        check(ocean_time_frame_batches(ctx_, batches, frames_per_batch, t0, dt, ms.data()));
+        return ms;
+    }
     // SURVEY 8a Q1/Q2 switches; OCEAN_QUIRKS_REFERENCE (default) = the shipped shaders
     void set_quirks(uint32_t quirks) { check(ocean_set_quirks(ctx_, quirks)); }
     uint32_t quirks() const { return ocean_quirks(ctx_); }

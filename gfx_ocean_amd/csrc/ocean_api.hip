@@ -88,6 +88,13 @@ struct OceanContext {
     // pass 2 also stores the source channel as a dense fp32 plane, which k_normals_plane differentiates behind it.
     int frame_normals = -1;       // source channel 0..2, or -1: the frame is the map alone
     float* plane = nullptr;       // N x N floats, allocated by ocean_set_frame_normals
+    // ocean_frame_batch (N <= 1024: K time steps in one launch pair): K intermediates + Nyquist scratches, and K maps when the
+    // caller brings no buffer; grown on demand
+    c32* batch_inter = nullptr;
+    c32* batch_nyq = nullptr;
+    int32_t batch_cap = 0;
+    float4* batch_out = nullptr;
+    int32_t batch_out_cap = 0;
     float4* positions = nullptr;  // ocean_positions: verts x verts float4, (re)allocated on demand
     int32_t position_verts = 0;
     unsigned long long* checksum_acc = nullptr;   // ocean_checksum_displacement
@@ -197,17 +204,20 @@ template <int N> struct Launch {
     }
     // Fused pass 1 on the column groups [x_group0, x_group0 + groups) of the half spectrum, written in layout `lay` to
     // `inter` (the context's intermediate for ocean_frame; the all-to-all send buffer of a sharded tile).
+    // `count` > 1 (N <= 1024 only: batched_launches<N>): that many time steps time, time + batch.dt, ... in this one launch.
     static void pass1_on(OceanContext* c, float time, float domain, c32* inter, const InterLayout& lay, int groups, int x_group0,
-                         hipStream_t s, Timing t) {
+                         hipStream_t s, Timing t, c32* nyq = nullptr, FrameBatch batch = FrameBatch(), int count = 1, bool allow_inter16 = true) {
+        if (!nyq) nyq = c->nyq;
+        const bool inter16 = c->inter16 && allow_inter16;          // (the sharded tile always ships the fp32 intermediate)
         const float descale = c->h0_f16 ? std::ldexp(1.0f, -c->scale_log2) : 1.0f;
         const void* h0T = c->h0T;
         const float* omT = c->omegaT;
         const c32* tw = c->tw;
         if constexpr (SPLIT) {
             const dim3 g(groups), b(H::split_threads1);
-            float* scales = c->inter16 ? c->inter_scale : nullptr;   // opt-in precision mode (ocean_set_intermediate)
+            float* scales = inter16 ? c->inter_scale : nullptr;      // opt-in precision mode (ocean_set_intermediate)
             if constexpr (I16_BUILT) {
-                if (c->inter16) {
+                if (inter16) {
                     if (c->h0_f16) launch(pass1_split_kernel<true, true>(), g, b, H::split_lds1, s, t, h0T, descale, omT, inter, c->nyq, tw, lay, time, domain, x_group0, scales);
                     else launch(pass1_split_kernel<false, true>(), g, b, H::split_lds1, s, t, h0T, descale, omT, inter, c->nyq, tw, lay, time, domain, x_group0, scales);
                     return;
@@ -216,20 +226,19 @@ template <int N> struct Launch {
             if (c->h0_f16) launch(pass1_split_kernel<true, false>(), g, b, H::split_lds1, s, t, h0T, descale, omT, inter, c->nyq, tw, lay, time, domain, x_group0, scales);
             else launch(pass1_split_kernel<false, false>(), g, b, H::split_lds1, s, t, h0T, descale, omT, inter, c->nyq, tw, lay, time, domain, x_group0, scales);
         } else {
-            const dim3 g(groups), b(H::half_threads1);
-            if (c->h0_f16) launch(pass1_kernel<true>(), g, b, H::half_lds1, s, t, h0T, descale, omT, inter, c->nyq, tw, lay, time, domain, x_group0);
-            else launch(pass1_kernel<false>(), g, b, H::half_lds1, s, t, h0T, descale, omT, inter, c->nyq, tw, lay, time, domain, x_group0);
+            const dim3 g(groups, count), b(H::half_threads1);
+            if (c->h0_f16) launch(pass1_kernel<true>(), g, b, H::half_lds1, s, t, h0T, descale, omT, inter, nyq, tw, lay, time, domain, x_group0, batch);
+            else launch(pass1_kernel<false>(), g, b, H::half_lds1, s, t, h0T, descale, omT, inter, nyq, tw, lay, time, domain, x_group0, batch);
         }
     }
     static void pass1(OceanContext* c, float time, float domain, hipStream_t s, Timing t = Timing()) {
         pass1_on(c, time, domain, c->inter, c->lay_h, H::half_grid1, 0, s, t);
     }
-    // Pass 2 into the context's map; with the normal field switched on (ocean_set_frame_normals) the PLANE instances, which
-    // also store the source channel as the dense plane k_normals_plane reads.
-    static void pass2(OceanContext* c, hipStream_t s, Timing t = Timing()) {
-        const c32* inter = c->inter;
+    // Pass 2 from `inter` into the map `out`; with the normal field switched on (ocean_set_frame_normals) the PLANE instances,
+    // which also store the source channel as the dense plane k_normals_plane reads.  `count` > 1: a batch (pass1_on).
+    static void pass2_on(OceanContext* c, const c32* inter, float4* out, hipStream_t s, Timing t, FrameBatch batch = FrameBatch(), int count = 1) {
         const c32* tw = c->tw;
-        const bool plane = c->frame_normals >= 0;
+        const bool plane = c->frame_normals >= 0 && count == 1;
         float* pl = c->plane;
         const int ch = c->frame_normals;
         if constexpr (REAL2) {
@@ -237,29 +246,29 @@ template <int N> struct Launch {
             if constexpr (I16_BUILT) {
                 if (c->inter16) {
                     const float* sc = c->inter_scale;
-                    if (plane) launch(pass2_real_kernel<false, true, true>(), g, b, H::real_lds2, s, t, inter, c->out, tw, c->lay_h, sc, pl, ch);
-                    else launch(pass2_real_kernel<false, true>(), g, b, H::real_lds2, s, t, inter, c->out, tw, c->lay_h, sc, (float*)nullptr, 0);
+                    if (plane) launch(pass2_real_kernel<false, true, true>(), g, b, H::real_lds2, s, t, inter, out, tw, c->lay_h, sc, pl, ch);
+                    else launch(pass2_real_kernel<false, true>(), g, b, H::real_lds2, s, t, inter, out, tw, c->lay_h, sc, (float*)nullptr, 0);
                     return;
                 }
             }
-            if (plane) launch(pass2_real_kernel<false, false, true>(), g, b, H::real_lds2, s, t, inter, c->out, tw, c->lay_h, (const float*)nullptr, pl, ch);
-            else launch(pass2_real_kernel<false, false>(), g, b, H::real_lds2, s, t, inter, c->out, tw, c->lay_h, (const float*)nullptr, (float*)nullptr, 0);
+            if (plane) launch(pass2_real_kernel<false, false, true>(), g, b, H::real_lds2, s, t, inter, out, tw, c->lay_h, (const float*)nullptr, pl, ch);
+            else launch(pass2_real_kernel<false, false>(), g, b, H::real_lds2, s, t, inter, out, tw, c->lay_h, (const float*)nullptr, (float*)nullptr, 0);
         } else {
-            const dim3 g(H::half_grid2), b(H::half_threads2);
-            if (plane) launch(pass2_kernel<false, true>(), g, b, H::half_lds2, s, t, inter, c->out, tw, c->lay_h, pl, ch);
-            else launch(pass2_kernel<false>(), g, b, H::half_lds2, s, t, inter, c->out, tw, c->lay_h, (float*)nullptr, 0);
+            const dim3 g(H::half_grid2, count), b(H::half_threads2);
+            if (plane) launch(pass2_kernel<false, true>(), g, b, H::half_lds2, s, t, inter, out, tw, c->lay_h, pl, ch, batch);
+            else launch(pass2_kernel<false>(), g, b, H::half_lds2, s, t, inter, out, tw, c->lay_h, (float*)nullptr, 0, batch);
         }
     }
+    static void pass2(OceanContext* c, hipStream_t s, Timing t = Timing()) { pass2_on(c, c->inter, c->out, s, t); }
+    static constexpr bool BATCHED = batched_launches<N>;
     // ---- one tile sharded over `world` GPUs (ocean_tile_pass1 / ocean_tile_pass2): the same kernels on this rank's
     // block of half-spectrum columns (pass 1, writing the all-to-all send buffer) and block of rows (pass 2, reading the
     // receive buffer).
     static bool tile_supported(int world, int parts) { return H::tile_supported(world, parts); }
     static void tile_pass1(OceanContext* c, float time, float domain, int rank, int world, int part, int parts, c32* send, hipStream_t s) {
         const int groups = (N / 2 / world / parts) / H::P;
-        const bool i16 = c->inter16;
-        c->inter16 = false;                                        // (the 16-bit intermediate is not combined with the sharded tile)
-        pass1_on(c, time, domain, send, H::tile_layout(world, parts), groups, (rank * parts + part) * groups, s, Timing());
-        c->inter16 = i16;
+        pass1_on(c, time, domain, send, H::tile_layout(world, parts), groups, (rank * parts + part) * groups, s, Timing(), nullptr, FrameBatch(), 1,
+                 /*allow_inter16=*/false);                         // (the 16-bit intermediate is not combined with the sharded tile)
     }
     static void tile_pass2(OceanContext* c, int world, int parts, const c32* recv, float4* out_rows, hipStream_t s) {
         const InterLayout lay = H::tile_layout(world, parts);
@@ -268,7 +277,7 @@ template <int N> struct Launch {
         if constexpr (REAL2)
             hipLaunchKernelGGL((pass2_real_kernel<true, false>()), dim3(rows), dim3(H::real_threads2), H::real_lds2, s, recv, out_rows, tw, lay, (const float*)nullptr, (float*)nullptr, 0);
         else
-            hipLaunchKernelGGL((pass2_kernel<true>()), dim3(rows / H::R2h), dim3(H::half_threads2), H::half_lds2, s, recv, out_rows, tw, lay, (float*)nullptr, 0);
+            hipLaunchKernelGGL((pass2_kernel<true>()), dim3(rows / H::R2h), dim3(H::half_threads2), H::half_lds2, s, recv, out_rows, tw, lay, (float*)nullptr, 0, FrameBatch());
     }
     static void stage_rows(OceanContext* c, int f, hipStream_t s) {
         if constexpr (G::stage_chunked)
@@ -412,7 +421,7 @@ void free_all(OceanContext* c) {
     auto f = [](void* p) { if (p) (void)hipFree(p); };
     f(c->h0); f(c->omega); f(c->field[0]); f(c->field[1]); f(c->field[2]);
     f(c->cfield[0]); f(c->cfield[1]); f(c->cfield[2]);
-    f(c->h0T); f(c->omegaT); f(c->inter); f(c->nyq); f(c->tw); f(c->out_own); f(c->normals); f(c->plane); f(c->positions); f(c->checksum_acc); f(c->inter_scale);
+    f(c->h0T); f(c->omegaT); f(c->inter); f(c->nyq); f(c->tw); f(c->out_own); f(c->normals); f(c->plane); f(c->batch_inter); f(c->batch_nyq); f(c->batch_out); f(c->positions); f(c->checksum_acc); f(c->inter_scale);
     if (c->ev_a) (void)hipEventDestroy(c->ev_a);
     if (c->ev_b) (void)hipEventDestroy(c->ev_b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -889,6 +898,98 @@ int32_t ocean_tile_pass2(OceanContext* ctx, int32_t rank, int32_t world, int32_t
     DeviceGuard guard(ctx->device);
     OCEAN_DISPATCH(ctx->n, L::tile_pass2(ctx, world, parts, (const c32*)recv_device, (float4*)out_rows_device, pick(ctx, stream)));
     return check_launch(ctx, "ocean_tile_pass2 launch");
+}
+
+// ---- K time steps of one tile per launch pair (the latency-bound sizes) -------------------------------------------------
+namespace {
+int32_t batch_check(OceanContext* ctx, int32_t count) {
+    if (count < 1 || count > OCEAN_BATCH_MAX) return fail(ctx, OCEAN_E_INVALID_ARG, "count must be in [1, OCEAN_BATCH_MAX]");
+    if (!ctx->uploaded) return fail(ctx, OCEAN_E_STATE, "ocean_upload_spectrum has not been called");
+    if (ctx->quirks != OCEAN_QUIRKS_REFERENCE) return fail(ctx, OCEAN_E_STATE, "the fused kernels implement the reference quirks only (ocean_set_quirks)");
+    if (ctx->frame_normals >= 0) return fail(ctx, OCEAN_E_STATE, "ocean_frame_batch does not carry the normal field (ocean_set_frame_normals(ctx, -1) first)");
+    return OCEAN_OK;
+}
+// the K intermediates / Nyquist scratches (and, without a caller buffer, the K maps) of a batch
+int32_t batch_reserve(OceanContext* ctx, int32_t count, bool own_out) {
+    bool batched = false;
+    OCEAN_DISPATCH(ctx->n, batched = L::BATCHED);
+    const size_t n2 = (size_t)ctx->n * ctx->n;
+    if (batched && ctx->batch_cap < count) {
+        HIP_TRY(ctx, sync_for_readback(ctx));
+        if (ctx->batch_inter) (void)hipFree(ctx->batch_inter);
+        if (ctx->batch_nyq) (void)hipFree(ctx->batch_nyq);
+        ctx->batch_inter = nullptr; ctx->batch_nyq = nullptr; ctx->batch_cap = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->batch_inter, (size_t)count * 3 * ctx->lay_h.fs * sizeof(c32)));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->batch_nyq, (size_t)count * 3 * ctx->n * sizeof(c32)));
+        ctx->batch_cap = count;
+    }
+    if (own_out && ctx->batch_out_cap < count) {
+        HIP_TRY(ctx, sync_for_readback(ctx));
+        if (ctx->batch_out) (void)hipFree(ctx->batch_out);
+        ctx->batch_out = nullptr; ctx->batch_out_cap = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->batch_out, (size_t)count * n2 * sizeof(float4)));
+        ctx->batch_out_cap = count;
+    }
+    return OCEAN_OK;
+}
+void launch_batch(OceanContext* c, float t0, float dt, int32_t count, float4* out, size_t out_stride_texels, hipStream_t s) {
+    bool batched = false;
+    OCEAN_DISPATCH(c->n, batched = L::BATCHED);
+    if (batched) {
+        FrameBatch b;
+        b.dt = dt;
+        b.inter_stride = (uint32_t)(3 * c->lay_h.fs);
+        b.out_stride = out_stride_texels;
+        OCEAN_DISPATCH(c->n, {
+            L::pass1_on(c, t0, c->default_domain, c->batch_inter, c->lay_h, L::H::half_grid1, 0, s, Timing(), c->batch_nyq, b, count);
+            L::pass2_on(c, c->batch_inter, out, s, Timing(), b, count);
+        });
+        return;
+    }
+    for (int i = 0; i < count; ++i)                                 // N > 1024: one frame fills the chip; the same frames, one launch pair each
+        OCEAN_DISPATCH(c->n, { L::pass1(c, t0 + dt * (float)i, c->default_domain, s); L::pass2_on(c, c->inter, out + (size_t)i * out_stride_texels, s, Timing()); });
+}
+}  // namespace
+
+int32_t ocean_frame_batch(OceanContext* ctx, float t0, float dt, int32_t count, void* out_base_device, int64_t out_stride_bytes, void* stream) {
+    if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    { const int32_t st = batch_check(ctx, count); if (st != OCEAN_OK) return st; }
+    const int64_t map_bytes = (int64_t)ctx->n * ctx->n * 16;
+    if (out_base_device) {
+        if ((reinterpret_cast<uintptr_t>(out_base_device) & 15u) || (out_stride_bytes & 15) || out_stride_bytes < map_bytes)
+            return fail(ctx, OCEAN_E_INVALID_ARG, "batch output: 16-byte aligned base, stride a multiple of 16 and >= N*N*16");
+    } else out_stride_bytes = map_bytes;
+    DeviceGuard guard(ctx->device);
+    { const int32_t st = batch_reserve(ctx, count, out_base_device == nullptr); if (st != OCEAN_OK) return st; }
+    float4* out = out_base_device ? (float4*)out_base_device : ctx->batch_out;
+    launch_batch(ctx, t0, dt, count, out, (size_t)(out_stride_bytes / 16), pick(ctx, stream));
+    return check_launch(ctx, "ocean_frame_batch launch");
+}
+void* ocean_batch_device_ptr(OceanContext* ctx) { return valid(ctx) ? (void*)ctx->batch_out : nullptr; }
+int32_t ocean_read_batch_displacement(OceanContext* ctx, int32_t index, float* host_rgba) {
+    if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    if (!host_rgba) return fail(ctx, OCEAN_E_INVALID_ARG, "NULL output");
+    if (!ctx->batch_out || index < 0 || index >= ctx->batch_out_cap) return fail(ctx, OCEAN_E_STATE, "no library-owned batch map with this index (ocean_frame_batch with out_base_device = NULL)");
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, sync_for_readback(ctx));
+    const size_t n2 = (size_t)ctx->n * ctx->n;
+    HIP_TRY(ctx, hipMemcpy(host_rgba, ctx->batch_out + (size_t)index * n2, n2 * sizeof(float4), hipMemcpyDeviceToHost));
+    return OCEAN_OK;
+}
+// `launches` batches of `count` frames back to back on the context stream between two events (library-owned maps): *out_ms.
+int32_t ocean_time_frame_batch(OceanContext* ctx, int32_t launches, int32_t count, float t0, float dt, float* out_ms) {
+    if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    if (launches < 1 || launches > 65536 || !out_ms) return fail(ctx, OCEAN_E_INVALID_ARG, "launches in [1, 65536], out_ms non-NULL");
+    { const int32_t st = batch_check(ctx, count); if (st != OCEAN_OK) return st; }
+    DeviceGuard guard(ctx->device);
+    { const int32_t st = batch_reserve(ctx, count, true); if (st != OCEAN_OK) return st; }
+    const size_t n2 = (size_t)ctx->n * ctx->n;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_a, ctx->stream));
+    for (int i = 0; i < launches; ++i) launch_batch(ctx, t0 + dt * (float)((int64_t)i * count), dt, count, ctx->batch_out, n2, ctx->stream);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_b, ctx->stream));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev_b));
+    HIP_TRY(ctx, hipEventElapsedTime(out_ms, ctx->ev_a, ctx->ev_b));
+    return check_launch(ctx, "ocean_time_frame_batch");
 }
 
 // ---- measurement ----------------------------------------------------------------------------------

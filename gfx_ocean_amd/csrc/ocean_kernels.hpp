@@ -125,6 +125,17 @@ __device__ __forceinline__ size_t tile_slab_offset(const InterLayout& lay, int X
 __device__ __forceinline__ size_t chunk_row_offset(const InterLayout& lay, int Y) {
     return (size_t)(Y >> lay.bshift) * lay.sy + (size_t)(Y & ((1 << lay.bshift) - 1)) * (size_t)16;   // one chunk = 16 elements
 }
+// K time steps of one tile in ONE launch pair (ocean_frame_batch; the latency-bound sizes N <= 1024, where a frame's two
+// launches fill an eighth of the chip and the reference itself keeps 3 frames in flight, src/lib.rs:86,150): gridDim.y = K
+// and frame y = blockIdx.y of the batch runs at time t0 + y dt with its own intermediate, Nyquist scratch and output map.
+// The kernels of N > 1024 ignore these (their launches are never batched: one frame fills the chip).
+struct FrameBatch {
+    float dt = 0.0f;                // frame y: time = t0 + dt * (float)y, rounded like the host's `t0 + dt * (float)y` (no FMA)
+    uint32_t inter_stride = 0;      // elements between the intermediates of consecutive frames
+    size_t out_stride = 0;          // texels (float4) between their output maps
+};
+template <int N> constexpr bool batched_launches = (N <= 1024);
+
 // A chunk is 4 columns x 4 rows of complex = 128 bytes.  A pass-1 workgroup owns P = 4 lines (whole
 // chunks, non-temporal stores) or P = 2 lines (the left or right 16 bytes of every chunk row; its
 // neighbour, dispatched in the adjacent slot of the same XCD, writes the other half and the XCD L2
@@ -508,7 +519,13 @@ template <int E> constexpr int pass1_waves_per_simd(int threads) {
 template <int N, int E, int P, bool H16, bool DMA = false, bool FPAR = false>
 __global__ void __launch_bounds__((N / E) * P * (FPAR ? 3 : 1), pass1_waves_per_simd<E>((N / E) * P * (FPAR ? 3 : 1)))
 k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restrict__ omegaT, c32* __restrict__ inter,
-             c32* nyq_spec, const c32* __restrict__ tw, InterLayout lay, float time, float domain_size, int x_group0) {
+             c32* nyq_spec, const c32* __restrict__ tw, InterLayout lay, float time, float domain_size, int x_group0, FrameBatch batch) {
+    if constexpr (batched_launches<N>) {                           // frame blockIdx.y of a batch (ocean_frame_batch; 0 for a plain frame)
+        const uint32_t fi = blockIdx.y;
+        time = __fadd_rn(time, __fmul_rn(batch.dt, (float)fi));
+        inter += (size_t)fi * batch.inter_stride;
+        nyq_spec += (size_t)fi * (3 * N);
+    }
     constexpr int T = N / E;
     constexpr int GT = T * P;                                      // threads of one field group (= the workgroup without FPAR)
     constexpr int H2 = P / 2;
@@ -772,7 +789,12 @@ template <int N, int R2> struct Pitch2 { static constexpr int elems = LdsLine<N>
 template <int N, int E, int P1, int R2, int GRP = 1, bool PPAR = false, bool SHARD = false, bool PLANE = false>
 __global__ void __launch_bounds__((N / E) * R2 * (PPAR ? 2 : 1), (E == 16) ? 4 : 2)
 k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32* __restrict__ tw, InterLayout lay,
-             float* __restrict__ plane, int plane_channel) {
+             float* __restrict__ plane, int plane_channel, FrameBatch batch) {
+    if constexpr (batched_launches<N> && !SHARD) {                 // frame blockIdx.y of a batch (ocean_frame_batch)
+        const uint32_t fi = blockIdx.y;
+        inter += (size_t)fi * batch.inter_stride;
+        out += (size_t)fi * batch.out_stride;
+    }
     constexpr int T = N / E;
     constexpr int GT = T * R2;                                     // threads of one transform group (= the workgroup without PPAR)
     constexpr int EH = E / 2;                                      // elements of the half spectrum per thread

@@ -105,6 +105,23 @@ class OceanDevice:
         loc = PropagateLocals(time, self.resolution, domain_size)._c()
         self._check(load_library().ocean_frame_ex(self._ctx, ctypes.byref(loc), stream))
 
+    def frame_batch(self, t0: float, dt: float, count: int, out_ptr=None, out_stride_bytes: int = 0, stream=None):
+        """`count` time steps t0 + i dt of this tile, each into its own map; at N <= 1024 ONE launch pair (ocean_frame_batch).
+        out_ptr None: library-owned maps (read_batch_displacement)."""
+        self._check(load_library().ocean_frame_batch(self._ctx, float(t0), float(dt), int(count), out_ptr, int(out_stride_bytes), stream))
+
+    def read_batch_displacement(self, index: int) -> np.ndarray:
+        n = self.resolution
+        out = np.empty((n, n, 4), dtype=np.float32)
+        self._check(load_library().ocean_read_batch_displacement(self._ctx, int(index), out.ctypes.data))
+        return out
+
+    def time_frame_batch(self, launches: int, count: int, t0: float = 0.0, dt: float = 1.0 / 60.0) -> float:
+        """Milliseconds of `launches` back-to-back ocean_frame_batch calls of `count` frames each (ocean_time_frame_batch)."""
+        ms = ctypes.c_float()
+        self._check(load_library().ocean_time_frame_batch(self._ctx, int(launches), int(count), float(t0), float(dt), ctypes.byref(ms)))
+        return float(ms.value)
+
     # -- SURVEY 8f #1: normal field (shader/ocean.frag:50-66) ----------------------------------------
     def normals(self, source_channel: int = 0, stream=None) -> np.ndarray:
         """Finite-difference normals of the current displacement map; channel 0 = disp_x as the

@@ -44,7 +44,15 @@ extern "C" {
     pub fn ocean_correct(c: *mut OceanCorrection, locals: *const OceanCorrectionLocals, stream: *mut c_void) -> i32;
     pub fn ocean_frame(ctx: *mut OceanContext, time: f32, stream: *mut c_void) -> i32;
     pub fn ocean_frame_ex(ctx: *mut OceanContext, locals: *const OceanPropagateLocals, stream: *mut c_void) -> i32;
+    pub fn ocean_frame_batch(ctx: *mut OceanContext, t0: f32, dt: f32, count: i32, out_base_device: *mut c_void, out_stride_bytes: i64,
+                             stream: *mut c_void) -> i32;
+    pub fn ocean_batch_device_ptr(ctx: *mut OceanContext) -> *mut c_void;
+    pub fn ocean_read_batch_displacement(ctx: *mut OceanContext, index: i32, host_rgba: *mut f32) -> i32;
+    pub fn ocean_time_frame_batch(ctx: *mut OceanContext, launches: i32, count: i32, t0: f32, dt: f32, out_ms: *mut f32) -> i32;
     pub fn ocean_normals(ctx: *mut OceanContext, source_channel: i32, stream: *mut c_void) -> i32;
+    pub fn ocean_set_frame_normals(ctx: *mut OceanContext, source_channel: i32) -> i32;
+    pub fn ocean_frame_normals(ctx: *const OceanContext) -> i32;
+    pub fn ocean_normals_device_ptr(ctx: *mut OceanContext) -> *mut c_void;
     pub fn ocean_read_normals(ctx: *mut OceanContext, host_xyz0: *mut f32) -> i32;
     pub fn ocean_positions(ctx: *mut OceanContext, verts: i32, offset_x: f32, offset_z: f32, stream: *mut c_void) -> i32;
     pub fn ocean_read_positions(ctx: *mut OceanContext, host_xyz1: *mut f32) -> i32;
@@ -65,6 +73,8 @@ extern "C" {
     pub fn ocean_time_frames(ctx: *mut OceanContext, frames: i32, t0: f32, dt: f32, out_ms: *mut f32) -> i32;
     pub fn ocean_time_frame_batches(ctx: *mut OceanContext, batches: i32, frames_per_batch: i32, t0: f32, dt: f32, batch_ms: *mut f32) -> i32;
     pub fn ocean_frame_times(ctx: *mut OceanContext, frames: i32, t0: f32, dt: f32, pass1_ms: *mut f32, pass2_ms: *mut f32, period_ms: *mut f32) -> i32;
+    pub fn ocean_frame_times_ex(ctx: *mut OceanContext, frames: i32, t0: f32, dt: f32, pass1_ms: *mut f32, pass2_ms: *mut f32, normals_ms: *mut f32,
+                                period_ms: *mut f32) -> i32;
     pub fn ocean_profile_frame(ctx: *mut OceanContext, time: f32, cap: i32, names: *mut *const c_char,
                                ms: *mut f32, out_n: *mut i32) -> i32;
     pub fn ocean_profile_staged(ctx: *mut OceanContext, time: f32, cap: i32, names: *mut *const c_char,

@@ -72,6 +72,52 @@ impl Device {
     pub fn frame(&self, time: f32) -> Result<(), Box<dyn Error>> {
         self.check(unsafe { ffi::ocean_frame(self.ctx, time, ptr::null_mut()) })
     }
+    /// `count` time steps `t0 + dt * i` of this tile into library-owned maps (one launch pair at N <= 1024:
+    /// include/ocean_hip.h `ocean_frame_batch`); read them with `read_batch_displacement`.
+    pub fn frame_batch(&self, t0: f32, dt: f32, count: i32) -> Result<(), Box<dyn Error>> {
+        self.check(unsafe { ffi::ocean_frame_batch(self.ctx, t0, dt, count, ptr::null_mut(), 0, ptr::null_mut()) })
+    }
+    pub fn read_batch_displacement(&self, index: i32, rgba: &mut [f32]) -> Result<(), Box<dyn Error>> {
+        let want = self.texels()? * 4;
+        if rgba.len() != want {
+            return Err(Box::new(OceanError { status: -1, message: format!(
+                "read_batch_displacement: expected a slice of {} floats, got {}", want, rgba.len()) }));
+        }
+        self.check(unsafe { ffi::ocean_read_batch_displacement(self.ctx, index, rgba.as_mut_ptr()) })
+    }
+    /// The frame with its normal field as one workload (shader/ocean.frag:50-66; channel 0 = disp_x as the reference, quirk Q5):
+    /// `Some(channel)` switches it on for every following frame, `None` off (include/ocean_hip.h `ocean_set_frame_normals`).
+    pub fn set_frame_normals(&self, source_channel: Option<i32>) -> Result<(), Box<dyn Error>> {
+        self.check(unsafe { ffi::ocean_set_frame_normals(self.ctx, source_channel.unwrap_or(-1)) })
+    }
+    /// N*N float4 (n.x, n.y, n.z, 0) of the last frame's normal field.
+    pub fn read_normals(&self, xyz0: &mut [f32]) -> Result<(), Box<dyn Error>> {
+        let want = self.texels()? * 4;
+        if xyz0.len() != want {
+            return Err(Box::new(OceanError { status: -1, message: format!(
+                "read_normals: expected a slice of {} floats, got {}", want, xyz0.len()) }));
+        }
+        self.check(unsafe { ffi::ocean_read_normals(self.ctx, xyz0.as_mut_ptr()) })
+    }
+    /// Milliseconds of `frames` back-to-back frames between two HIP events on the context stream.
+    pub fn time_frames(&self, frames: i32, t0: f32, dt: f32) -> Result<f32, Box<dyn Error>> {
+        let mut ms = 0f32;
+        self.check(unsafe { ffi::ocean_time_frames(self.ctx, frames, t0, dt, &mut ms) })?;
+        Ok(ms)
+    }
+    /// Per-batch milliseconds of `batches` x `frames_per_batch` back-to-back frames (the frame-time distribution).
+    pub fn time_frame_batches(&self, batches: i32, frames_per_batch: i32, t0: f32, dt: f32) -> Result<Vec<f32>, Box<dyn Error>> {
+        let mut ms = vec![0f32; batches.max(0) as usize];
+        self.check(unsafe { ffi::ocean_time_frame_batches(self.ctx, batches, frames_per_batch, t0, dt, ms.as_mut_ptr()) })?;
+        Ok(ms)
+    }
+    /// (pass 1, pass 2, period) milliseconds of every frame of a back-to-back loop, from events bound to the dispatches.
+    pub fn frame_times(&self, frames: i32, t0: f32, dt: f32) -> Result<(Vec<f32>, Vec<f32>, Vec<f32>), Box<dyn Error>> {
+        let k = frames.max(0) as usize;
+        let (mut a, mut b, mut c) = (vec![0f32; k], vec![0f32; k], vec![0f32; k]);
+        self.check(unsafe { ffi::ocean_frame_times(self.ctx, frames, t0, dt, a.as_mut_ptr(), b.as_mut_ptr(), c.as_mut_ptr()) })?;
+        Ok((a, b, c))
+    }
     /// SURVEY 8a Q1/Q2 switches; `QUIRKS_REFERENCE` (default) is the shipped shaders' arithmetic.
     pub fn set_quirks(&self, quirks: u32) -> Result<(), Box<dyn Error>> {
         self.check(unsafe { ffi::ocean_set_quirks(self.ctx, quirks) })

@@ -41,7 +41,8 @@ extern "C" {
  *    the same number in round 3); readbacks wait for the whole device once a dispatch has been put on a caller stream
  * 3: + ocean_frame_times, ocean_time_frame_batches; ocean_sync and ocean_context_destroy honour caller streams like the readbacks
  * 4: + ocean_set_frame_normals, ocean_frame_normals, ocean_normals_device_ptr, ocean_frame_times_ex (the frame with the normal
- *    field as one workload); ocean_time_frame_batches also bounds frames_per_batch (<= 4096) */
+ *    field as one workload); + ocean_frame_batch, ocean_batch_device_ptr, ocean_read_batch_displacement, ocean_time_frame_batch
+ *    (K time steps per launch pair); ocean_time_frame_batches also bounds frames_per_batch (<= 4096) */
 #define OCEAN_ABI_VERSION 4
 
 /* ---- status codes ------------------------------------------------------------------------- */
@@ -158,6 +159,20 @@ uint32_t ocean_quirks(const OceanContext* ctx);
 int32_t ocean_set_intermediate(OceanContext* ctx, int32_t mode);
 int32_t ocean_intermediate(const OceanContext* ctx);
 
+/* K consecutive time steps of this tile -- frame i at time t0 + dt * (float)i (fp32, as ocean_time_frames counts) -- each into
+ * its own map: out_base_device + i * out_stride_bytes (caller device memory: 16-byte aligned, stride >= N*N*16), or with
+ * out_base_device = NULL into library-owned maps N*N*16 bytes apart (ocean_batch_device_ptr, ocean_read_batch_displacement).
+ * At N <= 1024, where one frame's two launches fill an eighth of the chip and the host needs 5-7 us to submit them, the K
+ * frames are ONE launch pair (blockIdx.y = frame; K intermediates, allocated on demand) -- the reference keeps 3 frames in
+ * flight by command-buffer rotation (src/lib.rs:86,150) and draws 4 instances of one map (src/render.rs:540-551,1360); at
+ * N >= 2048 a frame fills the chip and the call is K ordinary launch pairs.  Every map is bit-identical to ocean_frame at the
+ * same time.  Reference quirks only; without the normal field (OCEAN_E_STATE otherwise).  ocean_frame's own map is untouched. */
+#define OCEAN_BATCH_MAX 64
+int32_t ocean_frame_batch(OceanContext* ctx, float t0, float dt, int32_t count, void* out_base_device, int64_t out_stride_bytes,
+                          void* stream);
+void* ocean_batch_device_ptr(OceanContext* ctx);                    /* library-owned maps of the last NULL-buffer batch */
+int32_t ocean_read_batch_displacement(OceanContext* ctx, int32_t index, float* host_rgba /* N*N*4 */);
+
 /* the reference's normal field (shader/ocean.frag:50-66: finite differences of the
  * displacement map with Tile wrap, height_scale 180) as a compute pass over the current
  * displacement map.  source_channel 0 = disp_x (what the reference differentiates, quirk Q5),
@@ -214,6 +229,8 @@ void* ocean_stream(OceanContext* ctx);                            /* the context
 /* ---- measurement (HIP events on the stream the kernels run on) -------------------------------- */
 /* Runs `frames` frames (time = t0 + i*dt) on the context stream between two events; *out_ms = total. */
 int32_t ocean_time_frames(OceanContext* ctx, int32_t frames, float t0, float dt, float* out_ms);
+/* `launches` (<= 65536) calls of ocean_frame_batch(count frames, library-owned maps) back to back between two events: *out_ms. */
+int32_t ocean_time_frame_batch(OceanContext* ctx, int32_t launches, int32_t count, float t0, float dt, float* out_ms);
 /* `batches` (<= 4096) x `frames_per_batch` (<= 4096) fused frames back to back with one stream event between batches and one sync at
  * the end: batch_ms[b] = duration of batch b.  The distribution SURVEY 8d asks for (median, p10 / p90 of a frame in an
  * undisturbed loop); the reference's only timing is an EMA of the vsync-bound frame delta (src/lib.rs:146-148). */

@@ -149,7 +149,7 @@ def quantize_f16(h0):
 
 
 def frame_half(h0, omega, time, L=1000.0, layout="p2", return_inter=False, spectrum_fp16=False, P=None, split=False, bshift=None,
-               inter16=False, plane_channel=None):
+               inter16=False, plane_channel=None, batch=None):
     """split=True: every line as two interleaved N/2 transforms (the N = 8192 geometry, P = 2; with P=1 the N = 16384 geometry:
     one column per pass-1 workgroup); inter16=True (split, P = 2 only): the 16-bit block-floating intermediate (OCEAN_INTER_BFP16)."""
     n = h0.shape[0]
@@ -163,9 +163,13 @@ def frame_half(h0, omega, time, L=1000.0, layout="p2", return_inter=False, spect
         h0T = np.ascontiguousarray(h0.T, np.complex64)
     omT = np.ascontiguousarray(omega.T, np.float32)
     sx, sy, fs, bshift = half_layout(n, P, layout, bshift=bshift)
-    inter = np.full(3 * fs, np.nan + 1j * np.nan, np.complex64)
-    nyq = np.full(6 * n, np.nan, np.float32)           # scratch: the Nyquist column's three spectra
-    out = np.full((n, n, 4), np.nan, np.float32)
+    # batch = (count, dt): `count` time steps time + i dt in ONE launch pair (ocean_frame_batch, N <= 1024) -> out [count, n, n, 4]
+    count, dt = batch if batch else (1, 0.0)
+    inter = np.full(count * 3 * fs, np.nan + 1j * np.nan, np.complex64)
+    nyq = np.full(count * 6 * n, np.nan, np.float32)   # scratch: the Nyquist column's three spectra (per frame)
+    out = np.full((count, n, n, 4) if batch else (n, n, 4), np.nan, np.float32)
+    lib().emu_set_batch.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_uint, ctypes.c_size_t]
+    lib().emu_set_batch(count, dt, 3 * fs, n * n)
     tw = twiddles(n)
     assert split or not inter16
     scales = np.full(3 * (n // 64) * (n // 4), np.nan, np.float32) if inter16 else None
@@ -177,6 +181,7 @@ def frame_half(h0, omega, time, L=1000.0, layout="p2", return_inter=False, spect
     assert lib().emu_frame_half(n, psel, _p(h0T), int(spectrum_fp16), descale, _p(omT), _p(inter),
                                 _p(nyq), _p(out), _p(tw), sx, sy, fs, bshift, time, L, _p(scales) if inter16 else None) == 0
     lib().emu_set_plane(None, 0)
+    lib().emu_set_batch(1, 0.0, 0, 0)
     if plane_channel is not None:
         return out, plane
     if return_inter:

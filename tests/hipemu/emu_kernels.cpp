@@ -22,18 +22,20 @@ namespace ocean { alignas(16) unsigned char smem[160 * 1024]; float g_emu_wave_s
 #include "ocean_staged_kernels.hpp"
 
 template <class F>
-static void emu_launch(int grid, int threads, F&& body) {
+static void emu_launch(int grid, int threads, F&& body, int grid_y = 1) {
     std::barrier<> bar(threads);
     g_barrier = &bar;
     gridDim.x = (unsigned)grid;
+    gridDim.y = (unsigned)grid_y;
     blockDim.x = (unsigned)threads;
     std::vector<std::thread> pool;
     pool.reserve(threads);
     for (int t = 0; t < threads; ++t) {
         pool.emplace_back([&, t] {
             threadIdx.x = (unsigned)t;
-            for (int b = 0; b < grid; ++b) {
-                blockIdx.x = (unsigned)b;
+            for (int b = 0; b < grid * grid_y; ++b) {
+                blockIdx.x = (unsigned)(b % grid);
+                blockIdx.y = (unsigned)(b / grid);
                 body();
                 bar.arrive_and_wait();   // the next block reuses the LDS buffer
             }
@@ -54,15 +56,19 @@ template <int N> static int run_fft_lines(int col, c32* data, const c32* tw) {
 // (pass 2 always runs as its PLANE instance here: the map must not depend on it, and emu_plane checks the plane)
 static float* plane = nullptr;
 static int plane_channel = 0;
+// ... and as a batch of `batch_count` time steps in one launch pair when emu_set_batch says so (ocean_frame_batch, N <= 1024)
+static int batch_count = 1;
+static FrameBatch batch{};
 template <int N, int PSEL> static int run_half_p(const void* h0T, int f16, float descale, const float* omT, c32* inter, c32* nyq,
                                                  float4* out, const c32* tw, InterLayout lay, float time, float L) {
     using G = Geo<N, PSEL>;
+    if (batch_count > 1 && !batched_launches<N>) return -8;
     if (f16) emu_launch(G::half_grid1, G::half_threads1,
-                        [&] { k_half_pass1<N, G::E1, G::P, true, G::dma, G::fpar>(h0T, descale, omT, inter, nyq, tw, lay, time, L, 0); });
+                        [&] { k_half_pass1<N, G::E1, G::P, true, G::dma, G::fpar>(h0T, descale, omT, inter, nyq, tw, lay, time, L, 0, batch); }, batch_count);
     else emu_launch(G::half_grid1, G::half_threads1,
-                    [&] { k_half_pass1<N, G::E1, G::P, false, G::dma, G::fpar>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L, 0); });
+                    [&] { k_half_pass1<N, G::E1, G::P, false, G::dma, G::fpar>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L, 0, batch); }, batch_count);
     emu_launch(G::half_grid2, G::half_threads2,
-               [&] { k_half_pass2<N, G::E2, CHUNK_W, G::R2h, G::p2_group, G::ppar, false, true>(inter, out, tw, lay, plane, plane_channel); });
+               [&] { k_half_pass2<N, G::E2, CHUNK_W, G::R2h, G::p2_group, G::ppar, false, true>(inter, out, tw, lay, plane, plane_channel, batch); }, batch_count);
     return 0;
 }
 template <int N, bool I16, int PS = 2> static int run_half_split(const void* h0T, int f16, float descale, const float* omT, c32* inter, c32* nyq,
@@ -107,9 +113,9 @@ template <int N, int PSEL> static int run_tile_pass1(int rank, int world, int pa
     const int groups = (N / 2 / world / parts) / G::P;
     const int x_group0 = (rank * parts + part) * groups;
     if (f16) emu_launch(groups, G::half_threads1,
-                        [&] { k_half_pass1<N, G::E1, G::P, true, G::dma, G::fpar>(h0T, descale, omT, send, nyq, tw, lay, time, L, x_group0); });
+                        [&] { k_half_pass1<N, G::E1, G::P, true, G::dma, G::fpar>(h0T, descale, omT, send, nyq, tw, lay, time, L, x_group0, FrameBatch{}); });
     else emu_launch(groups, G::half_threads1,
-                    [&] { k_half_pass1<N, G::E1, G::P, false, G::dma, G::fpar>(h0T, 1.0f, omT, send, nyq, tw, lay, time, L, x_group0); });
+                    [&] { k_half_pass1<N, G::E1, G::P, false, G::dma, G::fpar>(h0T, 1.0f, omT, send, nyq, tw, lay, time, L, x_group0, FrameBatch{}); });
     return 0;
 }
 template <int N, int PSEL> static int run_tile_pass2(int world, int parts, const c32* recv, float4* out, const c32* tw) {
@@ -117,7 +123,7 @@ template <int N, int PSEL> static int run_tile_pass2(int world, int parts, const
     if (!G::tile_supported(world, parts)) return -5;
     const InterLayout lay = G::tile_layout(world, parts);
     emu_launch((N / world) / G::R2h, G::half_threads2,
-               [&] { k_half_pass2<N, G::E2, CHUNK_W, G::R2h, G::p2_group, G::ppar, true>(recv, out, tw, lay, nullptr, 0); });
+               [&] { k_half_pass2<N, G::E2, CHUNK_W, G::R2h, G::p2_group, G::ppar, true>(recv, out, tw, lay, nullptr, 0, FrameBatch{}); });
     return 0;
 }
 // ... with the split geometry (what ocean_tile_pass1 / ocean_tile_pass2 launch at N >= 8192: k_half_pass1_split, k_half_pass2_real<SHARD>)
@@ -279,6 +285,13 @@ int emu_normals(int n, const float* rgba, float* normals, int channel) {
 }
 // where the fused pass 2 of the following emu_frame_half calls stores its source-channel plane (n * n floats; must be set)
 int emu_set_plane(float* p, int channel) { plane = p; plane_channel = channel; return 0; }
+// the following emu_frame_half calls (plain geometry, N <= 1024) run `count` time steps t, t + dt, ... as ONE launch pair; frame y
+// uses inter + y * inter_stride (elements), nyq + y * 3 n, out + y * out_stride (texels)
+int emu_set_batch(int count, float dt, unsigned inter_stride, size_t out_stride) {
+    batch_count = count;
+    batch = FrameBatch{dt, inter_stride, out_stride};
+    return 0;
+}
 int emu_normals_plane(int n, const float* src_plane, float* normals) {
     const int rows = normals_plane_rows(n);             // as launch_normals_plane of csrc/ocean_api.hip
     const int grid = (n / 256) * (n / rows) / 4;

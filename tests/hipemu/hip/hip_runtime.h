@@ -21,7 +21,7 @@ static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 
-struct emu_dim3 { unsigned x = 1, y = 1, z = 1; };
+struct emu_dim3 { unsigned x = 0, y = 0, z = 0; };   // (every launch sets what it uses)
 extern thread_local emu_dim3 threadIdx;
 extern thread_local emu_dim3 blockIdx;
 extern emu_dim3 blockDim;
@@ -36,3 +36,6 @@ static inline void sincospif(float x, float* s, float* c) {
 }
 
 static inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
+// round-to-nearest fp32 add / multiply that the compiler must not contract into an FMA
+static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }

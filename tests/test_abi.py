@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(so_path):
 
 def test_library_loads_and_reports_version(so_path):
     lib = g.load_library()
-    assert lib.ocean_abi_version() == 3
+    assert lib.ocean_abi_version() == 4
 
 
 def test_library_contains_gfx950_code(so_path):

@@ -97,6 +97,20 @@ def test_emu_frame_with_normal_plane(n, channel, split, ref_inputs, ref_inputs_2
     assert np.abs(got - oc.normals_literal(rgba, channel)).max() <= 2e-6
 
 
+@pytest.mark.parametrize("n", [256, 512])
+def test_emu_frame_batch(n, ref_inputs, ref_inputs_256):
+    """ocean_frame_batch at the latency-bound sizes: K time steps as blockIdx.y of ONE launch pair, every frame with its own
+    intermediate, Nyquist scratch and map -- each bit-identical to the plain frame at t0 + dt * i (fp32, no FMA)."""
+    h0, om = ref_inputs_256 if n == 256 else ref_inputs
+    t0, dt, K = np.float32(1.5), np.float32(1.0 / 60.0), 3
+    outs = emu.frame_half(h0, om, float(t0), batch=(K, float(dt)))
+    assert outs.shape == (K, n, n, 4)
+    for i in range(K):
+        ti = np.float32(t0 + np.float32(dt * np.float32(i)))
+        assert np.array_equal(outs[i], emu.frame_half(h0, om, float(ti))), i
+    assert not np.array_equal(outs[0], outs[1])
+
+
 def test_emu_split_line_geometry_block_layout(ref_inputs):
     """The split kernels (N = 8192 geometry) with the intermediate in blocks of 8 chunk rows."""
     h0, om = ref_inputs

@@ -36,7 +36,7 @@ def r256(ref_inputs_256):
 
 def test_native_library_is_loaded():
     lib = g.load_library()
-    assert lib.ocean_abi_version() == 3
+    assert lib.ocean_abi_version() == 4
     with open("/proc/self/maps") as f:
         assert "libocean_hip.so" in f.read()
 
@@ -389,6 +389,52 @@ def test_frame_with_normal_field_staged_quirks_and_errors():
         p1, p2, nrm, per = d.frame_times_ex(4)
         assert len(nrm) == 4 and all(v > 0 for v in nrm)
     finally:
+        d.destroy()
+
+
+@pytest.mark.parametrize("n,count,own,fp16", [(256, 8, True, False), (512, 8, True, False), (512, 5, False, True), (1024, 4, False, False),
+                                              (1024, 64, True, False), (2048, 3, False, False)])
+def test_frame_batch_is_bit_identical_to_single_frames(n, count, own, fp16):
+    """ocean_frame_batch: K time steps of one tile per launch pair at N <= 1024 (blockIdx.y = frame; K ordinary launch pairs
+    above).  Every map equals ocean_frame's at t0 + dt * i bit for bit; library-owned and caller-owned maps; the context's own
+    map is untouched."""
+    from hipmem import DeviceBuffer
+    h0, om = g.synth.make_inputs(n, seed=31)
+    d = g.OceanDevice(n)
+    buf = None
+    try:
+        d.upload_spectrum(h0, om, spectrum_fp16=fp16)
+        t0, dt = np.float32(0.75), np.float32(1.0 / 60.0)
+        d.frame(9.0)
+        keep = d.checksum()
+        stride = n * n * 16 + (0 if own else 4096)
+        if own:
+            d.frame_batch(float(t0), float(dt), count)
+            maps = [d.read_batch_displacement(i) for i in range(count)]
+        else:
+            buf = DeviceBuffer(stride * count)
+            buf.fill(0xFF)
+            d.frame_batch(float(t0), float(dt), count, out_ptr=buf.ptr, out_stride_bytes=stride)
+            d.sync()
+            raw = buf.to_host(np.uint8)
+            maps = [raw[i * stride:i * stride + n * n * 16].view(np.float32).reshape(n, n, 4) for i in range(count)]
+            assert np.all(raw[n * n * 16:stride] == 0xFF)          # the padding between two maps is nobody's
+        assert d.checksum() == keep
+        for i in sorted({0, 1, count // 2, count - 1}):
+            ti = np.float32(t0 + np.float32(dt * np.float32(i)))
+            d.frame(float(ti))
+            assert np.array_equal(maps[i], d.read_displacement()), (n, i)
+        assert not np.array_equal(maps[0], maps[1])
+        ms = d.time_frame_batch(3, count)
+        assert ms > 0.0
+        with pytest.raises(g.OceanError):
+            d.frame_batch(0.0, 0.1, 65)
+        d.set_frame_normals(0)
+        with pytest.raises(g.OceanError):
+            d.frame_batch(0.0, 0.1, 2)
+    finally:
+        if buf is not None:
+            buf.free()
         d.destroy()
 
 
