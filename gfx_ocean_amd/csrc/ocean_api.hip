@@ -15,6 +15,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <unordered_set>
 #include <vector>
 
@@ -169,11 +170,21 @@ template <int N> struct Launch {
     // 16384 two 8192-point sub-lines fill the LDS: one column per workgroup (the size that needs several GPUs).
     static constexpr int PSEL = (N == 512 || N > 8192) ? 1 : ((N <= 2048 || N > 4096) ? 2 : 4);
     static constexpr bool SPLIT = N > 4096;
+    static constexpr bool BATCHED = batched_launches<N>;
     using H = Geo<N, PSEL>;
     static_assert(!SPLIT || H::can_split, "split geometry");
     static constexpr bool I16_BUILT = SPLIT && H::P == 2;      // the opt-in 16-bit intermediate: N = 8192 (BASELINE config 5)
     // the shipped kernel instances of this size (fp32 / fp16-stored spectrum; split: + the opt-in 16-bit intermediate)
     template <bool H16> static constexpr auto pass1_kernel() { return k_half_pass1<N, H::E1, H::P, H16, H::dma, H::fpar>; }
+    // Pass 1 of a BATCHED launch (ocean_frame_batch, count > 1): two columns per workgroup and no field-parallel groups where the
+    // single frame has them (Geo<.., THROUGHPUT>), the arithmetic of the single-frame kernel (SHR as there: bit-identical frames).
+    // Measured (r05_run4, A/B on one box, frames/s at K = 8 / 16 / 64): N = 512 255k / 311-319k / 371-373k with the single-frame
+    // geometry, 296-297k / 383k / 485k with this one; N = 256 586-595k / 827-830k / 1.23M against 600-613k / 842-861k / 1.42M, but
+    // 399-421k against 346-371k at K = 4: from 8 frames on at 256.  (N = 1024 has no field-parallel groups, and sits at 5.8 TB/s.)
+    using HB = Geo<N, H::fpar ? 2 : PSEL, true>;
+    static constexpr bool BATCH_GEO = BATCHED && H::fpar && !SPLIT;
+    static constexpr int BATCH_GEO_MIN_COUNT = (N == 256) ? 8 : 2;
+    template <bool H16> static constexpr auto pass1_batch_kernel() { return k_half_pass1<N, HB::E1, HB::P, H16, HB::dma, HB::fpar, !H::fpar>; }
     template <bool H16, bool I16> static constexpr auto pass1_split_kernel() { return k_half_pass1_split<N, H::E1S, H::P, H16, I16>; }
     template <bool SHARD, bool PLANE = false> static constexpr auto pass2_kernel() { return k_half_pass2<N, H::E2, CHUNK_W, H::R2h, H::p2_group, H::ppar, SHARD, PLANE>; }
     // Pass 2 at N >= 8192: real-output rows (three N/2-point transforms per row, half the LDS and half the threads of a row:
@@ -197,6 +208,7 @@ template <int N> struct Launch {
             }
         } else {
             lds(pass1_kernel<false>(), H::half_lds1); lds(pass1_kernel<true>(), H::half_lds1);
+            if constexpr (BATCH_GEO) { lds(pass1_batch_kernel<false>(), HB::half_lds1); lds(pass1_batch_kernel<true>(), HB::half_lds1); }
             lds(pass2_kernel<false>(), H::half_lds2); lds(pass2_kernel<true>(), H::half_lds2);
             lds(pass2_kernel<false, true>(), H::half_lds2);
         }
@@ -226,6 +238,14 @@ template <int N> struct Launch {
             if (c->h0_f16) launch(pass1_split_kernel<true, false>(), g, b, H::split_lds1, s, t, h0T, descale, omT, inter, c->nyq, tw, lay, time, domain, x_group0, scales);
             else launch(pass1_split_kernel<false, false>(), g, b, H::split_lds1, s, t, h0T, descale, omT, inter, c->nyq, tw, lay, time, domain, x_group0, scales);
         } else {
+            if constexpr (BATCH_GEO) {
+                if (count >= BATCH_GEO_MIN_COUNT) {
+                    const dim3 g(HB::half_grid1, count), b(HB::half_threads1);
+                    if (c->h0_f16) launch(pass1_batch_kernel<true>(), g, b, HB::half_lds1, s, t, h0T, descale, omT, inter, nyq, tw, lay, time, domain, x_group0, batch);
+                    else launch(pass1_batch_kernel<false>(), g, b, HB::half_lds1, s, t, h0T, descale, omT, inter, nyq, tw, lay, time, domain, x_group0, batch);
+                    return;
+                }
+            }
             const dim3 g(groups, count), b(H::half_threads1);
             if (c->h0_f16) launch(pass1_kernel<true>(), g, b, H::half_lds1, s, t, h0T, descale, omT, inter, nyq, tw, lay, time, domain, x_group0, batch);
             else launch(pass1_kernel<false>(), g, b, H::half_lds1, s, t, h0T, descale, omT, inter, nyq, tw, lay, time, domain, x_group0, batch);
@@ -260,8 +280,7 @@ template <int N> struct Launch {
         }
     }
     static void pass2(OceanContext* c, hipStream_t s, Timing t = Timing()) { pass2_on(c, c->inter, c->out, s, t); }
-    static constexpr bool BATCHED = batched_launches<N>;
-    // ---- one tile sharded over `world` GPUs (ocean_tile_pass1 / ocean_tile_pass2): the same kernels on this rank's
+        // ---- one tile sharded over `world` GPUs (ocean_tile_pass1 / ocean_tile_pass2): the same kernels on this rank's
     // block of half-spectrum columns (pass 1, writing the all-to-all send buffer) and block of rows (pass 2, reading the
     // receive buffer).
     static bool tile_supported(int world, int parts) { return H::tile_supported(world, parts); }

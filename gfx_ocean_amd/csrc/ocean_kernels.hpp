@@ -516,7 +516,10 @@ template <int E> constexpr int pass1_waves_per_simd(int threads) {
 // transforms now run side by side.
 // DMA: the inputs are streamed through the idle line buffers by LDS-DMA (half_load_AB_dma, N >= 2048) instead of loaded
 // into registers (half_load_AB).
-template <int N, int E, int P, bool H16, bool DMA = false, bool FPAR = false>
+// SHR: the wave-vector normalisation applied once, to A and B in place (half_scale_AB; the kernels that transform the three
+// fields one after the other).  The batched launches of a size whose single frame is field-parallel switch it off: a frame of a
+// batch must equal ocean_frame's bit for bit, and the shared normalisation moves one rounding.
+template <int N, int E, int P, bool H16, bool DMA = false, bool FPAR = false, bool SHR = !FPAR>
 __global__ void __launch_bounds__((N / E) * P * (FPAR ? 3 : 1), pass1_waves_per_simd<E>((N / E) * P * (FPAR ? 3 : 1)))
 k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restrict__ omegaT, c32* __restrict__ inter,
              c32* nyq_spec, const c32* __restrict__ tw, InterLayout lay, float time, float domain_size, int x_group0, FrameBatch batch) {
@@ -570,7 +573,8 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
     for (int ff = 0; ff < (FPAR ? 1 : 3); ++ff) {
         // One field group per field (FPAR), or the three fields one after the other: height first, then A and B are
         // normalised in place and disp_x, disp_z cost three packed instructions per element (half_scale_AB).
-        constexpr bool SHARED_R = !FPAR;
+        constexpr bool SHARED_R = SHR;
+        static_assert(!(FPAR && SHR), "one field per wave group: nothing to share");
         const int f = FPAR ? fg : ((ff == 0) ? 1 : ((ff == 1) ? 0 : 2));
         c32 reg[E];
         const int jf = FPAR ? j : opaque_lane(j);                  // (one field per thread: nothing to keep apart, and the twiddle loads may move up)
@@ -1084,7 +1088,12 @@ k_half_pass2_real(const c32* __restrict__ inter, float4* __restrict__ out, const
 // Launch geometry per resolution -- the single source for the API (ocean_api.hip) and for the
 // host emulation harness (tests/hipemu).
 // ---------------------------------------------------------------------------------------------
-template <int N, int PSEL = 0> struct Geo {
+// THROUGHPUT = the geometry of a BATCHED launch (ocean_frame_batch, N <= 1024): K frames fill the chip, so what counts is work
+// per frame, not the serial chain of one workgroup -- no field-parallel wave groups (which load and propagate every line three
+// times).  Measured at N = 512 (r05_run3, A/B on one box, K = 8 / 16 time steps per launch pair): 256-259k / 322-324k frames/s
+// with the single-frame geometry (P = 1, FPAR), 300-306k / 386-399k with two columns per workgroup and no FPAR; the single
+// frame itself is slower that way (91k against 105k), so ocean_frame keeps its own.
+template <int N, int PSEL = 0, bool THROUGHPUT = false> struct Geo {
     static constexpr int E = 16;                                   // elements per thread
     // Elements per thread of fused pass 1.  At N <= 1024 a frame is launch- and latency-bound (a 512-point line with 16
     // elements per thread is half a wave): 8 elements per thread double the waves that share a workgroup's serial chain
@@ -1114,7 +1123,7 @@ template <int N, int PSEL = 0> struct Geo {
 #endif
     static constexpr bool dma = (N >= OCEAN_DMA_MIN_N) && (((N / E1) * P) % 64 == 0);
     // Field-parallel pass 1 (k_half_pass1<.., FPAR>): three wave groups per workgroup, one per field, at N <= 512.
-    static constexpr bool fpar = (N <= 512) && (((N / E1) * P) % 64 == 0) && (3 * (N / E1) * P <= 1024) && !dma;
+    static constexpr bool fpar = !THROUGHPUT && (N <= 512) && (((N / E1) * P) % 64 == 0) && (3 * (N / E1) * P <= 1024) && !dma;
     static constexpr int half_threads1 = (N / E1) * P * (fpar ? 3 : 1);   // fused pass 1
     static constexpr int split_threads1 = (N / E1S) * P;
     static constexpr int line_bytes = LinePitch<N>::elems * (int)sizeof(c32);

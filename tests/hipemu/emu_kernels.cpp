@@ -63,6 +63,18 @@ template <int N, int PSEL> static int run_half_p(const void* h0T, int f16, float
                                                  float4* out, const c32* tw, InterLayout lay, float time, float L) {
     using G = Geo<N, PSEL>;
     if (batch_count > 1 && !batched_launches<N>) return -8;
+    if constexpr (G::fpar) {
+        if (batch_count > 1) {                          // as Launch<N>::pass1_batch_kernel of csrc/ocean_api.hip: the throughput geometry, unshared normalisation
+            using GB = Geo<N, 2, true>;
+            if (f16) emu_launch(GB::half_grid1, GB::half_threads1,
+                                [&] { k_half_pass1<N, GB::E1, GB::P, true, GB::dma, GB::fpar, false>(h0T, descale, omT, inter, nyq, tw, lay, time, L, 0, batch); }, batch_count);
+            else emu_launch(GB::half_grid1, GB::half_threads1,
+                            [&] { k_half_pass1<N, GB::E1, GB::P, false, GB::dma, GB::fpar, false>(h0T, 1.0f, omT, inter, nyq, tw, lay, time, L, 0, batch); }, batch_count);
+            emu_launch(G::half_grid2, G::half_threads2,
+                       [&] { k_half_pass2<N, G::E2, CHUNK_W, G::R2h, G::p2_group, G::ppar, false, true>(inter, out, tw, lay, plane, plane_channel, batch); }, batch_count);
+            return 0;
+        }
+    }
     if (f16) emu_launch(G::half_grid1, G::half_threads1,
                         [&] { k_half_pass1<N, G::E1, G::P, true, G::dma, G::fpar>(h0T, descale, omT, inter, nyq, tw, lay, time, L, 0, batch); }, batch_count);
     else emu_launch(G::half_grid1, G::half_threads1,
