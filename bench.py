@@ -420,9 +420,31 @@ def main():
                     help="frames of the untimed loop behind the timed region that yields config.frame_ms_{median,p10,p90} (SURVEY 8d)")
     ap.add_argument("--ramp-frames", type=int, default=100, help="untimed frames before anything is measured (GPU clock ramp)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launch: seconds before the ranks are killed")
+    ap.add_argument("--no-pin", action="store_true", help="do not pin the rank to the cpus local to its GPU's NUMA node")
     ap.add_argument("--plumbing", action="store_true",
                     help="tests only: launcher + rendezvous + reductions + gather bookkeeping on gloo/CPU, no device work")
     args = ap.parse_args()
+
+    # More ranks than visible devices: one JSON error line within seconds instead of a rendezvous that times out.  In the
+    # process that only launches the ranks, and in a single-GPU run, the count comes from the library's own HIP runtime (no
+    # torch, no context); a rank of a distributed run asks torch after importing it (below) -- the library must not bring up
+    # its runtime in a process before torch has loaded its own copy.
+    def too_few_devices(have, want):
+        print(json.dumps({"metric": "ocean frames/sec (propagate + 3x 2-D iFFT + correction, one NxN tile per GPU)", "value": None,
+                          "unit": "frames/s", "n_gpus": want, "steps": args.steps, "warmup": args.warmup,
+                          "error": f"{want} ranks asked for, {max(have, 0)} HIP device(s) visible"}), flush=True)
+        sys.exit(2)
+
+    in_dist_rank = "WORLD_SIZE" in os.environ or os.environ.get("OCEAN_BENCH_FORCE_DIST") == "1"
+    if not args.plumbing and not in_dist_rank and os.environ.get("OCEAN_BENCH_SKIP_DEVICE_CHECK") != "1":   # (the switch: tests)
+        import gfx_ocean_amd as g0
+        try:
+            have = g0._lib.device_count()
+        except g0.OceanError as e:
+            have = -1
+            print(f"# bench.py: {e}", file=sys.stderr)
+        if have < args.gpus:
+            too_few_devices(have, args.gpus)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus, sys.argv[1:], args.launch_timeout))
@@ -453,6 +475,11 @@ def main():
         if args.plumbing:
             dist.init_process_group(backend="gloo")
         else:
+            if torch.cuda.device_count() < max(world, local_rank + 1) and os.environ.get("OCEAN_BENCH_SKIP_DEVICE_CHECK") != "1":
+                if rank == 0:
+                    sys.stdout = json_out
+                    too_few_devices(torch.cuda.device_count(), world)
+                sys.exit(2)
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     n_gpus = world if world > 1 else 1
@@ -463,6 +490,20 @@ def main():
     import gfx_ocean_amd as g
     seed = tile_seed(n, rank)
     line = None
+    # Rank r's host thread(s) on the NUMA node of GPU r (a 2-socket host; at N <= 1024 the frame rate is the host's submit rate,
+    # 5-7 us per frame): the cpus sysfs lists as local to the device's PCI function.  --no-pin leaves the placement to the OS.
+    affinity = {"pinned": False}
+    if not args.plumbing and not args.no_pin:
+        bus, node, cpus = g._lib.device_numa(local_rank)
+        affinity.update({"pci_bus_id": bus, "numa_node": node})
+        if cpus:
+            try:
+                allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
+                if allowed:
+                    os.sched_setaffinity(0, allowed)
+                    affinity.update({"pinned": True, "cpus": len(allowed)})
+            except OSError as e:
+                affinity["error"] = str(e)
 
     if args.plumbing:
         # ---- launcher / rendezvous / reduction / gather bookkeeping only; nothing is measured -----------------
@@ -484,7 +525,7 @@ def main():
         return
 
     h0, omega = g.synth.make_inputs(n, seed=seed)
-    dev = g.OceanDevice(n, device_ordinal=local_rank)
+    dev = g.OceanDevice(n, device_ordinal=local_rank, flags=g.CTX_FUSED_ONLY)   # the fused frame's buffers only (40 instead of 76-100 B/texel)
     dev.upload_spectrum(h0, omega, spectrum_fp16=(args.spectrum == "f16"))
     if args.intermediate == "bfp16":
         dev.set_intermediate(g.INTER_BFP16)
@@ -609,6 +650,7 @@ def main():
                                    f"three-complex-transform accounting of SURVEY 8d); seed N+rank",
                        "n": n, "spectrum": args.spectrum, "intermediate": args.intermediate, "normals": args.normals, "tiles": n_gpus,
                        "parallelism": f"tile-parallel x{n_gpus}, no data-path collective",
+                       "host_affinity": affinity,
                        "gpu_event_ms_per_step": frame_ms,
                        "frame_ms_median": spread["frame"]["median_ms"], "frame_ms_p10": spread["frame"]["p10_ms"],
                        "frame_ms_p90": spread["frame"]["p90_ms"],

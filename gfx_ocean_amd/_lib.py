@@ -17,7 +17,7 @@ STATUS_NAMES = {0: "OCEAN_OK", -1: "OCEAN_E_INVALID_ARG", -2: "OCEAN_E_UNSUPPORT
 
 # every symbol include/ocean_hip.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [
-    "ocean_abi_version", "ocean_context_create", "ocean_context_destroy", "ocean_last_error", "ocean_resolution",
+    "ocean_abi_version", "ocean_device_count", "ocean_device_pci_bus_id", "ocean_context_create", "ocean_context_create_ex", "ocean_context_flags", "ocean_context_destroy", "ocean_last_error", "ocean_resolution",
     "ocean_upload_spectrum", "ocean_upload_spectrum_f16", "ocean_spectrum_scale_log2", "ocean_read_spectrum",
     "ocean_fft_init", "ocean_fft_destroy", "ocean_propagation_init",
     "ocean_propagation_destroy", "ocean_correction_init", "ocean_correction_destroy", "ocean_propagate",
@@ -32,6 +32,40 @@ SYMBOLS = [
     "ocean_shard_cols", "ocean_shard_sync", "ocean_shard_stream",
     "ocean_tile_exchange_bytes", "ocean_tile_pass1", "ocean_tile_pass2",
 ]
+
+
+def device_count() -> int:
+    """Visible HIP devices (0 without a GPU or a driver)."""
+    return max(0, int(load_library().ocean_device_count()))
+
+
+def device_numa(ordinal: int):
+    """(pci bus id, NUMA node or None, cpu list or None) of HIP device `ordinal`, from sysfs."""
+    buf = ctypes.create_string_buffer(32)
+    if load_library().ocean_device_pci_bus_id(int(ordinal), buf, 32) != OCEAN_OK:
+        return None, None, None
+    bus = buf.value.decode().lower()
+    node, cpus = None, None
+    try:
+        with open(f"/sys/bus/pci/devices/{bus}/numa_node") as f:
+            node = int(f.read().strip())
+        with open(f"/sys/bus/pci/devices/{bus}/local_cpulist") as f:
+            cpus = parse_cpulist(f.read().strip())
+    except (OSError, ValueError):
+        pass
+    return bus, (node if node is not None and node >= 0 else None), (cpus or None)
+
+
+def parse_cpulist(text: str):
+    """"0-3,8,10-11" -> [0, 1, 2, 3, 8, 10, 11]"""
+    out = []
+    for part in text.split(","):
+        part = part.strip()
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
 
 
 class OceanError(RuntimeError):
@@ -84,7 +118,11 @@ def load_library():
     pp = ctypes.POINTER(vp)
     sig = {
         "ocean_abi_version": (i32, []),
+        "ocean_device_count": (i32, []),
+        "ocean_device_pci_bus_id": (i32, [i32, ctypes.c_char_p, i32]),
         "ocean_context_create": (i32, [i32, i32, pp]),
+        "ocean_context_create_ex": (i32, [i32, i32, ctypes.c_uint32, pp]),
+        "ocean_context_flags": (ctypes.c_uint32, [vp]),
         "ocean_context_destroy": (None, [vp]),
         "ocean_last_error": (ctypes.c_char_p, [vp]),
         "ocean_resolution": (i32, [vp]),

@@ -57,6 +57,7 @@ struct OceanContext {
     uint64_t generation = 0;    // unique per ocean_context_create (stage handles compare it)
     int device = 0;
     int n = 0;
+    uint32_t flags = 0;         // OCEAN_CTX_* of ocean_context_create_ex
     hipStream_t stream = nullptr;
     bool foreign_stream = false;  // some dispatch ran on a caller stream: readbacks then wait for the whole device
     hipEvent_t ev_a = nullptr, ev_b = nullptr;   // reused by ocean_time_frames (event creation is not free)
@@ -128,6 +129,21 @@ bool valid(const OceanContext* c) { return live(c) && c->magic == MAGIC_CTX; }
 template <class H> bool valid_stage(const H* h, uint32_t magic) {
     return live(h) && h->magic == magic && valid(h->ctx) && h->ctx->generation == h->generation;
 }
+
+// What a context created with OCEAN_CTX_FUSED_ONLY / OCEAN_CTX_TILE_RANK has no buffers for (ocean_context_create_ex).
+int32_t need_staged(OceanContext* c, const char* what) {
+    if (c->flags & OCEAN_CTX_FUSED_ONLY)
+        return fail(c, OCEAN_E_STATE, std::string(what) + ": this context was created with OCEAN_CTX_FUSED_ONLY and has no natural-layout "
+                                      "buffers (the staged dispatches, ocean_read/write_field, ocean_read_spectrum and non-reference quirks need them)");
+    return OCEAN_OK;
+}
+int32_t need_frame(OceanContext* c, const char* what) {
+    if (c->flags & OCEAN_CTX_TILE_RANK)
+        return fail(c, OCEAN_E_STATE, std::string(what) + ": this context was created with OCEAN_CTX_TILE_RANK and has neither an intermediate nor a "
+                                      "map of its own (only ocean_upload_spectrum* and ocean_tile_pass1/2 work on it)");
+    return OCEAN_OK;
+}
+#define NEED(expr) do { const int32_t st_ = (expr); if (st_ != OCEAN_OK) return st_; } while (0)
 
 struct DeviceGuard {
     int prev = -1;
@@ -452,9 +468,27 @@ extern "C" {
 
 int32_t ocean_abi_version(void) { return OCEAN_ABI_VERSION; }
 
+int32_t ocean_device_count(void) {
+    int count = 0;
+    const hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess) { (void)hip_fail(nullptr, e, "hipGetDeviceCount"); return (e == hipErrorNoDevice) ? 0 : OCEAN_E_HIP; }
+    return count;
+}
+int32_t ocean_device_pci_bus_id(int32_t device, char* out, int32_t capacity) {
+    if (!out || capacity < 16) return fail(nullptr, OCEAN_E_INVALID_ARG, "bus id buffer of at least 16 bytes");
+    const hipError_t e = hipDeviceGetPCIBusId(out, capacity, device);
+    if (e != hipSuccess) return hip_fail(nullptr, e, "hipDeviceGetPCIBusId");
+    return OCEAN_OK;
+}
+
 int32_t ocean_context_create(int32_t device, int32_t resolution, OceanContext** out_ctx) {
+    return ocean_context_create_ex(device, resolution, 0u, out_ctx);
+}
+int32_t ocean_context_create_ex(int32_t device, int32_t resolution, uint32_t flags, OceanContext** out_ctx) {
     if (!out_ctx) return fail(nullptr, OCEAN_E_INVALID_ARG, "out_ctx is NULL");
     *out_ctx = nullptr;
+    if (flags & ~(OCEAN_CTX_FUSED_ONLY | OCEAN_CTX_TILE_RANK)) return fail(nullptr, OCEAN_E_INVALID_ARG, "unknown context flags");
+    if (flags & OCEAN_CTX_TILE_RANK) flags |= OCEAN_CTX_FUSED_ONLY;
     if (!supported_n(resolution))
         return fail(nullptr, OCEAN_E_UNSUPPORTED_N, "resolution must be a power of two in [256, 16384]");
     int count = 0;
@@ -465,6 +499,7 @@ int32_t ocean_context_create(int32_t device, int32_t resolution, OceanContext** 
     if (!c) return fail(nullptr, OCEAN_E_OOM, "host allocation failed");
     c->device = device;
     c->n = resolution;
+    c->flags = flags;
     c->generation = g_generation.fetch_add(1);
     DeviceGuard guard(device);
     const size_t n2 = (size_t)resolution * resolution;
@@ -499,17 +534,26 @@ int32_t ocean_context_create(int32_t device, int32_t resolution, OceanContext** 
     CTX_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CTX_TRY(hipEventCreate(&c->ev_a));
     CTX_TRY(hipEventCreate(&c->ev_b));
-    CTX_TRY(hipMalloc((void**)&c->h0, n2 * sizeof(c32)));
-    CTX_TRY(hipMalloc((void**)&c->omega, n2 * sizeof(float)));
-    for (int f = 0; f < 3; ++f) CTX_TRY(hipMalloc((void**)&c->field[f], n2 * sizeof(c32)));
+    // One allocation per buffer the path in use needs (the reference sizes one allocation for exactly what it binds,
+    // src/render.rs:607-670): the natural-layout copies, fields and chunked hand-off of the staged path are 60 (36 at N >= 8192)
+    // of a full context's 100 (76) bytes per texel -- not allocated with OCEAN_CTX_FUSED_ONLY; a rank of a sharded tile
+    // (OCEAN_CTX_TILE_RANK) keeps the static inputs only: its intermediate and rows live in the caller's exchange buffers.
+    const bool staged = !(flags & OCEAN_CTX_FUSED_ONLY), framed = !(flags & OCEAN_CTX_TILE_RANK);
     OCEAN_DISPATCH(resolution, c->stage_chunked = L::G::stage_chunked);
-    if (c->stage_chunked)
-        for (int f = 0; f < 3; ++f) CTX_TRY(hipMalloc((void**)&c->cfield[f], c->lay.fs * sizeof(c32)));
+    if (staged) {
+        CTX_TRY(hipMalloc((void**)&c->h0, n2 * sizeof(c32)));
+        CTX_TRY(hipMalloc((void**)&c->omega, n2 * sizeof(float)));
+        for (int f = 0; f < 3; ++f) CTX_TRY(hipMalloc((void**)&c->field[f], n2 * sizeof(c32)));
+        if (c->stage_chunked)
+            for (int f = 0; f < 3; ++f) CTX_TRY(hipMalloc((void**)&c->cfield[f], c->lay.fs * sizeof(c32)));
+    }
     CTX_TRY(hipMalloc((void**)&c->h0T, n2 * sizeof(c32)));
     CTX_TRY(hipMalloc((void**)&c->omegaT, n2 * sizeof(float)));
-    CTX_TRY(hipMalloc((void**)&c->inter, 3 * c->lay_h.fs * sizeof(c32)));
     CTX_TRY(hipMalloc((void**)&c->nyq, 3 * (size_t)resolution * sizeof(c32)));
-    CTX_TRY(hipMalloc((void**)&c->out_own, n2 * sizeof(float4)));
+    if (framed) {
+        CTX_TRY(hipMalloc((void**)&c->inter, 3 * c->lay_h.fs * sizeof(c32)));
+        CTX_TRY(hipMalloc((void**)&c->out_own, n2 * sizeof(float4)));
+    }
     CTX_TRY(hipMalloc((void**)&c->tw, (size_t)resolution * sizeof(c32)));
     c->out = c->out_own;
     {
@@ -547,6 +591,7 @@ const char* ocean_last_error(const OceanContext* ctx) {
 }
 
 int32_t ocean_resolution(const OceanContext* ctx) { return valid(ctx) ? ctx->n : OCEAN_E_INVALID_ARG; }
+uint32_t ocean_context_flags(const OceanContext* ctx) { return valid(ctx) ? ctx->flags : 0u; }
 
 namespace {
 
@@ -566,17 +611,29 @@ int32_t upload_common(OceanContext* ctx, const float* h0_re_im, const float* ome
     // natural layout (the staged path; = the reference's initial_spec / omega_buffer), then the one-time re-layout for the
     // fused path on the device: h0T[x][y] = h0[y][x], omegaT likewise (k_transpose; round 2 did this on one host core:
     // 0.9 s at N = 8192, 2.2 s with the fp16 packing)
-    HIP_TRY(ctx, hipMemcpy(ctx->h0, h0_re_im, n2 * sizeof(c32), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(ctx->omega, omega, n2 * sizeof(float), hipMemcpyHostToDevice));
+    // (a fused-only context has no natural-layout copies: the upload lands in a staging buffer that lives for this call only)
+    struct Staging {
+        void* p = nullptr;
+        ~Staging() { if (p) (void)hipFree(p); }
+    } stage;
+    c32* h0_nat = ctx->h0;
+    float* om_nat = ctx->omega;
+    if (ctx->flags & OCEAN_CTX_FUSED_ONLY) {
+        HIP_TRY(ctx, hipMalloc(&stage.p, n2 * (sizeof(c32) + sizeof(float))));
+        h0_nat = reinterpret_cast<c32*>(stage.p);
+        om_nat = reinterpret_cast<float*>(h0_nat + n2);
+    }
+    HIP_TRY(ctx, hipMemcpy(h0_nat, h0_re_im, n2 * sizeof(c32), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(om_nat, omega, n2 * sizeof(float), hipMemcpyHostToDevice));
     const unsigned tiles = (unsigned)((n / 32) * (n / 32));
     hipStream_t s = ctx->stream;
     if (f16)
-        hipLaunchKernelGGL(k_quantise_f16_transpose, dim3(tiles), dim3(256), 0, s, reinterpret_cast<float2*>(ctx->h0),
+        hipLaunchKernelGGL(k_quantise_f16_transpose, dim3(tiles), dim3(256), 0, s, reinterpret_cast<float2*>(h0_nat),
                            reinterpret_cast<uint32_t*>(ctx->h0T), (int)n, std::ldexp(1.0f, scale_log2), std::ldexp(1.0f, -scale_log2));
     else
-        hipLaunchKernelGGL(k_transpose<float2>, dim3(tiles), dim3(256), 0, s, reinterpret_cast<const float2*>(ctx->h0),
+        hipLaunchKernelGGL(k_transpose<float2>, dim3(tiles), dim3(256), 0, s, reinterpret_cast<const float2*>(h0_nat),
                            reinterpret_cast<float2*>(ctx->h0T), (int)n);
-    hipLaunchKernelGGL(k_transpose<float>, dim3(tiles), dim3(256), 0, s, (const float*)ctx->omega, ctx->omegaT, (int)n);
+    hipLaunchKernelGGL(k_transpose<float>, dim3(tiles), dim3(256), 0, s, (const float*)om_nat, ctx->omegaT, (int)n);
     { const int32_t st = check_launch(ctx, "upload re-layout launch"); if (st != OCEAN_OK) return st; }
     HIP_TRY(ctx, hipStreamSynchronize(s));
     ctx->h0_f16 = f16;
@@ -596,6 +653,7 @@ int32_t ocean_upload_spectrum_f16(OceanContext* ctx, const float* h0_re_im, cons
 int32_t ocean_spectrum_scale_log2(const OceanContext* ctx) { return valid(ctx) ? ctx->scale_log2 : OCEAN_E_INVALID_ARG; }
 int32_t ocean_read_spectrum(OceanContext* ctx, float* host_re_im) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    NEED(need_staged(ctx, "ocean_read_spectrum"));
     if (!host_re_im) return fail(ctx, OCEAN_E_INVALID_ARG, "NULL output");
     if (!ctx->uploaded) return fail(ctx, OCEAN_E_STATE, "ocean_upload_spectrum has not been called");
     DeviceGuard guard(ctx->device);
@@ -647,6 +705,7 @@ void ocean_correction_destroy(OceanCorrection* c) { if (live(c) && c->magic == M
 int32_t ocean_propagate(OceanPropagation* p, const OceanPropagateLocals* locals, void* stream) {
     if (!valid_stage(p, MAGIC_PRO)) return OCEAN_E_INVALID_ARG;
     OceanContext* c = p->ctx;
+    NEED(need_staged(c, "ocean_propagate"));
     if (!locals) return fail(c, OCEAN_E_INVALID_ARG, "locals is NULL");
     if (locals->resolution != c->n) return fail(c, OCEAN_E_INVALID_ARG, "PropagateLocals.resolution != context resolution");
     if (!(locals->domain_size > 0.0f)) return fail(c, OCEAN_E_INVALID_ARG, "domain_size must be > 0");
@@ -659,6 +718,7 @@ int32_t ocean_propagate(OceanPropagation* p, const OceanPropagateLocals* locals,
 static int32_t fft_pass_common(OceanFft* fft, int32_t field, void* stream, bool cols) {
     if (!valid_stage(fft, MAGIC_FFT)) return OCEAN_E_INVALID_ARG;
     OceanContext* c = fft->ctx;
+    NEED(need_staged(c, cols ? "ocean_fft_cols" : "ocean_fft_rows"));
     if (field != OCEAN_FIELD_ALL && (field < 0 || field > 2)) return fail(c, OCEAN_E_INVALID_ARG, "bad field selector");
     DeviceGuard guard(c->device);
     hipStream_t s = pick(c, stream);
@@ -673,6 +733,7 @@ int32_t ocean_fft_cols(OceanFft* fft, int32_t field, void* stream) { return fft_
 int32_t ocean_correct(OceanCorrection* cor, const OceanCorrectionLocals* locals, void* stream) {
     if (!valid_stage(cor, MAGIC_COR)) return OCEAN_E_INVALID_ARG;
     OceanContext* c = cor->ctx;
+    NEED(need_staged(c, "ocean_correct"));
     if (!locals) return fail(c, OCEAN_E_INVALID_ARG, "locals is NULL");
     if (locals->resolution != (uint32_t)c->n) return fail(c, OCEAN_E_INVALID_ARG, "CorrectionLocals.resolution != context resolution");
     DeviceGuard guard(c->device);
@@ -682,6 +743,7 @@ int32_t ocean_correct(OceanCorrection* cor, const OceanCorrectionLocals* locals,
 
 int32_t ocean_frame_ex(OceanContext* ctx, const OceanPropagateLocals* locals, void* stream) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    NEED(need_frame(ctx, "ocean_frame"));
     if (!locals) return fail(ctx, OCEAN_E_INVALID_ARG, "locals is NULL");
     if (locals->resolution != ctx->n) return fail(ctx, OCEAN_E_INVALID_ARG, "PropagateLocals.resolution != context resolution");
     if (!(locals->domain_size > 0.0f)) return fail(ctx, OCEAN_E_INVALID_ARG, "domain_size must be > 0");
@@ -693,6 +755,7 @@ int32_t ocean_frame_ex(OceanContext* ctx, const OceanPropagateLocals* locals, vo
 int32_t ocean_set_quirks(OceanContext* ctx, uint32_t quirks) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
     if (quirks & ~OCEAN_QUIRKS_REFERENCE) return fail(ctx, OCEAN_E_INVALID_ARG, "unknown quirk bits");
+    if (quirks != OCEAN_QUIRKS_REFERENCE) NEED(need_staged(ctx, "ocean_set_quirks (the fused kernels implement the reference quirks only)"));
     ctx->quirks = quirks;
     return OCEAN_OK;
 }
@@ -723,6 +786,7 @@ int32_t ocean_frame(OceanContext* ctx, float time, void* stream) {
 
 int32_t ocean_normals(OceanContext* ctx, int32_t source_channel, void* stream) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    NEED(need_frame(ctx, "ocean_normals"));
     if (source_channel < 0 || source_channel > 2) return fail(ctx, OCEAN_E_INVALID_ARG, "source_channel must be 0, 1 or 2");
     DeviceGuard guard(ctx->device);
     const size_t n2 = (size_t)ctx->n * ctx->n;
@@ -732,6 +796,7 @@ int32_t ocean_normals(OceanContext* ctx, int32_t source_channel, void* stream) {
 }
 int32_t ocean_set_frame_normals(OceanContext* ctx, int32_t source_channel) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    NEED(need_frame(ctx, "ocean_set_frame_normals"));
     if (source_channel < -1 || source_channel > 2) return fail(ctx, OCEAN_E_INVALID_ARG, "source_channel must be -1 (off), 0, 1 or 2");
     if (source_channel >= 0) {
         DeviceGuard guard(ctx->device);
@@ -756,6 +821,7 @@ int32_t ocean_read_normals(OceanContext* ctx, float* host_xyz0) {
 
 int32_t ocean_positions(OceanContext* ctx, int32_t verts, float offset_x, float offset_z, void* stream) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    NEED(need_frame(ctx, "ocean_positions"));
     if (verts < 2 || verts > 16384) return fail(ctx, OCEAN_E_INVALID_ARG, "verts must be in [2, 16384]");
     DeviceGuard guard(ctx->device);
     const size_t nv = (size_t)verts * verts;
@@ -792,6 +858,7 @@ int32_t ocean_sync(OceanContext* ctx) {
 // ---- device-side consumers of the map: checksum (reproducibility tests), packed copies (final gather) ----------
 int32_t ocean_checksum_displacement(OceanContext* ctx, void* stream, uint64_t* out_sum) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    NEED(need_frame(ctx, "ocean_checksum_displacement"));
     if (!out_sum) return fail(ctx, OCEAN_E_INVALID_ARG, "NULL output");
     DeviceGuard guard(ctx->device);
     hipStream_t s = pick(ctx, stream);
@@ -820,6 +887,7 @@ int64_t ocean_packed_bytes(const OceanContext* ctx, int32_t format) {
 }
 int32_t ocean_pack_displacement(OceanContext* ctx, int32_t format, void* device_out, void* stream) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    NEED(need_frame(ctx, "ocean_pack_displacement"));
     if (!device_out || (reinterpret_cast<uintptr_t>(device_out) & 15u))
         return fail(ctx, OCEAN_E_INVALID_ARG, "packed output must be a 16-byte aligned device pointer");
     if (format != OCEAN_PACK_RGBA32F && format != OCEAN_PACK_RGB32F && format != OCEAN_PACK_HEIGHT32F)
@@ -840,6 +908,7 @@ int32_t ocean_pack_displacement(OceanContext* ctx, int32_t format, void* device_
 // ---- readback / injection ---------------------------------------------------------------------
 int32_t ocean_read_displacement(OceanContext* ctx, float* host_rgba) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    NEED(need_frame(ctx, "ocean_read_displacement"));
     if (!host_rgba) return fail(ctx, OCEAN_E_INVALID_ARG, "NULL output");
     DeviceGuard guard(ctx->device);
     HIP_TRY(ctx, sync_for_readback(ctx));
@@ -848,6 +917,7 @@ int32_t ocean_read_displacement(OceanContext* ctx, float* host_rgba) {
 }
 int32_t ocean_read_field(OceanContext* ctx, int32_t field, float* host_re_im) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    NEED(need_staged(ctx, "ocean_read_field"));
     if (!host_re_im || field < 0 || field > 2) return fail(ctx, OCEAN_E_INVALID_ARG, "bad field or NULL output");
     DeviceGuard guard(ctx->device);
     // The field may live in the chunked hand-off layout: natural copy first.  The un-chunk runs on the context stream,
@@ -861,6 +931,7 @@ int32_t ocean_read_field(OceanContext* ctx, int32_t field, float* host_re_im) {
 }
 int32_t ocean_write_field(OceanContext* ctx, int32_t field, const float* host_re_im) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    NEED(need_staged(ctx, "ocean_write_field"));
     if (!host_re_im || field < 0 || field > 2) return fail(ctx, OCEAN_E_INVALID_ARG, "bad field or NULL input");
     DeviceGuard guard(ctx->device);
     HIP_TRY(ctx, sync_for_readback(ctx));
@@ -873,6 +944,7 @@ int32_t ocean_write_field(OceanContext* ctx, int32_t field, const float* host_re
 void* ocean_displacement_device_ptr(OceanContext* ctx) { return valid(ctx) ? (void*)ctx->out : nullptr; }
 int32_t ocean_bind_displacement(OceanContext* ctx, void* device_rgba) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    NEED(need_frame(ctx, "ocean_bind_displacement"));
     if (device_rgba && (reinterpret_cast<uintptr_t>(device_rgba) & 15u))
         return fail(ctx, OCEAN_E_INVALID_ARG, "displacement buffer must be 16-byte aligned");
     ctx->out = device_rgba ? (float4*)device_rgba : ctx->out_own;
@@ -922,6 +994,7 @@ int32_t ocean_tile_pass2(OceanContext* ctx, int32_t rank, int32_t world, int32_t
 // ---- K time steps of one tile per launch pair (the latency-bound sizes) -------------------------------------------------
 namespace {
 int32_t batch_check(OceanContext* ctx, int32_t count) {
+    NEED(need_frame(ctx, "ocean_frame_batch"));
     if (count < 1 || count > OCEAN_BATCH_MAX) return fail(ctx, OCEAN_E_INVALID_ARG, "count must be in [1, OCEAN_BATCH_MAX]");
     if (!ctx->uploaded) return fail(ctx, OCEAN_E_STATE, "ocean_upload_spectrum has not been called");
     if (ctx->quirks != OCEAN_QUIRKS_REFERENCE) return fail(ctx, OCEAN_E_STATE, "the fused kernels implement the reference quirks only (ocean_set_quirks)");
@@ -1014,6 +1087,7 @@ int32_t ocean_time_frame_batch(OceanContext* ctx, int32_t launches, int32_t coun
 // ---- measurement ----------------------------------------------------------------------------------
 int32_t ocean_time_frames(OceanContext* ctx, int32_t frames, float t0, float dt, float* out_ms) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    NEED(need_frame(ctx, "ocean_time_frames"));
     if (frames <= 0 || !out_ms) return fail(ctx, OCEAN_E_INVALID_ARG, "frames must be > 0 and out_ms non-NULL");
     if (!ctx->uploaded) return fail(ctx, OCEAN_E_STATE, "ocean_upload_spectrum has not been called");
     DeviceGuard guard(ctx->device);
@@ -1029,6 +1103,8 @@ int32_t ocean_time_frames(OceanContext* ctx, int32_t frames, float t0, float dt,
 static int32_t profile_common(OceanContext* ctx, float time, int32_t cap, const char** names, float* ms,
                               int32_t* out_n, bool staged) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    NEED(need_frame(ctx, "ocean_profile_*"));
+    if (staged) NEED(need_staged(ctx, "ocean_profile_staged"));
     if (!names || !ms || !out_n) return fail(ctx, OCEAN_E_INVALID_ARG, "NULL output");
     if (!ctx->uploaded) return fail(ctx, OCEAN_E_STATE, "ocean_upload_spectrum has not been called");
     static const char* kNatural[8] = {"k_propagate", "k_fft_lines<ROW> dx", "k_fft_lines<ROW> dy", "k_fft_lines<ROW> dz",
@@ -1093,6 +1169,7 @@ static int32_t profile_common(OceanContext* ctx, float time, int32_t cap, const 
 // (an event per FRAME adds ~5 % of gaps: measured r04_run3, 193 against 185.5 us at N = 4096; one per 10 frames does not).
 int32_t ocean_time_frame_batches(OceanContext* ctx, int32_t batches, int32_t frames_per_batch, float t0, float dt, float* batch_ms) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    NEED(need_frame(ctx, "ocean_time_frame_batches"));
     if (batches <= 0 || batches > 4096 || frames_per_batch <= 0 || frames_per_batch > 4096 || !batch_ms)
         return fail(ctx, OCEAN_E_INVALID_ARG, "batches and frames_per_batch in [1, 4096], batch_ms non-NULL");
     if (!ctx->uploaded) return fail(ctx, OCEAN_E_STATE, "ocean_upload_spectrum has not been called");
@@ -1119,6 +1196,7 @@ int32_t ocean_time_frame_batches(OceanContext* ctx, int32_t batches, int32_t fra
 int32_t ocean_frame_times_ex(OceanContext* ctx, int32_t frames, float t0, float dt, float* pass1_ms, float* pass2_ms, float* normals_ms,
                              float* period_ms) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    NEED(need_frame(ctx, "ocean_frame_times"));
     if (frames <= 0 || frames > 4096) return fail(ctx, OCEAN_E_INVALID_ARG, "frames must be in [1, 4096]");
     if (!ctx->uploaded) return fail(ctx, OCEAN_E_STATE, "ocean_upload_spectrum has not been called");
     if (ctx->quirks != OCEAN_QUIRKS_REFERENCE)

@@ -10,6 +10,7 @@ from ._lib import OCEAN_OK, OceanError, load_library
 from .fft import FIELD_ALL, FIELD_DX, FIELD_DY, FIELD_DZ, Fft
 
 QUIRK_Q1, QUIRK_Q2, QUIRKS_REFERENCE = 1, 2, 3      # include/ocean_hip.h OCEAN_QUIRK_*
+CTX_FUSED_ONLY, CTX_TILE_RANK = 1, 2   # include/ocean_hip.h OCEAN_CTX_*
 INTER_F32, INTER_BFP16 = 0, 1                         # include/ocean_hip.h OCEAN_INTER_*
 PACK_RGBA32F, PACK_RGB32F, PACK_HEIGHT32F = 0, 1, 2   # include/ocean_hip.h OCEAN_PACK_*
 PACK_BYTES_PER_TEXEL = {PACK_RGBA32F: 16, PACK_RGB32F: 12, PACK_HEIGHT32F: 4}
@@ -20,10 +21,12 @@ class OceanDevice:
     """One GPU + the buffers of the path (initial_spec, omega, dx/dy/dz_spec, displacement map:
     src/render.rs:607-670, 820-869)."""
 
-    def __init__(self, resolution: int, device_ordinal: int = 0):
+    def __init__(self, resolution: int, device_ordinal: int = 0, flags: int = 0):
+        """flags: 0 = both paths' buffers; CTX_FUSED_ONLY = the fused frame's only (40 instead of 100 / 76 B/texel; the staged
+        dispatches then raise OCEAN_E_STATE); CTX_TILE_RANK = one rank of a sharded tile (static inputs only, 12 B/texel)."""
         lib = load_library()
         ctx = ctypes.c_void_p()
-        st = lib.ocean_context_create(int(device_ordinal), int(resolution), ctypes.byref(ctx))
+        st = lib.ocean_context_create_ex(int(device_ordinal), int(resolution), int(flags), ctypes.byref(ctx))
         if st != OCEAN_OK:
             raise OceanError(st, (lib.ocean_last_error(None) or b"").decode())
         self._ctx = ctx

@@ -24,7 +24,11 @@ pub struct OceanCorrectionLocals { pub resolution: u32 }
 
 extern "C" {
     pub fn ocean_abi_version() -> i32;
+    pub fn ocean_device_count() -> i32;
+    pub fn ocean_device_pci_bus_id(device: i32, out: *mut c_char, capacity: i32) -> i32;
     pub fn ocean_context_create(device: i32, resolution: i32, out: *mut *mut OceanContext) -> i32;
+    pub fn ocean_context_create_ex(device: i32, resolution: i32, flags: u32, out: *mut *mut OceanContext) -> i32;
+    pub fn ocean_context_flags(ctx: *const OceanContext) -> u32;
     pub fn ocean_context_destroy(ctx: *mut OceanContext);
     pub fn ocean_last_error(ctx: *const OceanContext) -> *const c_char;
     pub fn ocean_resolution(ctx: *const OceanContext) -> i32;

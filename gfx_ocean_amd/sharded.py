@@ -173,17 +173,24 @@ class HipTileBackend:
     `all_to_all_single` only at world = 1; every rank's KERNELS of world 2 / 4 / 8 are checked on one device against the
     oracle (tests/test_sharded.py), the multi-rank driver under gloo on the CPU emulation backend.
 
-    Every rank keeps the whole tile's static inputs (12 B/texel, uploaded once): pass 1 of rank r reads only the 4/R of
-    the transposed lines its column block touches (lines x, x-1, N-x, N-1-x for its x), but they are scattered over the
-    whole of h0T / omegaT -- two bands around r N/2R and N - r N/2R -- and the context's upload, transposes and the
-    single-GPU `ocean_frame` share those buffers; with 288 GB per GPU the 1.5 GiB of a 8192 tile is not what limits a rank."""
+    The context is an OCEAN_CTX_TILE_RANK one: the whole tile's static inputs (12 B/texel, uploaded once: 3 GiB at
+    N = 16384) and nothing else -- no staged buffers, no intermediate, no map; the exchange buffers and the rank's rows are
+    torch's.  [Round 4 used a full context: 76-100 B/texel, 20 GiB per rank at 16384.]  Pass 1 of rank r reads only the
+    4/R of the transposed lines its column block touches (lines x, x-1, N-x, N-1-x for its x: two bands around r N/2R and
+    N - r N/2R, each with one line that wraps around the tile's edge on rank 0); keeping just those bands would need the
+    kernels' line indices rebased per band and is not done: 12 B/texel of a 288 GB device is not what limits a rank.
+
+    `trace` (a list, or None): when set, every stream-ordering step of a frame is appended to it -- what
+    tests/test_sharded.py checks before the first multi-GPU run has to debug RCCL rather than bookkeeping."""
 
     def __init__(self, n: int, rank: int, world: int, device_ordinal: int = 0, parts: int = 1):
         import torch
         from .render import OceanDevice
         self.torch = torch
         self.lib = load_library()
-        self.dev = OceanDevice(n, device_ordinal)
+        from .render import CTX_TILE_RANK
+        self.dev = OceanDevice(n, device_ordinal, flags=CTX_TILE_RANK)
+        self.trace = None
         self.n, self.rank, self.world, self.rows, self.parts = n, rank, world, n // world, parts
         self.device = torch.device("cuda", device_ordinal)
         self.stream = torch.cuda.Stream(self.device)          # see HipShardBackend: explicit streams for kernels and collectives
@@ -206,20 +213,29 @@ class HipTileBackend:
 
     def pass1(self, time, domain_size, send_part, part=0):
         loc = PropagateLocalsC(float(time), int(self.n), float(domain_size))
+        self._t("pass1", "compute", int(part))
         self.dev._check(self.lib.ocean_tile_pass1(self.dev._ctx, ctypes.byref(loc), self.rank, self.world, int(part), self.parts,
                                                   send_part.data_ptr(), self.stream.cuda_stream))
 
+    def _t(self, *what):
+        if self.trace is not None:
+            self.trace.append(what)
+
     def pass2(self, recv, out):
+        self._t("pass2", "compute")
         self.dev._check(self.lib.ocean_tile_pass2(self.dev._ctx, self.rank, self.world, self.parts, recv.data_ptr(), out.data_ptr(),
                                                   self.stream.cuda_stream))
 
     def exchange(self, dist, recv_part, send_part):
         """The all-to-all of one part on the communication stream, behind everything the compute stream holds so far."""
+        self._t("wait", "comm", "compute")
         self.comm.wait_stream(self.stream)
         with self.torch.cuda.stream(self.comm):
+            self._t("all_to_all", "comm", int(recv_part.data_ptr()), int(send_part.data_ptr()))
             dist.all_to_all_single(recv_part, send_part)
 
     def join_exchanges(self):
+        self._t("wait", "compute", "comm")
         self.stream.wait_stream(self.comm)                    # pass 2 (and the next frame's pass 1) behind every all-to-all
 
     def synchronize(self):

@@ -42,7 +42,9 @@ extern "C" {
  * 3: + ocean_frame_times, ocean_time_frame_batches; ocean_sync and ocean_context_destroy honour caller streams like the readbacks
  * 4: + ocean_set_frame_normals, ocean_frame_normals, ocean_normals_device_ptr, ocean_frame_times_ex (the frame with the normal
  *    field as one workload); + ocean_frame_batch, ocean_batch_device_ptr, ocean_read_batch_displacement, ocean_time_frame_batch
- *    (K time steps per launch pair); ocean_time_frame_batches also bounds frames_per_batch (<= 4096) */
+ *    (K time steps per launch pair); + ocean_context_create_ex, ocean_context_flags (contexts with only the fused path's buffers); + ocean_device_count,
+ *    ocean_device_pci_bus_id;
+ *    ocean_time_frame_batches also bounds frames_per_batch (<= 4096) */
 #define OCEAN_ABI_VERSION 4
 
 /* ---- status codes ------------------------------------------------------------------------- */
@@ -82,7 +84,26 @@ typedef struct OceanCorrection OceanCorrection;   /* src/ocean.rs:184-191 `Corre
 
 /* ---- context: device open + buffer allocation (src/render.rs:118-172, 607-729, 820-869) ---- */
 int32_t ocean_abi_version(void);
+/* Visible HIP devices (0 if none; < 0: error status), and the PCI bus id "dddd:bb:dd.f" of one of them -- what a launcher needs to
+ * fail fast when asked for more ranks than there are GPUs and to place rank r's host thread on the NUMA node of GPU r
+ * (/sys/bus/pci/devices/<id>/numa_node, local_cpulist; bench.py).  No context needed. */
+int32_t ocean_device_count(void);
+int32_t ocean_device_pci_bus_id(int32_t device_ordinal, char* out, int32_t capacity /* >= 16 */);
 int32_t ocean_context_create(int32_t device_ordinal, int32_t resolution, OceanContext** out_ctx);
+/* ... with exactly the buffers the caller's path uses (the reference sizes one allocation for what it binds, src/render.rs:607-670).
+ * A full context holds both paths' buffers: 100 B/texel at N <= 4096 (1.6 GiB at 4096), 76 above (20 GiB at 16384).
+ *   OCEAN_CTX_FUSED_ONLY  no natural-layout copies, fields or chunked hand-off (the staged path's 60 / 36 B/texel): ocean_frame*,
+ *                         the consumers, the batch, the measurement loops and ocean_tile_pass1/2 work; ocean_propagate,
+ *                         ocean_fft_rows/cols, ocean_correct, ocean_read/write_field, ocean_read_spectrum, ocean_profile_staged and
+ *                         non-reference quirks return OCEAN_E_STATE with a message.  40 B/texel (10 GiB at 16384); the upload goes
+ *                         through a staging buffer that lives for the call.
+ *   OCEAN_CTX_TILE_RANK   one rank of a tile sharded over several GPUs (implies FUSED_ONLY): the static inputs only, 12 B/texel --
+ *                         the intermediate and the rows live in the caller's exchange buffers; everything but the upload and
+ *                         ocean_tile_pass1/2 returns OCEAN_E_STATE. */
+#define OCEAN_CTX_FUSED_ONLY 1u
+#define OCEAN_CTX_TILE_RANK 2u
+int32_t ocean_context_create_ex(int32_t device_ordinal, int32_t resolution, uint32_t flags, OceanContext** out_ctx);
+uint32_t ocean_context_flags(const OceanContext* ctx);
 void ocean_context_destroy(OceanContext* ctx);            /* NULL-safe; src/render.rs:1383-1438 */
 const char* ocean_last_error(const OceanContext* ctx);    /* ctx may be NULL: last error of a failed create */
 int32_t ocean_resolution(const OceanContext* ctx);

@@ -33,6 +33,15 @@ def hip():
     return _HIP
 
 
+def free_bytes() -> int:
+    """hipMemGetInfo's free figure for the current device (after everything enqueued has completed)."""
+    assert hip().hipDeviceSynchronize() == 0
+    free, total = ctypes.c_size_t(), ctypes.c_size_t()
+    hip().hipMemGetInfo.argtypes = [ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
+    assert hip().hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+    return int(free.value)
+
+
 class DeviceBuffer:
     """hipMalloc'ed bytes; .ptr is the device address the C ABI takes."""
 

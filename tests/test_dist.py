@@ -39,6 +39,36 @@ def test_byte_accounting_tables():
     assert sum(bench.CONTRACT_BYTES_PER_TEXEL["f16"].values()) == 72.0
 
 
+def test_byte_accounting_with_the_normal_field():
+    """BASELINE config 3 as one workload: pass 2 also writes the source-channel plane (+4), the normal-field kernel moves 4 + 16
+    and is priced on its algorithmic 4 + 12."""
+    m = bench.moved_bytes_per_texel(2048, normals=True)
+    assert m == {"pass1": 26.0, "pass2": 32.0, "normals": 20.0}
+    assert bench.NORMALS_ALGORITHMIC_BYTES_PER_TEXEL == 16.0 and bench.pass_of("k_normals_plane") == "normals"
+    assert bench.traffic_suffix("f32", "f32", True) == "_normals" and bench.traffic_suffix("f16", "bfp16") == "_f16_bfp16"
+
+
+def test_more_ranks_than_devices_fails_fast_with_one_json_line():
+    """`--gpus N` with fewer visible devices: one JSON error line and exit status 2 within seconds, not a rendezvous timeout
+    (this container has no GPU; on a GPU box the same holds for N > device count)."""
+    import time
+    import gfx_ocean_amd as g
+    want = g._lib.device_count() + 2
+    t0 = time.time()
+    p = subprocess.run([sys.executable, BENCH, "--gpus", str(want), "--steps", "2"], capture_output=True, text=True, timeout=60)
+    assert time.time() - t0 < 5.0 + 25.0 * (g._lib.device_count() > 0)      # (library load on a cold box)
+    assert p.returncode == 2
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["value"] is None and r["n_gpus"] == want and "visible" in r["error"]
+
+
+def test_cpulist_parser():
+    from gfx_ocean_amd import _lib
+    assert _lib.parse_cpulist("0-3,8,10-11") == [0, 1, 2, 3, 8, 10, 11] and _lib.parse_cpulist("") == [] and _lib.parse_cpulist("5") == [5]
+
+
 def _check_two_rank_line(stdout):
     lines = [l for l in stdout.splitlines() if l.strip()]
     assert len(lines) == 1, f"exactly one line on stdout, got {len(lines)}: {stdout[-2000:]}"
@@ -138,6 +168,7 @@ def test_two_ranks_under_torch_distributed_run():
 def test_failed_rank_fails_the_launch():
     """A rank that dies takes the launch down with a non-zero exit code instead of hanging the others."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["OCEAN_BENCH_SKIP_DEVICE_CHECK"] = "1"                   # past the launcher's own device count: the RANKS must fail
     p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--n", "300"],      # no GPU here + bad N: every rank fails
                        capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode != 0

@@ -438,6 +438,61 @@ def test_frame_batch_is_bit_identical_to_single_frames(n, count, own, fp16):
         d.destroy()
 
 
+@pytest.mark.parametrize("n", [2048, 8192])
+def test_fused_only_and_tile_rank_contexts(n):
+    """ocean_context_create_ex: a fused-only context allocates 40 instead of 100 (N <= 4096) / 76 B/texel and computes the same
+    frame bit for bit; the staged entry points refuse with OCEAN_E_STATE and a message; a tile-rank context holds the static
+    inputs only (12 B/texel).  Footprints by hipMemGetInfo."""
+    import hipmem
+    h0, om = g.synth.make_inputs(n, seed=41)
+    n2 = n * n
+    slack = 64 << 20                                              # allocator granularity, twiddles, scratch
+    before = hipmem.free_bytes()
+    full = g.OceanDevice(n)
+    used_full = before - hipmem.free_bytes()
+    full.upload_spectrum(h0, om)
+    full.frame(1.25)
+    want = full.checksum()
+    full.destroy()
+    assert abs(hipmem.free_bytes() - before) <= slack             # everything came back
+    fo = g.OceanDevice(n, flags=g.CTX_FUSED_ONLY)
+    try:
+        used_fo = before - hipmem.free_bytes()
+        per_texel_full = 100 if n <= 4096 else 76
+        assert abs(used_full - per_texel_full * n2) <= slack, (used_full / n2)
+        assert abs(used_fo - 40 * n2) <= slack, (used_fo / n2)
+        fo.upload_spectrum(h0, om)
+        assert abs((before - hipmem.free_bytes()) - 40 * n2) <= slack      # the upload's staging buffer is gone again
+        fo.frame(1.25)
+        assert fo.checksum() == want
+        fo.upload_spectrum(h0, om, spectrum_fp16=True)
+        fo.frame(1.25)
+        assert fo.checksum() != want
+        lib = g.load_library()
+        assert lib.ocean_context_flags(fo._ctx) == g.CTX_FUSED_ONLY
+        for call in (lambda: fo.read_field(g.FIELD_DY), lambda: fo.set_quirks(0), lambda: fo.profile_staged(0.0), lambda: fo.read_spectrum()):
+            with pytest.raises(g.OceanError) as e:
+                call()
+            assert e.value.status == -5 and "OCEAN_CTX_FUSED_ONLY" in str(e.value)
+        prop = g.Propagation.init(fo)                             # a stage object of the staged path
+        with pytest.raises(g.OceanError) as e:
+            prop.dispatch(g.PropagateLocals(0.0, n, 1000.0))
+        assert e.value.status == -5
+    finally:
+        fo.destroy()
+    lib = g.load_library()
+    tr = g.OceanDevice(n, flags=g.CTX_TILE_RANK)
+    try:
+        assert abs((before - hipmem.free_bytes()) - 12 * n2) <= slack
+        tr.upload_spectrum(h0, om)
+        assert lib.ocean_context_flags(tr._ctx) == (g.CTX_FUSED_ONLY | g.CTX_TILE_RANK)
+        with pytest.raises(g.OceanError) as e:
+            tr.frame(0.0)
+        assert e.value.status == -5 and "OCEAN_CTX_TILE_RANK" in str(e.value)
+    finally:
+        tr.destroy()
+
+
 @pytest.mark.parametrize("verts,offset", [(128, (0.0, 0.0)), (128, (127.0, 127.0)), (257, (0.0, 0.0))])
 def test_vertex_positions(r512, ref_inputs, verts, offset):
     """the vertex stage's positions (shader/ocean.vert:21-25; patch grid and offsets of

@@ -315,7 +315,7 @@ def _fused_loopback_frame(n, world, t, h0, om, f16=False, parts=1):
     from hipmem import DeviceBuffer
     from gfx_ocean_amd._lib import PropagateLocalsC, load_library
     lib = load_library()
-    d = g.OceanDevice(n)
+    d = g.OceanDevice(n, flags=0 if f16 else g.CTX_TILE_RANK)     # (the f16 case reads the dequantised spectrum back: a full context)
     bufs = []
     try:
         d.upload_spectrum(h0, om, spectrum_fp16=f16)
@@ -440,11 +440,23 @@ os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER
 torch.cuda.set_device(0)
 dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))   # RCCL, world 1: the collective call itself
 h0, om = g.synth.make_inputs(n, seed=9)
-for parts in (1, 4):                       # 4: the pipelined exchange -- four all-to-alls on the communication stream
-    tile = sharded.FusedShardedTile(sharded.HipTileBackend(n, 0, 1, parts=parts), dist)
+for parts in (1, 2, 4):                    # 2, 4: the pipelined exchange -- that many all-to-alls on the communication stream
+    be = sharded.HipTileBackend(n, 0, 1, parts=parts)
+    assert g.load_library().ocean_context_flags(be.dev._ctx) == (g.CTX_FUSED_ONLY | g.CTX_TILE_RANK)   # static inputs only
+    tile = sharded.FusedShardedTile(be, dist)
     tile.upload(h0, om)
     for rep in range(3):                   # consecutive frames reuse the exchange buffers behind the right events
+        be.trace = [] if rep == 2 else None
         tile.frame(2.25)
+    # the stream order of a frame (what the first multi-GPU run must not have to debug): pass 1 of part k on the compute
+    # stream, the communication stream waits for it, the all-to-all of part k (its own slices of the buffers), ...; the
+    # compute stream waits for the communication stream exactly once, right before pass 2
+    want = []
+    for k in range(parts):
+        want += [("pass1", "compute", k), ("wait", "comm", "compute"), ("all_to_all", "comm", tile.recv[k].data_ptr(), tile.send[k].data_ptr())]
+    want += [("wait", "compute", "comm"), ("pass2", "compute")]
+    assert be.trace == want, (parts, be.trace, want)
+    assert len({tile.send[k].data_ptr() for k in range(parts)}) == parts
     got = tile.gather_tile()
     nmax, rl2 = oc.parity_errors(got[..., :3], oc.frame_f64(h0, om, 2.25)[..., :3])
     assert nmax.max() < 2e-5 and rl2.max() < 2e-5 and np.all(got[..., 3] == 0.0), (parts, nmax, rl2)
