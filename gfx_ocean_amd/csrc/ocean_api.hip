@@ -430,6 +430,7 @@ void launch_normals_plane(OceanContext* c, hipStream_t s, Timing t = Timing()) {
     switch (rows) {
         case 2: launch(k_normals_plane<2>, grid, b, 0, s, t, plane, c->normals, c->n); break;
         case 4: launch(k_normals_plane<4>, grid, b, 0, s, t, plane, c->normals, c->n); break;
+        case 16: launch(k_normals_plane<16>, grid, b, 0, s, t, plane, c->normals, c->n); break;
         default: launch(k_normals_plane<8>, grid, b, 0, s, t, plane, c->normals, c->n); break;
     }
 }

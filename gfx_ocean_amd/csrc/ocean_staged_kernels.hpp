@@ -176,7 +176,8 @@ k_normals(const float4* __restrict__ rgba, float4* __restrict__ normals, int n, 
 // XCDs in contiguous ranges, so that a band's two halo rows are L2 hits.  grid = (N / 256) * (N / ROWS) / 4 workgroups of
 // four waves; N >= 256, N / ROWS >= 4.
 // Same arithmetic on the same floats as k_normals: bit-identical normals (tests/test_gpu_parity.py).
-constexpr int normals_plane_rows(int n) { return (n >= 2048) ? 8 : ((n >= 1024) ? 4 : 2); }
+// (rows per wave: 16 against 8 at N = 4096: 50.9-51.2 against 52.2-52.4 us, two halo rows per 16 instead of per 8; r05_run7)
+constexpr int normals_plane_rows(int n) { return (n >= 4096) ? 16 : ((n >= 2048) ? 8 : ((n >= 1024) ? 4 : 2)); }
 template <int ROWS>
 __global__ void __launch_bounds__(256)
 k_normals_plane(const float* __restrict__ plane, float4* __restrict__ normals, int n) {

@@ -309,6 +309,7 @@ int emu_normals_plane(int n, const float* src_plane, float* normals) {
     const int grid = (n / 256) * (n / rows) / 4;
     if (rows == 2) emu_launch(grid, 256, [&] { k_normals_plane<2>(src_plane, (float4*)normals, n); });
     else if (rows == 4) emu_launch(grid, 256, [&] { k_normals_plane<4>(src_plane, (float4*)normals, n); });
+    else if (rows == 16) emu_launch(grid, 256, [&] { k_normals_plane<16>(src_plane, (float4*)normals, n); });
     else emu_launch(grid, 256, [&] { k_normals_plane<8>(src_plane, (float4*)normals, n); });
     return 0;
 }
