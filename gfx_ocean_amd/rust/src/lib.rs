@@ -48,6 +48,14 @@ impl Device {
         if st != 0 { return Err(Box::new(error(ptr::null(), st))); }
         Ok(Device { ctx })
     }
+    /// A context with only the buffers `frame` needs (include/ocean_hip.h `OCEAN_CTX_FUSED_ONLY`: 40 instead of 76-100 bytes per
+    /// texel); the staged stage objects then fail with `OCEAN_E_STATE`.
+    pub fn fused_only(ordinal: i32, resolution: i32) -> Result<Self, Box<dyn Error>> {
+        let mut ctx = ptr::null_mut();
+        let st = unsafe { ffi::ocean_context_create_ex(ordinal, resolution, 1, &mut ctx) };
+        if st != 0 { return Err(Box::new(error(ptr::null(), st))); }
+        Ok(Device { ctx })
+    }
     fn check(&self, st: i32) -> Result<(), Box<dyn Error>> {
         if st == 0 { Ok(()) } else { Err(Box::new(error(self.ctx, st))) }
     }
