@@ -129,6 +129,15 @@ __device__ __forceinline__ void ocean_tl_hwid(unsigned long long* slot) {
 #define OCEAN_TL(k)
 #endif
 
+// The wave's slot on its SIMD (HW_ID.WAVE_ID, bits 3:0).
+__device__ __forceinline__ unsigned hw_wave_slot() {
+    unsigned id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(id));
+    return id;
+}
+
+__device__ __forceinline__ void wave_sleep_127() { __builtin_amdgcn_s_sleep(127); }   // 127 x 64 clocks = 3.4 us at 2.4 GHz
+
 // sin / cos of 2*pi*x for x in [-0.5, 0.5] revolutions: the gfx950 transcendental unit
 // (v_sin_f32 / v_cos_f32 take their argument in revolutions).  Measured max abs error on that
 // interval: 1.25e-7 (tools/sincos_acc.hip; ocml's sincospif: 5.2e-8) at 2 instructions instead of ~45.

@@ -557,6 +557,19 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
     const uint32_t x2 = (N - x) & (N - 1);
     c32 A[E], B[E];
     OCEAN_TL(0);
+    // N = 2048 is ONE dispatch round of 512 workgroups, two per CU, that start together: the whole chip loads, then the whole
+    // chip transforms.  The second workgroup of a CU -- known by its waves' slots on their SIMDs (HW_ID.WAVE_ID: a 512-thread
+    // workgroup is two waves per SIMD, the first arrival gets slots 0 and 1), not by the dispatch order -- starts 3.4 us late
+    // (s_sleep 127 = 8128 clocks), so that one loads while the other transforms.  Timing only: the same bits.  A launch with
+    // at most one workgroup per CU (a part of a sharded tile) has no wave in a slot >= 2 and pays nothing; a wave that lands
+    // elsewhere only delays its own workgroup.  Measured (r05_run8, one box, three interleaved repetitions): pass 1
+    // 28.2-28.5 -> 27.3-27.6 us, 21.17-21.20k -> 21.60-21.77k frames/s; the same 3.4 us for the FIRST arrival instead:
+    // 21.6-21.7k as well (what pays is the offset); 2 us: 21.1-21.65k.  A second box (r05_run9): pass 1 26.8-26.9 -> 25.4-25.6 us,
+    // frame 45.9-46.4 -> 44.7 us (+3.3 %), with the normal field 61.5-61.7 -> 60.4 us.  [Round 4 had the offset by block index:
+    // +3 %, not shipped because it rested on the dispatch order.]
+    if constexpr (N == 2048 && DMA && P == 2 && !FPAR) {
+        if (hw_wave_slot() >= 2u) wave_sleep_127();
+    }
     if constexpr (DMA) {
         static_assert(DmaRing<N, E, P, H16, 1>::bytes <= 160 * 1024, "the DMA ring fits the LDS");
         half_load_AB_dma<N, E, P, H16, 1>(h0T, descale, omegaT, (uint32_t)(Xg * P), c, 0, j, tid, time, smem, A, B);

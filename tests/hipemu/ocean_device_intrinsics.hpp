@@ -32,6 +32,8 @@ static inline c32 unpack_half2(uint32_t bits, float descale) {
                        ocean_emu_half_to_float((uint16_t)(bits >> 16)) * descale);
 }
 static inline int wave_uniform(int x) { return x; }
+static inline unsigned hw_wave_slot() { return 0u; }
+static inline void wave_sleep_127() {}
 static inline float sin_rev(float x) { return (float)std::sin(6.283185307179586 * (double)x); }
 static inline float cos_rev(float x) { return (float)std::cos(6.283185307179586 * (double)x); }
 static inline void store_float4_nt(float4* p, float4 v) { *p = v; }
