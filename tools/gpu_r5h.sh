@@ -1,0 +1,10 @@
+#!/bin/bash
+set -u
+exec < /dev/null
+TAG=${1:-r5h}; O=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $O
+cd $GRAFT_REPO_ROOT
+for rep in 1 2 3; do
+  for so in gfx_ocean_amd/libocean_hip.so gfx_ocean_amd/variants/*.so; do
+    OCEAN_HIP_LIB=$PWD/$so timeout 600 python tools/normals_time.py ${SIZES:-2048} 2>&1 | tee -a $O/ab.jsonl
+  done
+done
