@@ -475,7 +475,7 @@ def main():
         if args.plumbing:
             dist.init_process_group(backend="gloo")
         else:
-            if torch.cuda.device_count() < max(world, local_rank + 1) and os.environ.get("OCEAN_BENCH_SKIP_DEVICE_CHECK") != "1":
+            if torch.cuda.device_count() <= local_rank and os.environ.get("OCEAN_BENCH_SKIP_DEVICE_CHECK") != "1":   # this rank has no GPU
                 if rank == 0:
                     sys.stdout = json_out
                     too_few_devices(torch.cuda.device_count(), world)

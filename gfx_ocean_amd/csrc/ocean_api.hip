@@ -15,6 +15,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <utility>
 #include <type_traits>
 #include <unordered_set>
 #include <vector>
@@ -68,6 +69,9 @@ struct OceanContext {
     // Staged path, N <= 4096: ocean_fft_rows hands the field to ocean_fft_cols / ocean_correct in the 4 x 4-chunk
     // layout (k_stage_rows / k_stage_cols, ocean_kernels.hpp).  Per field: which copy holds the current contents.
     c32* cfield[3] = {nullptr, nullptr, nullptr};  // chunked copies (layout `lay`), allocated with the context
+    // Staged path, N >= 8192: the column pass runs in two steps, the second out of place (k_cols4_a / k_cols4_b); its destination
+    // becomes the field and the old buffer the next destination.  Allocated on the first ocean_fft_cols of a field.
+    c32* field_alt[3] = {nullptr, nullptr, nullptr};
     bool nat_valid[3] = {true, true, true};
     bool chk_valid[3] = {false, false, false};
     bool stage_chunked = false;
@@ -164,13 +168,18 @@ void launch(K kernel, dim3 grid, dim3 block, unsigned lds, hipStream_t s, Timing
 
 template <int N> struct Launch {
     using G = Geo<N>;
+    // Staged column pass at N >= 8192: two steps with 1024-point sub-transforms of sixteen columns at a time (k_cols4_a / k_cols4_b)
+    // instead of whole columns two at a time (k_fft_lines<COL>: 16-byte pieces, 1.26 TB/s).
+    static constexpr bool COLS4 = N >= 8192;
+    static constexpr int COLS4_S = COLS4 ? N / 512 : 1, COLS4_LPW = 16;   // sub-transforms of 512 points: two workgroups per CU (ocean_staged_kernels.hpp)
+    static constexpr int COLS4_LDS = COLS4_LPW * LinePitch<COLS4 ? N / COLS4_S : 1024>::elems * (int)sizeof(c32);
     static hipError_t prepare() {
         hipError_t e;
         e = hipFuncSetAttribute((const void*)k_fft_lines<N, G::E, G::ROW_LPW, false>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, G::row_lds);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)k_fft_lines<N, G::E, G::COL_LPW, true>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, G::col_lds);
+        if constexpr (COLS4) e = hipFuncSetAttribute((const void*)k_cols4_a<N, COLS4_S, G::E, COLS4_LPW>, hipFuncAttributeMaxDynamicSharedMemorySize, COLS4_LDS);
+        else e = hipFuncSetAttribute((const void*)k_fft_lines<N, G::E, G::COL_LPW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G::col_lds);
         if (e != hipSuccess) return e;
         if constexpr (G::stage_chunked) {
             e = hipFuncSetAttribute((const void*)k_stage_rows<N, G::E>, hipFuncAttributeMaxDynamicSharedMemorySize, G::stage_lds);
@@ -329,8 +338,18 @@ template <int N> struct Launch {
                            G::row_lds, s, data, c->tw);
     }
     static void cols(OceanContext* c, c32* data, hipStream_t s) {
-        hipLaunchKernelGGL((k_fft_lines<N, G::E, G::COL_LPW, true>), dim3(G::col_grid), dim3(G::col_threads),
-                           G::col_lds, s, data, c->tw);
+        if constexpr (!COLS4)
+            hipLaunchKernelGGL((k_fft_lines<N, G::E, G::COL_LPW, true>), dim3(G::col_grid), dim3(G::col_threads),
+                               G::col_lds, s, data, c->tw);
+    }
+    // in place on `data` (step A), then into `dst` (step B): the caller swaps the two
+    static void cols4(OceanContext* c, c32* data, c32* dst, hipStream_t s) {
+        if constexpr (COLS4) {
+            constexpr int M = N / COLS4_S;
+            hipLaunchKernelGGL((k_cols4_a<N, COLS4_S, G::E, COLS4_LPW>), dim3((N / COLS4_LPW) * COLS4_S), dim3((M / G::E) * COLS4_LPW), COLS4_LDS, s,
+                               data, (const c32*)c->tw);
+            hipLaunchKernelGGL((k_cols4_b<N, COLS4_S>), dim3((N / ((COLS4_S >= 32) ? 1 : 2) / 256) * M), dim3(256), 0, s, (const c32*)data, dst);
+        }
     }
 };
 
@@ -406,7 +425,12 @@ void launch_cols(OceanContext* c, int f, hipStream_t s) {
         c->nat_valid[f] = false;
         return;
     }
-    OCEAN_DISPATCH(c->n, L::cols(c, c->field[f], s));
+    bool cols4 = false;
+    OCEAN_DISPATCH(c->n, cols4 = L::COLS4);
+    if (cols4) {                                    // N >= 8192: two steps, the second into field_alt[f], which becomes the field
+        OCEAN_DISPATCH(c->n, L::cols4(c, c->field[f], c->field_alt[f], s));
+        std::swap(c->field[f], c->field_alt[f]);
+    } else OCEAN_DISPATCH(c->n, L::cols(c, c->field[f], s));
     c->chk_valid[f] = false;
 }
 // The normal field of the current map (shader/ocean.frag:50-66 at texel centres) into c->normals.
@@ -434,6 +458,13 @@ void launch_normals_plane(OceanContext* c, hipStream_t s, Timing t = Timing()) {
         default: launch(k_normals_plane<8>, grid, b, 0, s, t, plane, c->normals, c->n); break;
     }
 }
+// The second buffer of field f for the two-step column pass (N >= 8192), allocated on first use.
+int32_t reserve_cols(OceanContext* c, int f) {
+    bool cols4 = false;
+    OCEAN_DISPATCH(c->n, cols4 = L::COLS4);
+    if (cols4 && !c->field_alt[f]) HIP_TRY(c, hipMalloc((void**)&c->field_alt[f], (size_t)c->n * c->n * sizeof(c32)));
+    return OCEAN_OK;
+}
 void launch_frame(OceanContext* c, float time, float domain, hipStream_t s) {
     if (c->quirks != OCEAN_QUIRKS_REFERENCE) {      // the fused kernels implement the reference's arithmetic only
         launch_propagate(c, time, domain, s);
@@ -456,7 +487,7 @@ int32_t check_launch(OceanContext* c, const char* what) {
 void free_all(OceanContext* c) {
     auto f = [](void* p) { if (p) (void)hipFree(p); };
     f(c->h0); f(c->omega); f(c->field[0]); f(c->field[1]); f(c->field[2]);
-    f(c->cfield[0]); f(c->cfield[1]); f(c->cfield[2]);
+    f(c->cfield[0]); f(c->cfield[1]); f(c->cfield[2]); f(c->field_alt[0]); f(c->field_alt[1]); f(c->field_alt[2]);
     f(c->h0T); f(c->omegaT); f(c->inter); f(c->nyq); f(c->tw); f(c->out_own); f(c->normals); f(c->plane); f(c->batch_inter); f(c->batch_nyq); f(c->batch_out); f(c->positions); f(c->checksum_acc); f(c->inter_scale);
     if (c->ev_a) (void)hipEventDestroy(c->ev_a);
     if (c->ev_b) (void)hipEventDestroy(c->ev_b);
@@ -725,7 +756,10 @@ static int32_t fft_pass_common(OceanFft* fft, int32_t field, void* stream, bool 
     hipStream_t s = pick(c, stream);
     // reference order of the three descriptor sets: dx, dy, dz (src/render.rs:1158-1179)
     for (int f = 0; f < 3; ++f)
-        if (field == OCEAN_FIELD_ALL || field == f) { if (cols) launch_cols(c, f, s); else launch_rows(c, f, s); }
+        if (field == OCEAN_FIELD_ALL || field == f) {
+            if (cols) { NEED(reserve_cols(c, f)); launch_cols(c, f, s); }
+            else launch_rows(c, f, s);
+        }
     return check_launch(c, cols ? "k_fft_lines<COL> launch" : "k_fft_lines<ROW> launch");
 }
 int32_t ocean_fft_rows(OceanFft* fft, int32_t field, void* stream) { return fft_pass_common(fft, field, stream, false); }
@@ -756,7 +790,11 @@ int32_t ocean_frame_ex(OceanContext* ctx, const OceanPropagateLocals* locals, vo
 int32_t ocean_set_quirks(OceanContext* ctx, uint32_t quirks) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
     if (quirks & ~OCEAN_QUIRKS_REFERENCE) return fail(ctx, OCEAN_E_INVALID_ARG, "unknown quirk bits");
-    if (quirks != OCEAN_QUIRKS_REFERENCE) NEED(need_staged(ctx, "ocean_set_quirks (the fused kernels implement the reference quirks only)"));
+    if (quirks != OCEAN_QUIRKS_REFERENCE) {        // ocean_frame then runs the staged dispatches: their buffers must exist before a frame is launched
+        NEED(need_staged(ctx, "ocean_set_quirks (the fused kernels implement the reference quirks only)"));
+        DeviceGuard guard(ctx->device);
+        for (int f = 0; f < 3; ++f) NEED(reserve_cols(ctx, f));
+    }
     ctx->quirks = quirks;
     return OCEAN_OK;
 }
@@ -1105,22 +1143,24 @@ static int32_t profile_common(OceanContext* ctx, float time, int32_t cap, const 
                               int32_t* out_n, bool staged) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
     NEED(need_frame(ctx, "ocean_profile_*"));
-    if (staged) NEED(need_staged(ctx, "ocean_profile_staged"));
+    if (staged) {
+        NEED(need_staged(ctx, "ocean_profile_staged"));
+        DeviceGuard guard0(ctx->device);
+        for (int f = 0; f < 3; ++f) NEED(reserve_cols(ctx, f));
+    }
     if (!names || !ms || !out_n) return fail(ctx, OCEAN_E_INVALID_ARG, "NULL output");
     if (!ctx->uploaded) return fail(ctx, OCEAN_E_STATE, "ocean_upload_spectrum has not been called");
     static const char* kNatural[8] = {"k_propagate", "k_fft_lines<ROW> dx", "k_fft_lines<ROW> dy", "k_fft_lines<ROW> dz",
                                       "k_fft_lines<COL> dx", "k_fft_lines<COL> dy", "k_fft_lines<COL> dz", "k_correct"};
     static const char* kChunked[8] = {"k_propagate", "k_stage_rows(fft) dx", "k_stage_rows(fft) dy", "k_stage_rows(fft) dz",
                                       "k_stage_cols(fft) dx", "k_stage_cols(fft) dy", "k_stage_cols(fft) dz", "k_correct_chunked"};
-    // N = 8192: two 8192-point lines fill the LDS, so a column workgroup owns 16-byte pieces of the natural rows (or of a
-    // chunk) and the L2 has to merge neighbours: 0.85 ms per field = 1.26 TB/s (round 2) against 3.6-3.9 TB/s of the chunked
-    // hand-off at N <= 4096.  A chunked hand-off with half chunks was estimated at 3.0 ms per frame (today 4.2; the fused
-    // frame: 0.9) and NOT built: the staged calls are the 1:1 compatibility path, ocean_frame is the product
-    // (INTEGRATION.md 2).  The names say so where a profile is read.
-    static const char* kNatural8192[8] = {"k_propagate", "k_fft_lines<ROW> dx", "k_fft_lines<ROW> dy", "k_fft_lines<ROW> dz",
-                                          "k_fft_lines<COL> dx [natural layout, 16-byte pieces: compatibility path, ~1.3 TB/s]",
-                                          "k_fft_lines<COL> dy [compatibility path]", "k_fft_lines<COL> dz [compatibility path]", "k_correct"};
-    const char* const* kStaged = ctx->stage_chunked ? kChunked : (ctx->n >= 8192 ? kNatural8192 : kNatural);
+    // N >= 8192: the column pass of a field is two launches (k_cols4_a: sub-transforms of sixteen columns, in place; k_cols4_b: the
+    // S-point step over consecutive rows into the field's second buffer) -- 0.43-0.47 ms per field at 8192 where whole columns two
+    // at a time (k_fft_lines<COL>, 16-byte pieces) took 0.85; staged frame 4.2 -> 2.8 ms (r05_run12/13).  The staged calls remain
+    // the 1:1 compatibility path, ocean_frame (0.75 ms) the product.
+    static const char* kTwoStep[8] = {"k_propagate", "k_fft_lines<ROW> dx", "k_fft_lines<ROW> dy", "k_fft_lines<ROW> dz",
+                                      "k_cols4_a + k_cols4_b dx [two-step column pass]", "k_cols4_a + k_cols4_b dy", "k_cols4_a + k_cols4_b dz", "k_correct"};
+    const char* const* kStaged = ctx->stage_chunked ? kChunked : (ctx->n >= 8192 ? kTwoStep : kNatural);
     const char* kFused[2] = {"k_half_pass1", "k_half_pass2"};
     const int count = staged ? 8 : 2;
     if (cap < count) return fail(ctx, OCEAN_E_INVALID_ARG, "capacity too small");

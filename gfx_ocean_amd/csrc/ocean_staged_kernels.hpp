@@ -276,6 +276,83 @@ k_fft_lines(c32* __restrict__ data, const c32* __restrict__ tw) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Staged column pass at N >= 8192 in two steps ("four-step" FFT; shader/fft_col.comp:44-63 for lines that do not fit the LDS
+// sixteen at a time)
+// ---------------------------------------------------------------------------------------------
+// k_fft_lines<COL> keeps whole columns in LDS: two 8192-point columns fill it, so a workgroup owns 16-byte pieces of every row
+// and the pass runs at 1.26 TB/s (0.85 ms per field at N = 8192).  With NF = S * M, row n = r + S m and
+// output row k = k1 + M k2:
+//     X[k1 + M k2] = sum_{r < S} W_S^{r k2} * ( W_NF^{r k1} * sum_{m < M} x[r + S m] W_M^{m k1} ),      W_n = e^{+2 pi i / n}.
+// Step A (k_cols4_a, in place): per residue r the M-point transforms along m of LPW = 16 adjacent columns -- a workgroup moves
+//   whole 128-byte pieces (16 columns x 8 bytes of a row) -- times W_NF^{r k1}; Y[r][k1] stays at row r + S k1.  M = 512 (S = 16
+//   at 8192, 32 at 16384): 16 lines are 70 KiB of LDS and 512 threads, so TWO workgroups share a CU and one loads while the
+//   other transforms (M = 1024, one 1024-thread workgroup per CU in lock-step phases: 0.56-0.58 ms per field at 8192 instead of
+//   0.44; 32 columns of 512 points: 0.55; 8 columns of 1024: 0.50 -- r05_run12).
+// Step B (k_cols4_b, out of place): for every k1 the S values Y[0..S)[k1] are S CONSECUTIVE rows; an S-point DFT in registers,
+//   results to rows k1 + M k2 of the destination: whole rows in, whole rows out, no LDS.
+// 32 instead of 16 B/texel per field, all of it in full lines.  The destination of step B becomes the field (the API swaps the
+// two buffers), so nothing is copied back.
+template <int NF, int S, int E, int LPW>
+__global__ void __launch_bounds__((NF / S / E) * LPW)
+k_cols4_a(c32* __restrict__ data, const c32* __restrict__ tw) {
+    constexpr int M = NF / S, T = M / E;
+    static_assert(NF == S * M && M % E == 0 && T % 16 == 0, "four-step geometry (fft_line: threads per line a multiple of 16)");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    c32* lds = reinterpret_cast<c32*>(smem);
+    const int tid = threadIdx.x;
+    const int ll = tid % LPW, j = tid / LPW;                       // the line (column) is the fastest thread coordinate
+    const int groups = NF / LPW;
+    const int b = (int)blockIdx.x;
+    const int r = b / groups;                                      // residue of the rows this workgroup transforms
+    const int x = xcd_contiguous(b % groups, groups) * LPW + ll;
+    c32* lds_line = lds + ll * LinePitch<M>::elems;
+    c32* col = data + (size_t)r * NF + x;                          // row r + S m, column x
+    c32 reg[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) reg[e] = col[(size_t)(j + e * T) * S * NF];
+    fft_line<M, E, S>(reg, j, tw, lds_line);                       // (table of NF points: stride S)
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int k1 = j + e * T;
+        col[(size_t)k1 * S * NF] = (r == 0) ? reg[e] : cmul(reg[e], tw[r * k1]);   // W_NF^{r k1}, r k1 < NF
+    }
+}
+// One thread per CPT adjacent columns (2; 1 at S = 32: 4 S registers per column) and one k1; grid = (NF / CPT / 256) * M
+// workgroups of 256 threads.
+template <int NF, int S>
+__global__ void __launch_bounds__(256)
+k_cols4_b(const c32* __restrict__ src, c32* __restrict__ dst) {
+    constexpr int M = NF / S;
+    constexpr int CPT = (S >= 32) ? 1 : 2;
+    constexpr int PER_ROW = NF / CPT / 256;                        // workgroups per row
+    const int k1 = (int)blockIdx.x / PER_ROW;
+    const int x = (((int)blockIdx.x % PER_ROW) * 256 + (int)threadIdx.x) * CPT;
+    const c32* in = src + (size_t)k1 * S * NF + x;
+    c32* out = dst + (size_t)k1 * NF + x;
+    if constexpr (CPT == 2) {
+        c32 a[S], b[S], oa[S], ob[S];
+#pragma unroll
+        for (int r = 0; r < S; ++r) {
+            const float4 v = *reinterpret_cast<const float4*>(in + (size_t)r * NF);
+            a[r] = mk(v.x, v.y);
+            b[r] = mk(v.z, v.w);
+        }
+        Dft<S>::run(a, oa);
+        Dft<S>::run(b, ob);
+#pragma unroll
+        for (int k2 = 0; k2 < S; ++k2)
+            store_float4_nt(reinterpret_cast<float4*>(out + (size_t)k2 * M * NF), make_float4(oa[k2].x, oa[k2].y, ob[k2].x, ob[k2].y));
+    } else {
+        c32 a[S], oa[S];
+#pragma unroll
+        for (int r = 0; r < S; ++r) a[r] = in[(size_t)r * NF];
+        Dft<S>::run(a, oa);
+#pragma unroll
+        for (int k2 = 0; k2 < S; ++k2) out[(size_t)k2 * M * NF] = oa[k2];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Staged path, chunked hand-off (N <= 4096, 4 x 4 chunks)
 // ---------------------------------------------------------------------------------------------
 // The reference's column pass reads its lines with a 4 KiB lane stride (shader/fft_col.comp:45-47) and leaves it to

@@ -189,6 +189,17 @@ def frame_half(h0, omega, time, L=1000.0, layout="p2", return_inter=False, spect
     return out
 
 
+def cols4(field, s):
+    """The two-step staged column pass (k_cols4_a in place, k_cols4_b out of place): column transforms of `field` [NF, NF]."""
+    f = np.ascontiguousarray(field, np.complex64).copy()
+    nf = f.shape[0]
+    dst = np.full_like(f, np.nan + 1j * np.nan)
+    tw = twiddles(nf)
+    lib().emu_cols4.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    assert lib().emu_cols4(nf, int(s), _p(f), _p(dst), _p(tw)) == 0
+    return dst
+
+
 def normals_plane(plane):
     """k_normals_plane: the normal field from the dense source-channel plane of the fused pass 2."""
     plane = np.ascontiguousarray(plane, np.float32)

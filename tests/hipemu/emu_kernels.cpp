@@ -5,6 +5,7 @@
 #include <functional>
 #include <memory>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include <hip/hip_runtime.h>
@@ -312,6 +313,18 @@ int emu_normals_plane(int n, const float* src_plane, float* normals) {
     else if (rows == 16) emu_launch(grid, 256, [&] { k_normals_plane<16>(src_plane, (float4*)normals, n); });
     else emu_launch(grid, 256, [&] { k_normals_plane<8>(src_plane, (float4*)normals, n); });
     return 0;
+}
+// the staged column pass of N >= 8192 (two steps, k_cols4_a / k_cols4_b) at sizes the emulation can run: nf = s * m
+int emu_cols4(int nf, int s, float* data, float* dst, const float* tw) {
+    auto run = [&](auto NF, auto S) {
+        constexpr int nf_ = decltype(NF)::value, s_ = decltype(S)::value, m_ = nf_ / s_;
+        emu_launch((nf_ / 16) * s_, (m_ / 16) * 16, [&] { k_cols4_a<nf_, s_, 16, 16>((c32*)data, (const c32*)tw); });
+        emu_launch((nf_ / ((s_ >= 32) ? 1 : 2) / 256) * m_, 256, [&] { k_cols4_b<nf_, s_>((const c32*)data, (c32*)dst); });
+        return 0;
+    };
+    if (nf == 2048 && s == 8) return run(std::integral_constant<int, 2048>{}, std::integral_constant<int, 8>{});
+    if (nf == 4096 && s == 16) return run(std::integral_constant<int, 4096>{}, std::integral_constant<int, 16>{});
+    return -2;
 }
 int emu_propagate(int n, const float* h0, const float* omega, float* h, float* dx, float* dz, float time, float L, unsigned quirks) {
     if (quirks == 3u) {                                 // as launch_propagate of csrc/ocean_api.hip: the paired kernel for the reference quirks

@@ -67,6 +67,21 @@ def test_emu_fft_lines(n, col):
     assert_parity(got, ref, 2e-6, f"emu fft n={n} col={col}")
 
 
+@pytest.mark.parametrize("nf,s", [(2048, 8), (4096, 16)])
+def test_emu_two_step_column_pass(nf, s):
+    """The staged column pass of N >= 8192 (k_cols4_a: sub-transforms of sixteen columns + twiddles, in place; k_cols4_b: the
+    S-point step over consecutive rows, out of place) with the product's S = 8 and 16 at sizes the emulation can run."""
+    rng = np.random.default_rng(nf)
+    x = np.zeros((nf, nf), np.complex64)
+    cols = rng.choice(nf, 48, replace=False)              # a few columns carry data (the reference transform of all of them is slow)
+    x[:, cols] = (rng.standard_normal((nf, 48)) + 1j * rng.standard_normal((nf, 48))).astype(np.complex64)
+    got = emu.cols4(x, s)
+    ref = oc.ifft_lines_f64(np.ascontiguousarray(x[:, cols].T)).T
+    assert_parity(got[:, cols], ref, 2e-6, f"two-step column pass nf={nf} s={s}")
+    rest = np.delete(got, cols, axis=1)
+    assert np.all(rest == 0)
+
+
 def test_emu_correct(ref_inputs_256):
     h0, om = ref_inputs_256
     h, dx, dz = oc.propagate_literal(h0, om, 1.0)

@@ -286,6 +286,32 @@ def test_full_size_properties(n):
         r.dispose()
 
 
+def test_staged_column_pass_16384():
+    """The two-step staged column pass (k_cols4_a / k_cols4_b) with S = 16 at N = 16384: sampled columns of random data vs fp64,
+    twice in a row (the field and its second buffer swap roles), rows untouched by a column pass of another field."""
+    n = 16384
+    rng = np.random.default_rng(n)
+    a = rng.standard_normal((n, n), dtype=np.float32).astype(np.complex64)
+    cols = (0, 5, 4097, n - 1)
+    for xx in cols:
+        a[:, xx] += 1j * rng.standard_normal(n).astype(np.float32)
+    d = g.OceanDevice(n)
+    fft = g.Fft.init(d)
+    try:
+        d.write_field(g.FIELD_DZ, a)
+        fft.col_pass(g.FIELD_DZ)
+        once = d.read_field(g.FIELD_DZ)
+        for xx in cols:
+            assert_parity(once[:, xx], oc.ifft_lines_f64(a[:, xx][None])[0], 5e-6, f"col {xx}")
+        fft.col_pass(g.FIELD_DZ)                                  # from the second buffer back into the first
+        twice = d.read_field(g.FIELD_DZ)
+        for xx in cols[:2]:
+            assert_parity(twice[:, xx], oc.ifft_lines_f64(once[:, xx][None])[0], 5e-6, f"col {xx}, second pass")
+    finally:
+        fft.destroy()
+        d.destroy()
+
+
 def test_linearity_and_impulse_1024():
     n = 1024
     om = g.synth.dispersion(n)
