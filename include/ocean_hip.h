@@ -91,7 +91,8 @@ int32_t ocean_device_count(void);
 int32_t ocean_device_pci_bus_id(int32_t device_ordinal, char* out, int32_t capacity /* >= 16 */);
 int32_t ocean_context_create(int32_t device_ordinal, int32_t resolution, OceanContext** out_ctx);
 /* ... with exactly the buffers the caller's path uses (the reference sizes one allocation for what it binds, src/render.rs:607-670).
- * A full context holds both paths' buffers: 100 B/texel at N <= 4096 (1.6 GiB at 4096), 76 above (20 GiB at 16384).
+ * A full context holds both paths' buffers: 100 B/texel at N <= 4096 (1.6 GiB at 4096), 76 above (20 GiB at 16384; + 8 per field
+ * on the first ocean_fft_cols of that field, whose two-step column pass at N >= 8192 works out of place).
  *   OCEAN_CTX_FUSED_ONLY  no natural-layout copies, fields or chunked hand-off (the staged path's 60 / 36 B/texel): ocean_frame*,
  *                         the consumers, the batch, the measurement loops and ocean_tile_pass1/2 work; ocean_propagate,
  *                         ocean_fft_rows/cols, ocean_correct, ocean_read/write_field, ocean_read_spectrum, ocean_profile_staged and
