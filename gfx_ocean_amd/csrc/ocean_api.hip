@@ -451,6 +451,10 @@ void launch_normals_plane(OceanContext* c, hipStream_t s, Timing t = Timing()) {
     const int rows = normals_plane_rows(c->n);
     const dim3 grid((unsigned)((c->n / 256) * (c->n / rows) / 4)), b(256);
     const float* plane = c->plane;
+    if (c->n >= 8192) {                              // the stores are the bound: one contiguous span of whole rows per workgroup
+        launch(k_normals_plane_bands<NORMALS_BAND_ROWS>, dim3((unsigned)(c->n / NORMALS_BAND_ROWS)), b, 0, s, t, plane, c->normals, c->n);
+        return;
+    }
     switch (rows) {
         case 2: launch(k_normals_plane<2>, grid, b, 0, s, t, plane, c->normals, c->n); break;
         case 4: launch(k_normals_plane<4>, grid, b, 0, s, t, plane, c->normals, c->n); break;

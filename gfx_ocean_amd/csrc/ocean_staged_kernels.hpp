@@ -214,6 +214,49 @@ k_normals_plane(const float* __restrict__ plane, float4* __restrict__ normals, i
     }
 }
 
+// The same, one workgroup per band of ROWS whole rows (N >= 8192, where the field's N*N*16 bytes of stores -- 1 GiB at 8192 -- are
+// the bound and go to HBM one way or the other): the workgroup walks along the rows, 1024 columns per step, so that what it writes
+// is ONE contiguous span of ROWS * N * 16 bytes (contiguous spans per workgroup stream at 6.2 TB/s on this part, fine-interleaved
+// stores at 4.5: tools/membench2.hip).  grid = N / ROWS workgroups of 256 threads.  Measured at N = 8192 (r05_run14, one box, two
+// repetitions): k_normals_plane<16> 312 us; bands of 4 / 8 / 16 rows 291 / 266 / 303 us; whole rows one after the other with the rows
+// above and below re-read from the caches: 348-350 us.  Bands of 8: 1342 MB at 5.0 TB/s.  Same arithmetic: the same bits.
+constexpr int NORMALS_BAND_ROWS = 8;
+template <int ROWS>
+__global__ void __launch_bounds__(256)
+k_normals_plane_bands(const float* __restrict__ plane, float4* __restrict__ normals, int n) {
+    const uint32_t un = (uint32_t)n, mask = un - 1u;
+    const uint32_t y0 = (uint32_t)xcd_contiguous((int)blockIdx.x, (int)gridDim.x) * ROWS;
+    const float sd = 360.0f / (float)n;
+    for (uint32_t xb = 0; xb < un; xb += 1024u) {
+        const uint32_t x0 = xb + (threadIdx.x >> 6) * 256u + (threadIdx.x & 63u);
+        float above[4], centre[4];
+        const float* pa = plane + (size_t)((y0 + un - 1u) & mask) * un + x0;
+        const float* pc = plane + (size_t)y0 * un + x0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { above[k] = pa[64 * k]; centre[k] = pc[64 * k]; }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const uint32_t y = y0 + (uint32_t)r;
+            const float* pb = plane + (size_t)((y + 1u) & mask) * un + x0;
+            const float* prow = plane + (size_t)y * un;
+            float below[4], left[4], right[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                below[k] = pb[64 * k];
+                left[k] = prow[(x0 + 64u * k + un - 1u) & mask];
+                right[k] = prow[(x0 + 64u * k + 1u) & mask];
+            }
+            float4* o = normals + (size_t)y * un + x0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                store_float4_nt(o + 64 * k, normal_from_differences(right[k] - left[k], below[k] - above[k], sd));
+                above[k] = centre[k];
+                centre[k] = below[k];
+            }
+        }
+    }
+}
+
 // SURVEY 8f #2 -- the vertex stage's consumer of the map (shader/ocean.vert:21-25) as a compute kernel: the
 // V x V patch grid of src/render.rs:494-508 (a_Pos = (x, 0, z), a_Uv = (x, z) / (V - 1); V = HALF_RESOLUTION
 // = 128 in the reference), the displacement sampled with the reference's sampler (Filter::Linear,

@@ -200,13 +200,15 @@ def cols4(field, s):
     return dst
 
 
-def normals_plane(plane):
-    """k_normals_plane: the normal field from the dense source-channel plane of the fused pass 2."""
+def normals_plane(plane, bands=False):
+    """k_normals_plane (bands=True: k_normals_plane_bands, the N >= 8192 kernel; n >= 1024 here): the normal field from the dense
+    source-channel plane of the fused pass 2."""
     plane = np.ascontiguousarray(plane, np.float32)
     n = plane.shape[0]
     out = np.full((n, n, 4), np.nan, np.float32)
-    lib().emu_normals_plane.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
-    assert lib().emu_normals_plane(n, _p(plane), _p(out)) == 0
+    fn = lib().emu_normals_plane_bands if bands else lib().emu_normals_plane
+    fn.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    assert fn(n, _p(plane), _p(out)) == 0
     return out
 
 

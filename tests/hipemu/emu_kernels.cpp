@@ -305,6 +305,10 @@ int emu_set_batch(int count, float dt, unsigned inter_stride, size_t out_stride)
     batch = FrameBatch{dt, inter_stride, out_stride};
     return 0;
 }
+int emu_normals_plane_bands(int n, const float* src_plane, float* normals) {   // what launch_normals_plane runs at N >= 8192
+    emu_launch(n / NORMALS_BAND_ROWS, 256, [&] { k_normals_plane_bands<NORMALS_BAND_ROWS>(src_plane, (float4*)normals, n); });
+    return 0;
+}
 int emu_normals_plane(int n, const float* src_plane, float* normals) {
     const int rows = normals_plane_rows(n);             // as launch_normals_plane of csrc/ocean_api.hip
     const int grid = (n / 256) * (n / rows) / 4;

@@ -12,7 +12,16 @@ from oracle import ocean_oracle as oc
 
 @pytest.fixture(scope="module", autouse=True)
 def _build():
+    """Both builds of the emulation at once (each is a minute of g++): the default one, and the one with the LDS-DMA loader at
+    every size that test_emu_dma_loader_at_every_size runs in its own process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    other = subprocess.Popen([sys.executable, "-c", "import sys; sys.path.insert(0, sys.argv[1] + '/tests'); import emu; emu.build()", root],
+                             env=dict(os.environ, OCEAN_EMU_FLAGS="-DOCEAN_DMA_MIN_N=256"))
     emu.build()
+    assert other.wait() == 0
 
 
 def test_emu_propagate_matches_literal(ref_inputs_256):
@@ -120,6 +129,8 @@ def test_emu_normals_plane_rows_per_wave_variants(n, channel):
     got = emu.normals_plane(np.ascontiguousarray(rgba[..., channel]))
     assert np.array_equal(got, emu.normals(rgba, channel))
     assert np.abs(got - oc.normals_literal(rgba, channel)).max() <= 2e-6
+    if n == 2048:                                        # the kernel of N >= 8192: one band of whole rows per workgroup
+        assert np.array_equal(emu.normals_plane(np.ascontiguousarray(rgba[..., channel]), bands=True), got)
 
 
 @pytest.mark.parametrize("n", [256])
@@ -143,7 +154,7 @@ def test_emu_split_line_geometry_block_layout(ref_inputs):
     assert_parity(out[..., :3], oc.frame_f64(h0, om, 2.5)[..., :3], 5e-6, "split frame, blocks of 8 chunk rows")
 
 
-@pytest.mark.parametrize("n", [512, 1024])
+@pytest.mark.parametrize("n", [512])                               # (1024 passes too: 46 s of host emulation; the GPU tier runs 8192)
 def test_emu_split_line_geometry(n, ref_inputs):
     """The N = 8192 kernels (every line as two interleaved N/2 transforms, last radix-2 step at read-out) at sizes
     the emulation can run: same frame and same intermediate as the plain kernels."""
@@ -180,10 +191,7 @@ def test_emu_split_one_column_per_workgroup(n):
             plain = inter_p
         assert_parity(emu.unpack_inter(inter, n, P, lay, f, columns=n // 2, cmajor=True), emu.unpack_inter(plain, n, 2, lay, f, columns=n // 2), 5e-6,
                       f"intermediate field {f}")
-    if n == 1024:
-        _, deq, _ = emu.quantize_f16(h0)
-        o16 = emu.frame_half(h0, om, 1.0, spectrum_fp16=True, split=True, P=1)
-        assert_parity(o16[..., :3], oc.frame_f64(deq, om, 1.0)[..., :3], 5e-6, "fp16 spectrum, one column per workgroup")
+    # (the fp16-stored spectrum with this geometry: tests/test_gpu_parity.py::test_fp16_spectrum_16384_sampled_texels; here 20 s more)
 
 
 def test_emu_split_fp16_spectrum(ref_inputs):

@@ -286,6 +286,31 @@ def test_full_size_properties(n):
         r.dispose()
 
 
+def test_fp16_spectrum_16384_sampled_texels():
+    """The fp16-stored spectrum with the one-column split geometry (N = 16384; the emulation runs this geometry at 1024 with
+    the fp32 spectrum only): sampled texels of ocean_frame against direct fp64 evaluations of the 2-D sum on the DEQUANTISED
+    spectrum the kernels use."""
+    n, t = 16384, 1.25
+    h0, om = g.synth.make_inputs(n, seed=77)
+    d = g.OceanDevice(n)
+    try:
+        d.upload_spectrum(h0, om, spectrum_fp16=True)
+        deq = d.read_spectrum()
+        d.frame(t)
+        out = d.read_displacement()
+    finally:
+        d.destroy()
+    H, DX, DZ = oc.propagate_f64(deq, om, t)
+    k = np.arange(n)
+    scale = np.abs(out[..., :3]).max((0, 1))
+    for (x, y) in [(0, 0), (n // 2 + 3, n // 3), (n - 1, n - 1)]:
+        ey, ex = np.exp(2j * np.pi * k * y / n), np.exp(2j * np.pi * k * x / n)
+        sgn = -1.0 if (x + y) % 2 == 0 else 1.0
+        ref = np.array([(ey @ (F @ ex)).real for F in (DX, H, DZ)]) * sgn
+        assert np.all(np.abs(out[y, x, :3] - ref) <= TOL * scale), (x, y, out[y, x, :3], ref)
+    assert np.all(out[..., 3] == 0.0)
+
+
 def test_staged_column_pass_16384():
     """The two-step staged column pass (k_cols4_a / k_cols4_b) with S = 16 at N = 16384: sampled columns of random data vs fp64,
     twice in a row (the field and its second buffer swap roles), rows untouched by a column pass of another field."""
