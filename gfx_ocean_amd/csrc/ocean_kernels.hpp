@@ -1138,7 +1138,7 @@ template <int N, int PSEL = 0, bool THROUGHPUT = false> struct Geo {
 #endif
     static constexpr bool dma = (N >= OCEAN_DMA_MIN_N) && (((N / E1) * P) % 64 == 0);
     // Field-parallel pass 1 (k_half_pass1<.., FPAR>): three wave groups per workgroup, one per field, at N <= 512.
-    static constexpr bool fpar = !THROUGHPUT && (N <= 512) && (((N / E1) * P) % 64 == 0) && (3 * (N / E1) * P <= 1024) && !dma;
+        static constexpr bool fpar = !THROUGHPUT && (N <= 512) && (((N / E1) * P) % 64 == 0) && (3 * (N / E1) * P <= 1024) && !dma;
     static constexpr int half_threads1 = (N / E1) * P * (fpar ? 3 : 1);   // fused pass 1
     static constexpr int split_threads1 = (N / E1S) * P;
     static constexpr int line_bytes = LinePitch<N>::elems * (int)sizeof(c32);
