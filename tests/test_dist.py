@@ -179,7 +179,7 @@ def test_committed_bench_lines_carry_the_contract_fields():
     """The lines the GPU box produced (profiles/) have every field of the bench contract, with the roofline computed from
     the bytes the kernels move and the three-complex-transform accounting beside it, never as `achieved`."""
     import glob
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[234]_run*_bench*.json")))
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[2345]_run*_bench*.json")))
     assert paths
     for path in paths:
         with open(path) as f:
@@ -196,8 +196,17 @@ def test_committed_bench_lines_carry_the_contract_fields():
         n, spec = r["config"]["n"], r["config"].get("spectrum", "f32")
         dom = [k for k in ro["kernels"] if k["name"] == ro["kernel"]][0]
         inter = r["config"].get("intermediate", "f32")
-        if os.path.basename(path).startswith("r04"):
-            moved = bench.moved_bytes_per_texel(n, spec, inter)[bench.pass_of(dom["name"])] * n * n
+        normals = r["config"].get("normals", "off") != "off"
+        if normals:      # BASELINE config 3 as one workload: the normal-field kernel has its own entry, priced on 4 R + 12 W with what it moves beside it
+            nk = [k for k in ro["kernels"] if k["name"] == "k_normals_plane"][0]
+            assert abs(nk["algorithmic_bytes"] - 16.0 * n * n) < 1 and abs(nk["moved_bytes"] - 20.0 * n * n) < 1 and nk["avg_ms"] > 0
+            assert "normal" in r["config"]["workload"] and len(ro["kernels"]) == 3
+            if nk["traffic"] is not None:
+                assert nk["moved_bytes"] <= nk["traffic"] * 1.005
+        if r.get("batched"):
+            assert "BATCHED MODE, not the headline" in r["metric"] and r["steps_timed"] % r["batched"] == 0
+        if os.path.basename(path)[:3] in ("r04", "r05"):
+            moved = bench.moved_bytes_per_texel(n, spec, inter, normals)[bench.pass_of(dom["name"])] * n * n
             # ... and what the line calls algorithmic never exceeds what the counters saw; below 4096
             # the static inputs stay in the caches from frame to frame and the counters see LESS than the kernel reads
             if ro["traffic"] is not None and n >= 4096:
@@ -213,7 +222,7 @@ def test_committed_bench_lines_carry_the_contract_fields():
         assert abs(dom["algorithmic_bytes"] - moved) < 1 and abs(ro["achieved"] - moved / dom["avg_ms"] / 1e6) < 1e-6 * ro["achieved"]
         assert ro["contract_frac"] > ro["frac"]                      # the 76-byte accounting is reported, but not as `achieved`
         assert 0.0 < ro["frac"] < 0.79                               # nothing above the part's measured copy ceiling (6.29 TB/s)
-        if os.path.basename(path)[:3] in ("r03", "r04"):            # round 3 on: where the traffic figure comes from, and the real warm-up
+        if os.path.basename(path)[:3] in ("r03", "r04", "r05"):     # round 3 on: where the traffic figure comes from, and the real warm-up
             if ro["traffic"] is not None:                             # (null = no committed PMC pass for this variant yet)
                 assert ro["traffic_source"]["file"].startswith("profiles/hbm_traffic_n") and "NOT measured in this run" in ro["traffic_source"]["method"]
             assert r["config"]["effective_warmup_frames"] >= r["warmup"]
