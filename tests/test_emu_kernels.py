@@ -76,7 +76,7 @@ def test_emu_fft_lines(n, col):
     assert_parity(got, ref, 2e-6, f"emu fft n={n} col={col}")
 
 
-@pytest.mark.parametrize("nf,s", [(2048, 8), (4096, 16)])
+@pytest.mark.parametrize("nf,s", [(2048, 8)])                        # ((4096, 16) passes too: 30 s; the GPU tier runs S = 16 and 32)
 def test_emu_two_step_column_pass(nf, s):
     """The staged column pass of N >= 8192 (k_cols4_a: sub-transforms of sixteen columns + twiddles, in place; k_cols4_b: the
     S-point step over consecutive rows, out of place) with the product's S = 8 and 16 at sizes the emulation can run."""
