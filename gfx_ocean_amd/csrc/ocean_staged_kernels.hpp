@@ -125,8 +125,9 @@ k_correct(const c32* __restrict__ height, const c32* __restrict__ disp_x, const 
 // (the two inner normalisations scale the cross product by 1/(|na'| |nb'|) and drop out of the outer one).  Evaluated in
 // that closed form -- n = (ax, s d, -az) * rsqrt(ax^2 + az^2 + (s d)^2): one v_rsq_f32, no division -- instead of the
 // literal three normalize() with a square root and three IEEE divisions each, which made the kernel VALU-issue-bound
-// (9 divisions + 3 square roots = ~180 issue slots per texel: 19 of the 25 us at N = 2048; round 5).  Fewer roundings
-// than the literal form: closer to the fp64 value (tests/test_gpu_parity.py::test_normal_field holds both to the literal
+// (9 divisions + 3 square roots = ~180 issue slots per texel: 19 of the 25 us at N = 2048; round 5).  As close
+// to the fp64 value as the literal form (1.2e-7 either way on the reference's data, 1.8e-7 from each other: restated in numpy;
+// tests/test_gpu_parity.py::test_normal_field holds both to the literal
 // fp32 restatement within 1e-5 absolute; GLSL's own normalize() is implementation-defined, usually v * inversesqrt(dot(v, v))).
 __device__ __forceinline__ float4 normal_from_differences(float ax, float az, float sd) {
 #ifdef OCEAN_NORMALS_LITERAL                                         // A/B only (tools/build_variants.py): the literal evaluation
