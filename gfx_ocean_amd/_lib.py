@@ -27,7 +27,7 @@ SYMBOLS = [
     "ocean_normals", "ocean_read_normals", "ocean_set_frame_normals", "ocean_frame_normals", "ocean_normals_device_ptr", "ocean_positions", "ocean_read_positions",
     "ocean_checksum_displacement", "ocean_packed_bytes", "ocean_pack_displacement",
     "ocean_read_displacement", "ocean_read_field", "ocean_write_field", "ocean_displacement_device_ptr",
-    "ocean_bind_displacement", "ocean_stream", "ocean_time_frames", "ocean_time_frame_batches", "ocean_frame_times", "ocean_frame_times_ex", "ocean_profile_frame", "ocean_profile_staged",
+    "ocean_bind_displacement", "ocean_bind_displacement_fd", "ocean_stream", "ocean_time_frames", "ocean_time_frame_batches", "ocean_frame_times", "ocean_frame_times_ex", "ocean_profile_frame", "ocean_profile_staged",
     "ocean_shard_create", "ocean_shard_destroy", "ocean_shard_last_error", "ocean_shard_upload", "ocean_shard_rows",
     "ocean_shard_cols", "ocean_shard_sync", "ocean_shard_stream",
     "ocean_tile_exchange_bytes", "ocean_tile_pass1", "ocean_tile_pass2",
@@ -166,6 +166,7 @@ def load_library():
         "ocean_write_field": (i32, [vp, i32, vp]),
         "ocean_displacement_device_ptr": (vp, [vp]),
         "ocean_bind_displacement": (i32, [vp, vp]),
+        "ocean_bind_displacement_fd": (i32, [vp, i32, ctypes.c_uint64, ctypes.c_uint64]),
         "ocean_stream": (vp, [vp]),
         "ocean_time_frames": (i32, [vp, i32, f32, f32, ctypes.POINTER(f32)]),
         "ocean_time_frame_batches": (i32, [vp, i32, i32, f32, f32, ctypes.POINTER(f32)]),

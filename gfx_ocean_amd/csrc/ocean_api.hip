@@ -89,6 +89,7 @@ struct OceanContext {
     c32* tw = nullptr;          // e^{+2 pi i k/N}
     float4* out_own = nullptr;  // displacement map (src/render.rs:820-869), linear RGBA32F
     float4* out = nullptr;      // = out_own or the caller's buffer (ocean_bind_displacement)
+    hipExternalMemory_t ext_mem = nullptr;   // ocean_bind_displacement_fd: the imported allocation the map currently lives in
     float4* normals = nullptr;    // allocated on first ocean_normals call
     // The frame with the normal field (ocean_set_frame_normals; BASELINE config 3 "height + displacement + normal"):
     // pass 2 also stores the source channel as a dense fp32 plane, which k_normals_plane differentiates behind it.
@@ -488,7 +489,11 @@ int32_t check_launch(OceanContext* c, const char* what) {
     return OCEAN_OK;
 }
 
+void release_import(OceanContext* c) {
+    if (c->ext_mem) { (void)hipDestroyExternalMemory(c->ext_mem); c->ext_mem = nullptr; }
+}
 void free_all(OceanContext* c) {
+    release_import(c);
     auto f = [](void* p) { if (p) (void)hipFree(p); };
     f(c->h0); f(c->omega); f(c->field[0]); f(c->field[1]); f(c->field[2]);
     f(c->cfield[0]); f(c->cfield[1]); f(c->cfield[2]); f(c->field_alt[0]); f(c->field_alt[1]); f(c->field_alt[2]);
@@ -990,7 +995,42 @@ int32_t ocean_bind_displacement(OceanContext* ctx, void* device_rgba) {
     NEED(need_frame(ctx, "ocean_bind_displacement"));
     if (device_rgba && (reinterpret_cast<uintptr_t>(device_rgba) & 15u))
         return fail(ctx, OCEAN_E_INVALID_ARG, "displacement buffer must be 16-byte aligned");
+    if (ctx->ext_mem) {                                            // frames in flight may still write the imported allocation
+        DeviceGuard guard(ctx->device);
+        HIP_TRY(ctx, sync_for_readback(ctx));
+        release_import(ctx);
+    }
     ctx->out = device_rgba ? (float4*)device_rgba : ctx->out_own;
+    return OCEAN_OK;
+}
+int32_t ocean_bind_displacement_fd(OceanContext* ctx, int32_t fd, uint64_t allocation_bytes, uint64_t offset_bytes) {
+    if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    NEED(need_frame(ctx, "ocean_bind_displacement_fd"));
+    const uint64_t map_bytes = (uint64_t)ctx->n * ctx->n * sizeof(float4);
+    if (fd < 0 || (offset_bytes & 15u) || offset_bytes > allocation_bytes || allocation_bytes - offset_bytes < map_bytes)
+        return fail(ctx, OCEAN_E_INVALID_ARG, "import: a valid descriptor, a 16-byte aligned offset, and N*N*16 bytes behind it inside the allocation");
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, sync_for_readback(ctx));
+    hipExternalMemoryHandleDesc d;
+    std::memset(&d, 0, sizeof d);
+    d.type = hipExternalMemoryHandleTypeOpaqueFd;                  // VK_EXTERNAL_MEMORY_HANDLE_TYPE_OPAQUE_FD_BIT / a HIP-exported POSIX descriptor
+    d.handle.fd = fd;
+    d.size = allocation_bytes;
+    hipExternalMemory_t ext = nullptr;
+    HIP_TRY(ctx, hipImportExternalMemory(&ext, &d));               // (on success the runtime owns the descriptor)
+    hipExternalMemoryBufferDesc b;
+    std::memset(&b, 0, sizeof b);
+    b.offset = offset_bytes;
+    b.size = map_bytes;
+    void* mapped = nullptr;
+    hipError_t e = hipExternalMemoryGetMappedBuffer(&mapped, ext, &b);
+    if (e != hipSuccess || !mapped || (reinterpret_cast<uintptr_t>(mapped) & 15u)) {
+        (void)hipDestroyExternalMemory(ext);
+        return (e != hipSuccess) ? hip_fail(ctx, e, "hipExternalMemoryGetMappedBuffer") : fail(ctx, OCEAN_E_HIP, "the imported mapping is not 16-byte aligned");
+    }
+    release_import(ctx);
+    ctx->ext_mem = ext;
+    ctx->out = (float4*)mapped;
     return OCEAN_OK;
 }
 void* ocean_stream(OceanContext* ctx) { return valid(ctx) ? (void*)ctx->stream : nullptr; }

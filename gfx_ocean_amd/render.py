@@ -210,6 +210,11 @@ class OceanDevice:
     def bind_displacement(self, device_ptr):
         self._check(load_library().ocean_bind_displacement(self._ctx, device_ptr))
 
+    def bind_displacement_fd(self, fd: int, allocation_bytes: int, offset_bytes: int = 0):
+        """Frames into memory another API exported as a file descriptor (a Vulkan VkDeviceMemory via VK_KHR_external_memory_fd, a
+        HIP allocation via hipMemExportToShareableHandle); the descriptor is consumed (ocean_bind_displacement_fd)."""
+        self._check(load_library().ocean_bind_displacement_fd(self._ctx, int(fd), int(allocation_bytes), int(offset_bytes)))
+
     # -- measurement ------------------------------------------------------------------------------------
     def time_frames(self, frames: int, t0: float = 0.0, dt: float = 1.0 / 60.0) -> float:
         """Total milliseconds (HIP events on the context stream) of `frames` fused frames."""

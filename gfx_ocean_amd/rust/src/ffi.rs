@@ -73,6 +73,7 @@ extern "C" {
     pub fn ocean_write_field(ctx: *mut OceanContext, field: i32, host_re_im: *const f32) -> i32;
     pub fn ocean_displacement_device_ptr(ctx: *mut OceanContext) -> *mut c_void;
     pub fn ocean_bind_displacement(ctx: *mut OceanContext, device_rgba: *mut c_void) -> i32;
+    pub fn ocean_bind_displacement_fd(ctx: *mut OceanContext, fd: i32, allocation_bytes: u64, offset_bytes: u64) -> i32;
     pub fn ocean_stream(ctx: *mut OceanContext) -> *mut c_void;
     pub fn ocean_time_frames(ctx: *mut OceanContext, frames: i32, t0: f32, dt: f32, out_ms: *mut f32) -> i32;
     pub fn ocean_time_frame_batches(ctx: *mut OceanContext, batches: i32, frames_per_batch: i32, t0: f32, dt: f32, batch_ms: *mut f32) -> i32;

@@ -126,6 +126,11 @@ impl Device {
         self.check(unsafe { ffi::ocean_frame_times(self.ctx, frames, t0, dt, a.as_mut_ptr(), b.as_mut_ptr(), c.as_mut_ptr()) })?;
         Ok((a, b, c))
     }
+    /// Render every following frame straight into device memory another API exported as a file descriptor -- the `VkDeviceMemory`
+    /// behind `displacement_map` (src/render.rs:820-869), exported with VK_KHR_external_memory_fd; the descriptor is consumed.
+    pub fn bind_displacement_fd(&self, fd: std::os::unix::io::RawFd, allocation_bytes: u64, offset_bytes: u64) -> Result<(), Box<dyn Error>> {
+        self.check(unsafe { ffi::ocean_bind_displacement_fd(self.ctx, fd, allocation_bytes, offset_bytes) })
+    }
     /// SURVEY 8a Q1/Q2 switches; `QUIRKS_REFERENCE` (default) is the shipped shaders' arithmetic.
     pub fn set_quirks(&self, quirks: u32) -> Result<(), Box<dyn Error>> {
         self.check(unsafe { ffi::ocean_set_quirks(self.ctx, quirks) })

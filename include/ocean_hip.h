@@ -43,7 +43,7 @@ extern "C" {
  * 4: + ocean_set_frame_normals, ocean_frame_normals, ocean_normals_device_ptr, ocean_frame_times_ex (the frame with the normal
  *    field as one workload); + ocean_frame_batch, ocean_batch_device_ptr, ocean_read_batch_displacement, ocean_time_frame_batch
  *    (K time steps per launch pair); + ocean_context_create_ex, ocean_context_flags (contexts with only the fused path's buffers); + ocean_device_count,
- *    ocean_device_pci_bus_id;
+ *    ocean_device_pci_bus_id; + ocean_bind_displacement_fd (the map in memory imported from another API's file descriptor);
  *    ocean_time_frame_batches also bounds frames_per_batch (<= 4096) */
 #define OCEAN_ABI_VERSION 4
 
@@ -246,6 +246,14 @@ int32_t ocean_pack_displacement(OceanContext* ctx, int32_t format, void* device_
 /* ---- zero-copy hooks for device-side consumers ----------------------------------------------- */
 void* ocean_displacement_device_ptr(OceanContext* ctx);           /* float4[N*N] in HBM */
 int32_t ocean_bind_displacement(OceanContext* ctx, void* device_rgba); /* write frames into caller memory (NULL = own) */
+/* The same for memory another API owns and has exported as a POSIX file descriptor: the VkDeviceMemory behind the reference's
+ * `displacement_map` image (src/render.rs:820-869: Rgba32Sfloat, STORAGE | SAMPLED; allocate it linear and export it with
+ * VK_KHR_external_memory_fd, handle type OPAQUE_FD), or a HIP allocation exported with hipMemExportToShareableHandle.  The library
+ * imports the allocation (hipImportExternalMemory; on success the descriptor belongs to the runtime, as with Vulkan's own import),
+ * maps the N*N*16 bytes at `offset_bytes` and writes every following frame straight into them: the sampler of ocean.vert:21 /
+ * ocean.frag:56-59 reads what pass 2 stored, no copy.  ocean_bind_displacement(ctx, NULL or another pointer), another import or
+ * ocean_context_destroy release the import (after waiting for the frames in flight). */
+int32_t ocean_bind_displacement_fd(OceanContext* ctx, int32_t fd, uint64_t allocation_bytes, uint64_t offset_bytes);
 void* ocean_stream(OceanContext* ctx);                            /* the context's hipStream_t */
 
 /* ---- measurement (HIP events on the stream the kernels run on) -------------------------------- */

@@ -50,3 +50,19 @@ def test_plain_c_caller_renders_the_reference_frame(tmp_path):
     assert p.returncode == 0, p.stdout + p.stderr
     assert "native c: fused" in p.stdout
     print(p.stdout.strip())
+
+
+@pytest.mark.gpu
+def test_displacement_map_in_memory_imported_from_a_file_descriptor(tmp_path):
+    """INTEGRATION.md 4 / SURVEY 8f #4 "interop": the map lives in an allocation another owner exported as a POSIX file descriptor
+    (the role of the reference's own image memory, src/render.rs:820-869); ocean_bind_displacement_fd imports it and frames land
+    there -- read back through the exporter's mapping, bit-identical to the library-owned frame."""
+    so = g.build_library()
+    libdir = os.path.dirname(so)
+    exe = str(tmp_path / "ext_interop_check")
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "ext_interop_check.hip"), "-o", exe, "-L", libdir, "-locean_hip", "-Wl,-rpath," + libdir])
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "bit for bit" in p.stdout
+    print(p.stdout.strip())
