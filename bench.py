@@ -404,6 +404,9 @@ def main():
                     help="NOT the headline: K time steps of the tile per launch pair (ocean_frame_batch; one launch pair at N <= 1024, where a "
                          "frame's two launches fill an eighth of the chip).  `value` is then frames/s of ceil(steps / K) batched launches, "
                          "the line says \"batched\": K, and carries the frame-level roofline only")
+    ap.add_argument("--batch-tiles", action="store_true",
+                    help="with --batch K: the K frames of a launch pair are K DIFFERENT tiles (seeds N + rank + 1000 k; ocean_frame_tiles, "
+                         "N <= 1024) instead of K time steps of one tile")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", dest="gather", action="store_true", default=None,
                     help="time frames followed by an RCCL gather of every tile's RGBA map to rank 0 (BASELINE config 4; "
@@ -525,8 +528,14 @@ def main():
         return
 
     h0, omega = g.synth.make_inputs(n, seed=seed)
-    dev = g.OceanDevice(n, device_ordinal=local_rank, flags=g.CTX_FUSED_ONLY)   # the fused frame's buffers only (40 instead of 76-100 B/texel)
-    dev.upload_spectrum(h0, omega, spectrum_fp16=(args.spectrum == "f16"))
+    if args.batch_tiles and args.batch > 1:                          # K independent tiles per launch pair (labelled batched mode)
+        dev = g.OceanDevice(n, device_ordinal=local_rank, tiles=args.batch)
+        dev.upload_spectrum(h0, omega, tile=0)
+        for k in range(1, args.batch):
+            dev.upload_spectrum(*g.synth.make_inputs(n, seed=seed + 1000 * k), tile=k)
+    else:
+        dev = g.OceanDevice(n, device_ordinal=local_rank, flags=g.CTX_FUSED_ONLY)   # the fused frame's buffers only (40 instead of 76-100 B/texel)
+        dev.upload_spectrum(h0, omega, spectrum_fp16=(args.spectrum == "f16"))
     if args.intermediate == "bfp16":
         dev.set_intermediate(g.INTER_BFP16)
     with_normals = args.normals != "off"
@@ -664,8 +673,10 @@ def main():
             "roofline": roofline,
         }
         if batched > 1:
+            what = "independent tiles per launch pair (ocean_frame_tiles)" if args.batch_tiles else "time steps per launch pair (ocean_frame_batch)"
             line["batched"] = batched
-            line["metric"] += f" -- BATCHED MODE, not the headline: {batched} time steps per launch pair (ocean_frame_batch)"
+            line["batched_kind"] = "tiles" if args.batch_tiles else "time steps"
+            line["metric"] += f" -- BATCHED MODE, not the headline: {batched} {what}"
             line["steps_timed"] = timed_frames
             line["config"]["workload"] += (f"; BATCHED: {batched} time steps of the tile per launch pair, {timed_frames} frames timed as "
                                            f"{timed_frames // batched} batched launches (the per-kernel figures and the frame-time "

@@ -59,6 +59,7 @@ struct OceanContext {
     int device = 0;
     int n = 0;
     uint32_t flags = 0;         // OCEAN_CTX_* of ocean_context_create_ex
+    int32_t tiles = 1;          // ocean_context_create_tiles: this many independent tiles' static inputs, one frame of each per launch pair
     hipStream_t stream = nullptr;
     bool foreign_stream = false;  // some dispatch ran on a caller stream: readbacks then wait for the whole device
     hipEvent_t ev_a = nullptr, ev_b = nullptr;   // reused by ocean_time_frames (event creation is not free)
@@ -105,7 +106,8 @@ struct OceanContext {
     float4* positions = nullptr;  // ocean_positions: verts x verts float4, (re)allocated on demand
     int32_t position_verts = 0;
     unsigned long long* checksum_acc = nullptr;   // ocean_checksum_displacement
-    bool uploaded = false;
+    bool uploaded = false;        // every tile's inputs are there (uploaded_tiles has `tiles` bits set)
+    uint64_t uploaded_tiles = 0;
     float default_domain = 1000.0f;   // src/render.rs:46
     uint32_t quirks = OCEAN_QUIRKS_REFERENCE;   // ocean_set_quirks
     std::string err;
@@ -525,7 +527,20 @@ int32_t ocean_device_pci_bus_id(int32_t device, char* out, int32_t capacity) {
 int32_t ocean_context_create(int32_t device, int32_t resolution, OceanContext** out_ctx) {
     return ocean_context_create_ex(device, resolution, 0u, out_ctx);
 }
+static int32_t context_create(int32_t device, int32_t resolution, uint32_t flags, int32_t tiles, OceanContext** out_ctx);
 int32_t ocean_context_create_ex(int32_t device, int32_t resolution, uint32_t flags, OceanContext** out_ctx) {
+    return context_create(device, resolution, flags, 1, out_ctx);
+}
+int32_t ocean_context_create_tiles(int32_t device, int32_t resolution, int32_t tiles, OceanContext** out_ctx) {
+    if (!out_ctx) return fail(nullptr, OCEAN_E_INVALID_ARG, "out_ctx is NULL");
+    *out_ctx = nullptr;
+    bool batched = false;
+    OCEAN_DISPATCH(resolution, batched = L::BATCHED);
+    if (!batched) return fail(nullptr, OCEAN_E_UNSUPPORTED_N, "several tiles per launch pair exist at N <= 1024 (above, one tile fills the chip: one context per tile)");
+    if (tiles < 1 || tiles > OCEAN_BATCH_MAX) return fail(nullptr, OCEAN_E_INVALID_ARG, "tiles must be in [1, OCEAN_BATCH_MAX]");
+    return context_create(device, resolution, OCEAN_CTX_FUSED_ONLY, tiles, out_ctx);
+}
+static int32_t context_create(int32_t device, int32_t resolution, uint32_t flags, int32_t tiles, OceanContext** out_ctx) {
     if (!out_ctx) return fail(nullptr, OCEAN_E_INVALID_ARG, "out_ctx is NULL");
     *out_ctx = nullptr;
     if (flags & ~(OCEAN_CTX_FUSED_ONLY | OCEAN_CTX_TILE_RANK)) return fail(nullptr, OCEAN_E_INVALID_ARG, "unknown context flags");
@@ -541,6 +556,7 @@ int32_t ocean_context_create_ex(int32_t device, int32_t resolution, uint32_t fla
     c->device = device;
     c->n = resolution;
     c->flags = flags;
+    c->tiles = tiles;
     c->generation = g_generation.fetch_add(1);
     DeviceGuard guard(device);
     const size_t n2 = (size_t)resolution * resolution;
@@ -588,8 +604,8 @@ int32_t ocean_context_create_ex(int32_t device, int32_t resolution, uint32_t fla
         if (c->stage_chunked)
             for (int f = 0; f < 3; ++f) CTX_TRY(hipMalloc((void**)&c->cfield[f], c->lay.fs * sizeof(c32)));
     }
-    CTX_TRY(hipMalloc((void**)&c->h0T, n2 * sizeof(c32)));
-    CTX_TRY(hipMalloc((void**)&c->omegaT, n2 * sizeof(float)));
+    CTX_TRY(hipMalloc((void**)&c->h0T, (size_t)tiles * n2 * sizeof(c32)));      // (tile k's inputs at k * N * N elements)
+    CTX_TRY(hipMalloc((void**)&c->omegaT, (size_t)tiles * n2 * sizeof(float)));
     CTX_TRY(hipMalloc((void**)&c->nyq, 3 * (size_t)resolution * sizeof(c32)));
     if (framed) {
         CTX_TRY(hipMalloc((void**)&c->inter, 3 * c->lay_h.fs * sizeof(c32)));
@@ -636,9 +652,11 @@ uint32_t ocean_context_flags(const OceanContext* ctx) { return valid(ctx) ? ctx-
 
 namespace {
 
-int32_t upload_common(OceanContext* ctx, const float* h0_re_im, const float* omega, bool f16) {
+int32_t upload_common(OceanContext* ctx, const float* h0_re_im, const float* omega, bool f16, int32_t tile = 0) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
     if (!h0_re_im || !omega) return fail(ctx, OCEAN_E_INVALID_ARG, "NULL input");
+    if (tile < 0 || tile >= ctx->tiles) return fail(ctx, OCEAN_E_INVALID_ARG, "no such tile in this context");
+    if (f16 && ctx->tiles > 1) return fail(ctx, OCEAN_E_INVALID_ARG, "a context of several tiles stores fp32 spectra (one scale per context, not per tile)");
     DeviceGuard guard(ctx->device);
     const size_t n = (size_t)ctx->n, n2 = n * n;
     HIP_TRY(ctx, sync_for_readback(ctx));                         // frames in flight still read the old inputs
@@ -673,13 +691,14 @@ int32_t upload_common(OceanContext* ctx, const float* h0_re_im, const float* ome
                            reinterpret_cast<uint32_t*>(ctx->h0T), (int)n, std::ldexp(1.0f, scale_log2), std::ldexp(1.0f, -scale_log2));
     else
         hipLaunchKernelGGL(k_transpose<float2>, dim3(tiles), dim3(256), 0, s, reinterpret_cast<const float2*>(h0_nat),
-                           reinterpret_cast<float2*>(ctx->h0T), (int)n);
-    hipLaunchKernelGGL(k_transpose<float>, dim3(tiles), dim3(256), 0, s, (const float*)om_nat, ctx->omegaT, (int)n);
+                           reinterpret_cast<float2*>(ctx->h0T) + (size_t)tile * n2, (int)n);
+    hipLaunchKernelGGL(k_transpose<float>, dim3(tiles), dim3(256), 0, s, (const float*)om_nat, ctx->omegaT + (size_t)tile * n2, (int)n);
     { const int32_t st = check_launch(ctx, "upload re-layout launch"); if (st != OCEAN_OK) return st; }
     HIP_TRY(ctx, hipStreamSynchronize(s));
     ctx->h0_f16 = f16;
     ctx->scale_log2 = scale_log2;
-    ctx->uploaded = true;
+    ctx->uploaded_tiles |= (uint64_t)1 << tile;
+    ctx->uploaded = ctx->uploaded_tiles == ((ctx->tiles >= 64) ? ~(uint64_t)0 : (((uint64_t)1 << ctx->tiles) - 1));
     return OCEAN_OK;
 }
 
@@ -688,6 +707,10 @@ int32_t upload_common(OceanContext* ctx, const float* h0_re_im, const float* ome
 int32_t ocean_upload_spectrum(OceanContext* ctx, const float* h0_re_im, const float* omega) {
     return upload_common(ctx, h0_re_im, omega, false);
 }
+int32_t ocean_upload_spectrum_tile(OceanContext* ctx, int32_t tile, const float* h0_re_im, const float* omega) {
+    return upload_common(ctx, h0_re_im, omega, false, tile);
+}
+int32_t ocean_context_tiles(const OceanContext* ctx) { return valid(ctx) ? ctx->tiles : OCEAN_E_INVALID_ARG; }
 int32_t ocean_upload_spectrum_f16(OceanContext* ctx, const float* h0_re_im, const float* omega) {
     return upload_common(ctx, h0_re_im, omega, true);
 }
@@ -1107,7 +1130,8 @@ int32_t batch_reserve(OceanContext* ctx, int32_t count, bool own_out) {
     }
     return OCEAN_OK;
 }
-void launch_batch(OceanContext* c, float t0, float dt, int32_t count, float4* out, size_t out_stride_texels, hipStream_t s) {
+// `tiles`: the K frames are K different tiles at the same time (ocean_frame_tiles) instead of K time steps of tile 0.
+void launch_batch(OceanContext* c, float t0, float dt, int32_t count, float4* out, size_t out_stride_texels, hipStream_t s, bool tiles = false) {
     bool batched = false;
     OCEAN_DISPATCH(c->n, batched = L::BATCHED);
     if (batched) {
@@ -1115,6 +1139,10 @@ void launch_batch(OceanContext* c, float t0, float dt, int32_t count, float4* ou
         b.dt = dt;
         b.inter_stride = (uint32_t)(3 * c->lay_h.fs);
         b.out_stride = out_stride_texels;
+        if (tiles) {
+            b.spec_stride_bytes = (size_t)c->n * c->n * sizeof(c32);
+            b.omega_stride = (uint32_t)((size_t)c->n * c->n);
+        }
         OCEAN_DISPATCH(c->n, {
             L::pass1_on(c, t0, c->default_domain, c->batch_inter, c->lay_h, L::H::half_grid1, 0, s, Timing(), c->batch_nyq, b, count);
             L::pass2_on(c, c->batch_inter, out, s, Timing(), b, count);
@@ -1140,6 +1168,20 @@ int32_t ocean_frame_batch(OceanContext* ctx, float t0, float dt, int32_t count, 
     launch_batch(ctx, t0, dt, count, out, (size_t)(out_stride_bytes / 16), pick(ctx, stream));
     return check_launch(ctx, "ocean_frame_batch launch");
 }
+int32_t ocean_frame_tiles(OceanContext* ctx, float time, void* out_base_device, int64_t out_stride_bytes, void* stream) {
+    if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    { const int32_t st = batch_check(ctx, ctx->tiles); if (st != OCEAN_OK) return st; }
+    const int64_t map_bytes = (int64_t)ctx->n * ctx->n * 16;
+    if (out_base_device) {
+        if ((reinterpret_cast<uintptr_t>(out_base_device) & 15u) || (out_stride_bytes & 15) || out_stride_bytes < map_bytes)
+            return fail(ctx, OCEAN_E_INVALID_ARG, "tile maps: 16-byte aligned base, stride a multiple of 16 and >= N*N*16");
+    } else out_stride_bytes = map_bytes;
+    DeviceGuard guard(ctx->device);
+    { const int32_t st = batch_reserve(ctx, ctx->tiles, out_base_device == nullptr); if (st != OCEAN_OK) return st; }
+    float4* out = out_base_device ? (float4*)out_base_device : ctx->batch_out;
+    launch_batch(ctx, time, 0.0f, ctx->tiles, out, (size_t)(out_stride_bytes / 16), pick(ctx, stream), true);
+    return check_launch(ctx, "ocean_frame_tiles launch");
+}
 void* ocean_batch_device_ptr(OceanContext* ctx) { return valid(ctx) ? (void*)ctx->batch_out : nullptr; }
 int32_t ocean_read_batch_displacement(OceanContext* ctx, int32_t index, float* host_rgba) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
@@ -1156,11 +1198,14 @@ int32_t ocean_time_frame_batch(OceanContext* ctx, int32_t launches, int32_t coun
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
     if (launches < 1 || launches > 65536 || !out_ms) return fail(ctx, OCEAN_E_INVALID_ARG, "launches in [1, 65536], out_ms non-NULL");
     { const int32_t st = batch_check(ctx, count); if (st != OCEAN_OK) return st; }
+    if (ctx->tiles > 1 && count != ctx->tiles) return fail(ctx, OCEAN_E_INVALID_ARG, "a context of K tiles is timed with count = K");
     DeviceGuard guard(ctx->device);
     { const int32_t st = batch_reserve(ctx, count, true); if (st != OCEAN_OK) return st; }
     const size_t n2 = (size_t)ctx->n * ctx->n;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_a, ctx->stream));
-    for (int i = 0; i < launches; ++i) launch_batch(ctx, t0 + dt * (float)((int64_t)i * count), dt, count, ctx->batch_out, n2, ctx->stream);
+    const bool tiles = ctx->tiles > 1;                             // a context of several tiles: every launch pair = one frame of each tile
+    for (int i = 0; i < launches; ++i)
+        launch_batch(ctx, tiles ? t0 + dt * (float)i : t0 + dt * (float)((int64_t)i * count), tiles ? 0.0f : dt, count, ctx->batch_out, n2, ctx->stream, tiles);
     HIP_TRY(ctx, hipEventRecord(ctx->ev_b, ctx->stream));
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev_b));
     HIP_TRY(ctx, hipEventElapsedTime(out_ms, ctx->ev_a, ctx->ev_b));

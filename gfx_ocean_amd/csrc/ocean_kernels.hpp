@@ -133,6 +133,9 @@ struct FrameBatch {
     float dt = 0.0f;                // frame y: time = t0 + dt * (float)y, rounded like the host's `t0 + dt * (float)y` (no FMA)
     uint32_t inter_stride = 0;      // elements between the intermediates of consecutive frames
     size_t out_stride = 0;          // texels (float4) between their output maps
+    // K TILES instead of K time steps (ocean_frame_tiles: dt = 0): frame y reads its own static inputs
+    size_t spec_stride_bytes = 0;   // between the transposed spectra of consecutive tiles
+    uint32_t omega_stride = 0;      // elements between their transposed dispersion arrays
 };
 template <int N> constexpr bool batched_launches = (N <= 1024);
 
@@ -528,6 +531,8 @@ k_half_pass1(const void* __restrict__ h0T, float descale, const float* __restric
         time = __fadd_rn(time, __fmul_rn(batch.dt, (float)fi));
         inter += (size_t)fi * batch.inter_stride;
         nyq_spec += (size_t)fi * (3 * N);
+        h0T = reinterpret_cast<const char*>(h0T) + (size_t)fi * batch.spec_stride_bytes;
+        omegaT += (size_t)fi * batch.omega_stride;
     }
     constexpr int T = N / E;
     constexpr int GT = T * P;                                      // threads of one field group (= the workgroup without FPAR)

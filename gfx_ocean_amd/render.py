@@ -21,15 +21,19 @@ class OceanDevice:
     """One GPU + the buffers of the path (initial_spec, omega, dx/dy/dz_spec, displacement map:
     src/render.rs:607-670, 820-869)."""
 
-    def __init__(self, resolution: int, device_ordinal: int = 0, flags: int = 0):
+    def __init__(self, resolution: int, device_ordinal: int = 0, flags: int = 0, tiles: int = 1):
         """flags: 0 = both paths' buffers; CTX_FUSED_ONLY = the fused frame's only (40 instead of 100 / 76 B/texel; the staged
         dispatches then raise OCEAN_E_STATE); CTX_TILE_RANK = one rank of a sharded tile (static inputs only, 12 B/texel)."""
         lib = load_library()
         ctx = ctypes.c_void_p()
-        st = lib.ocean_context_create_ex(int(device_ordinal), int(resolution), int(flags), ctypes.byref(ctx))
+        if tiles > 1:      # K independent tiles' static inputs in one fused-only context: one frame of each per launch pair (N <= 1024)
+            st = lib.ocean_context_create_tiles(int(device_ordinal), int(resolution), int(tiles), ctypes.byref(ctx))
+        else:
+            st = lib.ocean_context_create_ex(int(device_ordinal), int(resolution), int(flags), ctypes.byref(ctx))
         if st != OCEAN_OK:
             raise OceanError(st, (lib.ocean_last_error(None) or b"").decode())
         self._ctx = ctx
+        self.tiles = int(tiles)
         self.resolution = int(resolution)
         self.device_ordinal = int(device_ordinal)
 
@@ -63,14 +67,20 @@ class OceanDevice:
         self._check(load_library().ocean_sync(self._ctx))
 
     # -- upload (src/render.rs:742-924) ----------------------------------------------------------
-    def upload_spectrum(self, h0: np.ndarray, omega: np.ndarray, spectrum_fp16: bool = False):
+    def upload_spectrum(self, h0: np.ndarray, omega: np.ndarray, spectrum_fp16: bool = False, tile: int = 0):
         """spectrum_fp16=True: BASELINE config 5 -- h0 kept in HBM as scaled fp16 pairs for the fused
-        path (fp32 arithmetic); read_spectrum() then returns the dequantised values in use."""
+        path (fp32 arithmetic); read_spectrum() then returns the dequantised values in use.
+        tile: which tile of a context of several (OceanDevice(.., tiles=K)) these inputs belong to."""
         n = self.resolution
         h0 = np.ascontiguousarray(h0, dtype=np.complex64)
         omega = np.ascontiguousarray(omega, dtype=np.float32)
         if h0.shape != (n, n) or omega.shape != (n, n):
             raise OceanError(-1, f"expected ({n},{n}) arrays, got {h0.shape} and {omega.shape}")
+        if tile or self.tiles > 1:
+            if spectrum_fp16:
+                raise OceanError(-1, "a context of several tiles stores fp32 spectra")
+            self._check(load_library().ocean_upload_spectrum_tile(self._ctx, int(tile), h0.ctypes.data, omega.ctypes.data))
+            return
         fn = load_library().ocean_upload_spectrum_f16 if spectrum_fp16 else load_library().ocean_upload_spectrum
         self._check(fn(self._ctx, h0.ctypes.data, omega.ctypes.data))
 
@@ -112,6 +122,10 @@ class OceanDevice:
         """`count` time steps t0 + i dt of this tile, each into its own map; at N <= 1024 ONE launch pair (ocean_frame_batch).
         out_ptr None: library-owned maps (read_batch_displacement)."""
         self._check(load_library().ocean_frame_batch(self._ctx, float(t0), float(dt), int(count), out_ptr, int(out_stride_bytes), stream))
+
+    def frame_tiles(self, time: float, out_ptr=None, out_stride_bytes: int = 0, stream=None):
+        """One frame of EVERY tile of this context at `time` in one launch pair (ocean_frame_tiles); maps as frame_batch."""
+        self._check(load_library().ocean_frame_tiles(self._ctx, float(time), out_ptr, int(out_stride_bytes), stream))
 
     def read_batch_displacement(self, index: int) -> np.ndarray:
         n = self.resolution

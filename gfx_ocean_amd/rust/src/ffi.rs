@@ -48,6 +48,10 @@ extern "C" {
     pub fn ocean_correct(c: *mut OceanCorrection, locals: *const OceanCorrectionLocals, stream: *mut c_void) -> i32;
     pub fn ocean_frame(ctx: *mut OceanContext, time: f32, stream: *mut c_void) -> i32;
     pub fn ocean_frame_ex(ctx: *mut OceanContext, locals: *const OceanPropagateLocals, stream: *mut c_void) -> i32;
+    pub fn ocean_context_create_tiles(device: i32, resolution: i32, tiles: i32, out: *mut *mut OceanContext) -> i32;
+    pub fn ocean_context_tiles(ctx: *const OceanContext) -> i32;
+    pub fn ocean_upload_spectrum_tile(ctx: *mut OceanContext, tile: i32, h0_re_im: *const f32, omega: *const f32) -> i32;
+    pub fn ocean_frame_tiles(ctx: *mut OceanContext, time: f32, out_base_device: *mut c_void, out_stride_bytes: i64, stream: *mut c_void) -> i32;
     pub fn ocean_frame_batch(ctx: *mut OceanContext, t0: f32, dt: f32, count: i32, out_base_device: *mut c_void, out_stride_bytes: i64,
                              stream: *mut c_void) -> i32;
     pub fn ocean_batch_device_ptr(ctx: *mut OceanContext) -> *mut c_void;

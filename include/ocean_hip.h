@@ -41,7 +41,8 @@ extern "C" {
  *    the same number in round 3); readbacks wait for the whole device once a dispatch has been put on a caller stream
  * 3: + ocean_frame_times, ocean_time_frame_batches; ocean_sync and ocean_context_destroy honour caller streams like the readbacks
  * 4: + ocean_set_frame_normals, ocean_frame_normals, ocean_normals_device_ptr, ocean_frame_times_ex (the frame with the normal
- *    field as one workload); + ocean_frame_batch, ocean_batch_device_ptr, ocean_read_batch_displacement, ocean_time_frame_batch
+ *    field as one workload); + ocean_context_create_tiles, ocean_context_tiles, ocean_upload_spectrum_tile, ocean_frame_tiles (K tiles per launch pair);
+ *    + ocean_frame_batch, ocean_batch_device_ptr, ocean_read_batch_displacement, ocean_time_frame_batch
  *    (K time steps per launch pair); + ocean_context_create_ex, ocean_context_flags (contexts with only the fused path's buffers); + ocean_device_count,
  *    ocean_device_pci_bus_id; + ocean_bind_displacement_fd (the map in memory imported from another API's file descriptor);
  *    ocean_time_frame_batches also bounds frames_per_batch (<= 4096) */
@@ -190,6 +191,15 @@ int32_t ocean_intermediate(const OceanContext* ctx);
  * N >= 2048 a frame fills the chip and the call is K ordinary launch pairs.  Every map is bit-identical to ocean_frame at the
  * same time.  Reference quirks only; without the normal field (OCEAN_E_STATE otherwise).  ocean_frame's own map is untouched. */
 #define OCEAN_BATCH_MAX 64
+/* ... and K independent TILES per launch pair (N <= 1024, fp32 spectra): ocean_context_create_tiles makes a fused-only context
+ * that holds K tiles' static inputs (ocean_upload_spectrum_tile, k = 0 .. K-1; ocean_upload_spectrum = tile 0), and
+ * ocean_frame_tiles(ctx, time, ...) computes the frame of every tile at `time` in ONE launch pair (blockIdx.y = tile), maps as in
+ * ocean_frame_batch.  Tile k's map is bit-identical to ocean_frame on a context that holds that tile alone.  (ocean_frame and
+ * ocean_frame_batch on such a context use tile 0.) */
+int32_t ocean_context_create_tiles(int32_t device_ordinal, int32_t resolution, int32_t tiles, OceanContext** out_ctx);
+int32_t ocean_context_tiles(const OceanContext* ctx);
+int32_t ocean_upload_spectrum_tile(OceanContext* ctx, int32_t tile, const float* h0_re_im, const float* omega);
+int32_t ocean_frame_tiles(OceanContext* ctx, float time, void* out_base_device, int64_t out_stride_bytes, void* stream);
 int32_t ocean_frame_batch(OceanContext* ctx, float t0, float dt, int32_t count, void* out_base_device, int64_t out_stride_bytes,
                           void* stream);
 void* ocean_batch_device_ptr(OceanContext* ctx);                    /* library-owned maps of the last NULL-buffer batch */

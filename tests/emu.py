@@ -152,16 +152,20 @@ def frame_half(h0, omega, time, L=1000.0, layout="p2", return_inter=False, spect
                inter16=False, plane_channel=None, batch=None):
     """split=True: every line as two interleaved N/2 transforms (the N = 8192 geometry, P = 2; with P=1 the N = 16384 geometry:
     one column per pass-1 workgroup); inter16=True (split, P = 2 only): the 16-bit block-floating intermediate (OCEAN_INTER_BFP16)."""
-    n = h0.shape[0]
+    # h0 / omega [K, n, n] with batch=(K, 0.0): K TILES per launch pair (ocean_frame_tiles) instead of K time steps of one
+    tiles = h0.ndim == 3
+    n = h0.shape[-1]
     P = (1 if P == 1 else 2) if split else (P or lib().emu_frame_p(n))
     descale = 1.0
     if spectrum_fp16:
         packed, _, s = quantize_f16(h0)
         h0T = np.ascontiguousarray(packed.T, np.uint32)
         descale = 2.0 ** -s
+    elif tiles:
+        h0T = np.ascontiguousarray(np.swapaxes(h0, 1, 2), np.complex64)
     else:
         h0T = np.ascontiguousarray(h0.T, np.complex64)
-    omT = np.ascontiguousarray(omega.T, np.float32)
+    omT = np.ascontiguousarray(np.swapaxes(omega, -1, -2), np.float32)
     sx, sy, fs, bshift = half_layout(n, P, layout, bshift=bshift)
     # batch = (count, dt): `count` time steps time + i dt in ONE launch pair (ocean_frame_batch, N <= 1024) -> out [count, n, n, 4]
     count, dt = batch if batch else (1, 0.0)
@@ -170,6 +174,8 @@ def frame_half(h0, omega, time, L=1000.0, layout="p2", return_inter=False, spect
     out = np.full((count, n, n, 4) if batch else (n, n, 4), np.nan, np.float32)
     lib().emu_set_batch.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_uint, ctypes.c_size_t]
     lib().emu_set_batch(count, dt, 3 * fs, n * n)
+    lib().emu_set_batch_tiles.argtypes = [ctypes.c_size_t, ctypes.c_uint]
+    lib().emu_set_batch_tiles(n * n * 8 if tiles else 0, n * n if tiles else 0)
     tw = twiddles(n)
     assert split or not inter16
     scales = np.full(3 * (n // 64) * (n // 4), np.nan, np.float32) if inter16 else None

@@ -305,6 +305,12 @@ int emu_set_batch(int count, float dt, unsigned inter_stride, size_t out_stride)
     batch = FrameBatch{dt, inter_stride, out_stride};
     return 0;
 }
+// ... and K TILES instead of K time steps (ocean_frame_tiles): frame y reads its own transposed inputs, these strides apart
+int emu_set_batch_tiles(size_t spec_stride_bytes, unsigned omega_stride) {
+    batch.spec_stride_bytes = spec_stride_bytes;
+    batch.omega_stride = omega_stride;
+    return 0;
+}
 int emu_normals_plane_bands(int n, const float* src_plane, float* normals) {   // what launch_normals_plane runs at N >= 8192
     emu_launch(n / NORMALS_BAND_ROWS, 256, [&] { k_normals_plane_bands<NORMALS_BAND_ROWS>(src_plane, (float4*)normals, n); });
     return 0;

@@ -147,6 +147,15 @@ def test_emu_frame_batch(n, ref_inputs, ref_inputs_256):
     assert not np.array_equal(outs[0], outs[1])
 
 
+def test_emu_frame_tiles(ref_inputs_256):
+    """ocean_frame_tiles: K independent tiles as blockIdx.y of one launch pair, each with its own transposed inputs."""
+    h0, om = ref_inputs_256
+    h1, o1 = g.synth.make_inputs(256, seed=6)
+    outs = emu.frame_half(np.stack([h0, h1]), np.stack([om, o1]), 1.5, batch=(2, 0.0))
+    assert np.array_equal(outs[0], emu.frame_half(h0, om, 1.5)) and np.array_equal(outs[1], emu.frame_half(h1, o1, 1.5))
+    assert not np.array_equal(outs[0], outs[1])
+
+
 def test_emu_split_line_geometry_block_layout(ref_inputs):
     """The split kernels (N = 8192 geometry) with the intermediate in blocks of 8 chunk rows."""
     h0, om = ref_inputs

@@ -544,6 +544,43 @@ def test_fused_only_and_tile_rank_contexts(n):
         tr.destroy()
 
 
+@pytest.mark.parametrize("n,tiles", [(256, 8), (512, 3), (1024, 2)])
+def test_frame_tiles_is_bit_identical_to_one_context_per_tile(n, tiles):
+    """ocean_frame_tiles: K independent tiles (their own spectra and dispersion arrays) per launch pair at N <= 1024.  Tile k's map
+    equals ocean_frame's on a context that holds that tile alone, bit for bit; a frame is refused until every tile is uploaded."""
+    inputs = [g.synth.make_inputs(n, seed=100 + k) for k in range(tiles)]
+    d = g.OceanDevice(n, tiles=tiles)
+    try:
+        assert g.load_library().ocean_context_tiles(d._ctx) == tiles
+        for k, (h0, om) in enumerate(inputs[:-1]):
+            d.upload_spectrum(h0, om, tile=k)
+        with pytest.raises(g.OceanError):
+            d.frame_tiles(1.0)                                    # the last tile has no inputs yet
+        d.upload_spectrum(*inputs[-1], tile=tiles - 1)
+        d.frame_tiles(2.25)
+        maps = [d.read_batch_displacement(k) for k in range(tiles)]
+        for t_ in (0.5, 2.25):                                    # consecutive launches reuse the intermediates
+            d.frame_tiles(t_)
+        again = [d.read_batch_displacement(k) for k in range(tiles)]
+        assert d.time_frame_batch(3, tiles) > 0
+        with pytest.raises(g.OceanError):
+            d.upload_spectrum(*inputs[0], spectrum_fp16=True)
+    finally:
+        d.destroy()
+    for k, (h0, om) in enumerate(inputs):
+        one = g.OceanDevice(n, flags=g.CTX_FUSED_ONLY)
+        try:
+            one.upload_spectrum(h0, om)
+            one.frame(2.25)
+            want = one.read_displacement()
+        finally:
+            one.destroy()
+        assert np.array_equal(maps[k], want) and np.array_equal(again[k], want), (n, k)
+    assert not np.array_equal(maps[0], maps[1])
+    with pytest.raises(g.OceanError):
+        g.OceanDevice(2048, tiles=2)                              # above 1024 one tile fills the chip: one context per tile
+
+
 @pytest.mark.parametrize("verts,offset", [(128, (0.0, 0.0)), (128, (127.0, 127.0)), (257, (0.0, 0.0))])
 def test_vertex_positions(r512, ref_inputs, verts, offset):
     """the vertex stage's positions (shader/ocean.vert:21-25; patch grid and offsets of
