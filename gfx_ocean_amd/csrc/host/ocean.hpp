@@ -30,6 +30,15 @@ public:
         const int32_t st = ocean_context_create(ordinal, resolution, &ctx_);
         if (st != OCEAN_OK) throw Error(st, ocean_last_error(nullptr));
     }
+    // `tiles` independent tiles in one context (N <= 1024): upload_spectrum_tile each, frame_tiles = one frame of every tile per launch pair
+    Device(int resolution, int ordinal, int tiles) {
+        const int32_t st = ocean_context_create_tiles(ordinal, resolution, tiles, &ctx_);
+        if (st != OCEAN_OK) throw Error(st, ocean_last_error(nullptr));
+    }
+    void upload_spectrum_tile(int tile, const std::vector<std::complex<float>>& h0, const std::vector<float>& omega) {
+        check(ocean_upload_spectrum_tile(ctx_, tile, reinterpret_cast<const float*>(h0.data()), omega.data()));
+    }
+    void frame_tiles(float time, void* stream = nullptr) { check(ocean_frame_tiles(ctx_, time, nullptr, 0, stream)); }
     ~Device() { ocean_context_destroy(ctx_); }
     Device(const Device&) = delete;
     Device& operator=(const Device&) = delete;

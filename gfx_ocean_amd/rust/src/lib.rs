@@ -56,6 +56,26 @@ impl Device {
         if st != 0 { return Err(Box::new(error(ptr::null(), st))); }
         Ok(Device { ctx })
     }
+    /// `tiles` independent tiles' static inputs in one context (N <= 1024): `upload_spectrum_tile` each, then `frame_tiles` computes
+    /// one frame of every tile in one launch pair (include/ocean_hip.h `ocean_context_create_tiles`).
+    pub fn with_tiles(ordinal: i32, resolution: i32, tiles: i32) -> Result<Self, Box<dyn Error>> {
+        let mut ctx = ptr::null_mut();
+        let st = unsafe { ffi::ocean_context_create_tiles(ordinal, resolution, tiles, &mut ctx) };
+        if st != 0 { return Err(Box::new(error(ptr::null(), st))); }
+        Ok(Device { ctx })
+    }
+    pub fn upload_spectrum_tile(&self, tile: i32, spectrum: &[[f32; 2]], omega: &[f32]) -> Result<(), Box<dyn Error>> {
+        let n2 = self.texels()?;
+        if spectrum.len() != n2 || omega.len() != n2 {
+            return Err(Box::new(OceanError { status: -1, message: format!(
+                "upload_spectrum_tile: expected {} texels, got {} and {}", n2, spectrum.len(), omega.len()) }));
+        }
+        self.check(unsafe { ffi::ocean_upload_spectrum_tile(self.ctx, tile, spectrum.as_ptr() as *const f32, omega.as_ptr()) })
+    }
+    /// One frame of every tile at `time` into library-owned maps (`read_batch_displacement(k, ..)`).
+    pub fn frame_tiles(&self, time: f32) -> Result<(), Box<dyn Error>> {
+        self.check(unsafe { ffi::ocean_frame_tiles(self.ctx, time, ptr::null_mut(), 0, ptr::null_mut()) })
+    }
     fn check(&self, st: i32) -> Result<(), Box<dyn Error>> {
         if st == 0 { Ok(()) } else { Err(Box::new(error(self.ctx, st))) }
     }

@@ -17,6 +17,7 @@ timeout 600 $B --no-cpu-baseline --n 2048 --steps 200 --warmup 20 2>/dev/null | 
 echo "== bench config 2 plain / batched"
 timeout 600 $B --n 512 --steps 200 --warmup 20 2>/dev/null | tee $O/bench_n512.json | cut -c1-260
 for k in 8 16 64; do timeout 600 $B --no-cpu-baseline --n 512 --batch $k --steps 8192 --warmup 128 2>/dev/null | tee $O/bench_n512_batch$k.json | cut -c1-260; done
+timeout 600 $B --no-cpu-baseline --n 512 --batch 8 --batch-tiles --steps 8192 --warmup 128 2>/dev/null | tee $O/bench_n512_batch8_tiles.json | cut -c1-260
 timeout 600 $B --no-cpu-baseline --n 256 --batch 64 --steps 8192 --warmup 128 2>/dev/null | tee $O/bench_n256_batch64.json | cut -c1-260
 timeout 600 $B --no-cpu-baseline --n 1024 --batch 16 --steps 4096 --warmup 64 2>/dev/null | tee $O/bench_n1024_batch16.json | cut -c1-260
 echo "== bench 4096 with normals, 8192, 16384"
