@@ -14,13 +14,13 @@ from .ocean import (Correction, CorrectionLocals, Propagation, PropagateLocals, 
 from .fft import Fft  # noqa: F401
 from .render import (OceanDevice, OceanRenderer, FIELD_DX, FIELD_DY, FIELD_DZ, FIELD_ALL,  # noqa: F401
                      QUIRK_Q1, QUIRK_Q2, QUIRKS_REFERENCE, PACK_RGBA32F, PACK_RGB32F, PACK_HEIGHT32F,
-                     PACK_BYTES_PER_TEXEL, INTER_F32, INTER_BFP16, CTX_FUSED_ONLY, CTX_TILE_RANK)
+                     PACK_BYTES_PER_TEXEL, INTER_F32, INTER_BFP16, CTX_FUSED_ONLY, CTX_TILE_RANK, CTX_TILE_BANDS)
 from . import bincode, synth  # noqa: F401
 
 __all__ = [
     "OceanError", "build_library", "library_path", "load_library",
     "Correction", "CorrectionLocals", "Propagation", "PropagateLocals", "Fft",
     "OceanDevice", "OceanRenderer", "FIELD_DX", "FIELD_DY", "FIELD_DZ", "FIELD_ALL",
-    "QUIRK_Q1", "QUIRK_Q2", "QUIRKS_REFERENCE", "PACK_RGBA32F", "PACK_RGB32F", "PACK_HEIGHT32F", "PACK_BYTES_PER_TEXEL", "INTER_F32", "INTER_BFP16", "CTX_FUSED_ONLY", "CTX_TILE_RANK",
+    "QUIRK_Q1", "QUIRK_Q2", "QUIRKS_REFERENCE", "PACK_RGBA32F", "PACK_RGB32F", "PACK_HEIGHT32F", "PACK_BYTES_PER_TEXEL", "INTER_F32", "INTER_BFP16", "CTX_FUSED_ONLY", "CTX_TILE_RANK", "CTX_TILE_BANDS",
     "DOMAIN_SIZE", "RESOLUTION", "bincode", "synth",
 ]

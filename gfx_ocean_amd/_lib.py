@@ -17,7 +17,7 @@ STATUS_NAMES = {0: "OCEAN_OK", -1: "OCEAN_E_INVALID_ARG", -2: "OCEAN_E_UNSUPPORT
 
 # every symbol include/ocean_hip.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [
-    "ocean_abi_version", "ocean_device_count", "ocean_device_pci_bus_id", "ocean_context_create", "ocean_context_create_ex", "ocean_context_flags", "ocean_context_destroy", "ocean_last_error", "ocean_resolution",
+    "ocean_abi_version", "ocean_device_count", "ocean_device_pci_bus_id", "ocean_context_create", "ocean_context_create_ex", "ocean_context_create_tile_rank", "ocean_context_flags", "ocean_context_destroy", "ocean_last_error", "ocean_resolution",
     "ocean_upload_spectrum", "ocean_upload_spectrum_f16", "ocean_spectrum_scale_log2", "ocean_read_spectrum",
     "ocean_fft_init", "ocean_fft_destroy", "ocean_propagation_init",
     "ocean_propagation_destroy", "ocean_correction_init", "ocean_correction_destroy", "ocean_propagate",
@@ -123,6 +123,7 @@ def load_library():
         "ocean_device_pci_bus_id": (i32, [i32, ctypes.c_char_p, i32]),
         "ocean_context_create": (i32, [i32, i32, pp]),
         "ocean_context_create_ex": (i32, [i32, i32, ctypes.c_uint32, pp]),
+        "ocean_context_create_tile_rank": (i32, [i32, i32, i32, i32, pp]),
         "ocean_context_flags": (ctypes.c_uint32, [vp]),
         "ocean_context_destroy": (None, [vp]),
         "ocean_last_error": (ctypes.c_char_p, [vp]),

@@ -59,6 +59,14 @@ struct OceanContext {
     int device = 0;
     int n = 0;
     uint32_t flags = 0;         // OCEAN_CTX_* of ocean_context_create_ex
+    // ocean_context_create_tile_rank: h0T / omegaT are address ranges of the full size of which only the lines this rank's pass 1 reads
+    // are backed by memory (HIP virtual-memory API: the kernels keep indexing absolute lines)
+    bool bands = false;
+    int32_t tile_rank = 0, tile_world = 1;
+    std::vector<std::pair<int, int>> band_blocks;                 // [first, count) in blocks of 32 lines, sorted, disjoint
+    struct Mapping { void* va; size_t bytes; hipMemGenericAllocationHandle_t handle; };
+    std::vector<Mapping> band_maps;
+    size_t h0T_reserved = 0, omegaT_reserved = 0;
     int32_t tiles = 1;          // ocean_context_create_tiles: this many independent tiles' static inputs, one frame of each per launch pair
     hipStream_t stream = nullptr;
     bool foreign_stream = false;  // some dispatch ran on a caller stream: readbacks then wait for the whole device
@@ -496,6 +504,14 @@ void release_import(OceanContext* c) {
 }
 void free_all(OceanContext* c) {
     release_import(c);
+    if (c->bands) {                                // the two sparse address ranges: unmap and release what backs them, then the ranges themselves
+        for (auto& m : c->band_maps) { (void)hipMemUnmap(m.va, m.bytes); (void)hipMemRelease(m.handle); }
+        c->band_maps.clear();
+        if (c->h0T) (void)hipMemAddressFree(c->h0T, c->h0T_reserved);
+        if (c->omegaT) (void)hipMemAddressFree(c->omegaT, c->omegaT_reserved);
+        c->h0T = nullptr;
+        c->omegaT = nullptr;
+    }
     auto f = [](void* p) { if (p) (void)hipFree(p); };
     f(c->h0); f(c->omega); f(c->field[0]); f(c->field[1]); f(c->field[2]);
     f(c->cfield[0]); f(c->cfield[1]); f(c->cfield[2]); f(c->field_alt[0]); f(c->field_alt[1]); f(c->field_alt[2]);
@@ -527,7 +543,16 @@ int32_t ocean_device_pci_bus_id(int32_t device, char* out, int32_t capacity) {
 int32_t ocean_context_create(int32_t device, int32_t resolution, OceanContext** out_ctx) {
     return ocean_context_create_ex(device, resolution, 0u, out_ctx);
 }
-static int32_t context_create(int32_t device, int32_t resolution, uint32_t flags, int32_t tiles, OceanContext** out_ctx);
+static int32_t context_create(int32_t device, int32_t resolution, uint32_t flags, int32_t tiles, OceanContext** out_ctx, int32_t band_rank = -1,
+                              int32_t band_world = 1);
+int32_t ocean_context_create_tile_rank(int32_t device, int32_t resolution, int32_t rank, int32_t world, OceanContext** out_ctx) {
+    if (!out_ctx) return fail(nullptr, OCEAN_E_INVALID_ARG, "out_ctx is NULL");
+    *out_ctx = nullptr;
+    if (!supported_n(resolution)) return fail(nullptr, OCEAN_E_UNSUPPORTED_N, "resolution must be a power of two in [256, 16384]");
+    if (world < 1 || (world & (world - 1)) || resolution / world < 32 || rank < 0 || rank >= world)
+        return fail(nullptr, OCEAN_E_INVALID_ARG, "world a power of two with at least 32 rows per rank, 0 <= rank < world");
+    return context_create(device, resolution, OCEAN_CTX_TILE_RANK | OCEAN_CTX_TILE_BANDS, 1, out_ctx, rank, world);
+}
 int32_t ocean_context_create_ex(int32_t device, int32_t resolution, uint32_t flags, OceanContext** out_ctx) {
     return context_create(device, resolution, flags, 1, out_ctx);
 }
@@ -540,10 +565,11 @@ int32_t ocean_context_create_tiles(int32_t device, int32_t resolution, int32_t t
     if (tiles < 1 || tiles > OCEAN_BATCH_MAX) return fail(nullptr, OCEAN_E_INVALID_ARG, "tiles must be in [1, OCEAN_BATCH_MAX]");
     return context_create(device, resolution, OCEAN_CTX_FUSED_ONLY, tiles, out_ctx);
 }
-static int32_t context_create(int32_t device, int32_t resolution, uint32_t flags, int32_t tiles, OceanContext** out_ctx) {
+static int32_t context_create(int32_t device, int32_t resolution, uint32_t flags, int32_t tiles, OceanContext** out_ctx, int32_t band_rank, int32_t band_world) {
     if (!out_ctx) return fail(nullptr, OCEAN_E_INVALID_ARG, "out_ctx is NULL");
     *out_ctx = nullptr;
-    if (flags & ~(OCEAN_CTX_FUSED_ONLY | OCEAN_CTX_TILE_RANK)) return fail(nullptr, OCEAN_E_INVALID_ARG, "unknown context flags");
+    if (flags & ~(OCEAN_CTX_FUSED_ONLY | OCEAN_CTX_TILE_RANK | ((band_rank >= 0) ? OCEAN_CTX_TILE_BANDS : 0u)))
+        return fail(nullptr, OCEAN_E_INVALID_ARG, "unknown context flags (OCEAN_CTX_TILE_BANDS comes from ocean_context_create_tile_rank)");
     if (flags & OCEAN_CTX_TILE_RANK) flags |= OCEAN_CTX_FUSED_ONLY;
     if (!supported_n(resolution))
         return fail(nullptr, OCEAN_E_UNSUPPORTED_N, "resolution must be a power of two in [256, 16384]");
@@ -557,6 +583,9 @@ static int32_t context_create(int32_t device, int32_t resolution, uint32_t flags
     c->n = resolution;
     c->flags = flags;
     c->tiles = tiles;
+    c->bands = band_rank >= 0;
+    c->tile_rank = c->bands ? band_rank : 0;
+    c->tile_world = c->bands ? band_world : 1;
     c->generation = g_generation.fetch_add(1);
     DeviceGuard guard(device);
     const size_t n2 = (size_t)resolution * resolution;
@@ -604,8 +633,75 @@ static int32_t context_create(int32_t device, int32_t resolution, uint32_t flags
         if (c->stage_chunked)
             for (int f = 0; f < 3; ++f) CTX_TRY(hipMalloc((void**)&c->cfield[f], c->lay.fs * sizeof(c32)));
     }
-    CTX_TRY(hipMalloc((void**)&c->h0T, (size_t)tiles * n2 * sizeof(c32)));      // (tile k's inputs at k * N * N elements)
-    CTX_TRY(hipMalloc((void**)&c->omegaT, (size_t)tiles * n2 * sizeof(float)));
+    if (c->bands) {
+        // Reserve the full ranges, back the bands: own-type lines a-1 .. b-1 and mirror-type lines N-b .. N-a (mod N) of the rank's
+        // half-spectrum columns [a, b), on rank 0 also the Nyquist column's N/2-1 and N/2 (gfx_ocean_amd/sharded.py tile_rank_lines;
+        // tests/test_sharded.py poisons every other line and gets the same bits), rounded to the 32-line tiles of the upload.
+        const int nb = resolution / 32, a = c->tile_rank * (resolution / 2 / c->tile_world), b = a + resolution / 2 / c->tile_world;
+        std::vector<char> need((size_t)nb, 0);
+        auto mark = [&](int line) { need[(size_t)(((line % resolution) + resolution) % resolution) / 32] = 1; };
+        for (int x = a - 1; x < b; ++x) mark(x);
+        for (int x = resolution - b; x <= resolution - a; ++x) mark(x);
+        if (c->tile_rank == 0) { mark(resolution / 2 - 1); mark(resolution / 2); }
+        for (int i = 0; i < nb;) {
+            if (!need[(size_t)i]) { ++i; continue; }
+            int j = i;
+            while (j < nb && need[(size_t)j]) ++j;
+            c->band_blocks.push_back({i, j - i});
+            i = j;
+        }
+        hipMemAllocationProp prop;
+        std::memset(&prop, 0, sizeof prop);
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = device;
+        // Mappings in units of 2 MiB (the runtime reports a granularity of 4 KiB, but hipMemSetAccess refuses some ranges that are
+        // not aligned to the 2 MiB fragments it maps with -- measured): every band's byte range rounded outwards, overlaps merged,
+        // per array.
+        size_t gran = 0;
+        CTX_TRY(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+        if (gran == 0) return bail(hipErrorNotSupported, "no allocation granularity");
+        if (gran < ((size_t)2 << 20)) gran = (size_t)2 << 20;
+        hipMemAccessDesc acc;
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        c->h0T_reserved = (n2 * sizeof(c32) + gran - 1) / gran * gran;
+        c->omegaT_reserved = (n2 * sizeof(float) + gran - 1) / gran * gran;
+        CTX_TRY(hipMemAddressReserve((void**)&c->h0T, c->h0T_reserved, gran, nullptr, 0));
+        CTX_TRY(hipMemAddressReserve((void**)&c->omegaT, c->omegaT_reserved, gran, nullptr, 0));
+        for (int which = 0; which < 2; ++which) {
+            const size_t line_bytes = (size_t)resolution * (which ? sizeof(float) : sizeof(c32));
+            char* base = which ? (char*)c->omegaT : (char*)c->h0T;
+            size_t cur_lo = 0, cur_hi = 0;                          // the merged range being built
+            auto flush = [&]() -> hipError_t {                      // one allocation per 2 MiB piece (a larger mapping that is aligned to
+                for (size_t at = cur_lo; at < cur_hi; at += gran) { //  2 MiB only is refused by hipMemSetAccess as well -- measured)
+                    OceanContext::Mapping m;
+                    m.bytes = gran;
+                    m.va = base + at;
+                    hipError_t me = hipMemCreate(&m.handle, m.bytes, &prop, 0);
+                    if (me != hipSuccess) return me;
+                    me = hipMemMap(m.va, m.bytes, 0, m.handle, 0);
+                    if (me != hipSuccess) { (void)hipMemRelease(m.handle); return me; }
+                    c->band_maps.push_back(m);
+                    me = hipMemSetAccess(m.va, m.bytes, &acc, 1);
+                    if (me != hipSuccess) return me;
+                }
+                return hipSuccess;
+            };
+            for (const auto& br : c->band_blocks) {
+                const size_t lo = (size_t)br.first * 32 * line_bytes / gran * gran;
+                const size_t hi = ((size_t)(br.first + br.second) * 32 * line_bytes + gran - 1) / gran * gran;
+                if (lo <= cur_hi && cur_hi != cur_lo) { cur_hi = hi > cur_hi ? hi : cur_hi; continue; }
+                CTX_TRY(flush());
+                cur_lo = lo;
+                cur_hi = hi;
+            }
+            CTX_TRY(flush());
+        }
+    } else {
+        CTX_TRY(hipMalloc((void**)&c->h0T, (size_t)tiles * n2 * sizeof(c32)));      // (tile k's inputs at k * N * N elements)
+        CTX_TRY(hipMalloc((void**)&c->omegaT, (size_t)tiles * n2 * sizeof(float)));
+    }
     CTX_TRY(hipMalloc((void**)&c->nyq, 3 * (size_t)resolution * sizeof(c32)));
     if (framed) {
         CTX_TRY(hipMalloc((void**)&c->inter, 3 * c->lay_h.fs * sizeof(c32)));
@@ -657,6 +753,7 @@ int32_t upload_common(OceanContext* ctx, const float* h0_re_im, const float* ome
     if (!h0_re_im || !omega) return fail(ctx, OCEAN_E_INVALID_ARG, "NULL input");
     if (tile < 0 || tile >= ctx->tiles) return fail(ctx, OCEAN_E_INVALID_ARG, "no such tile in this context");
     if (f16 && ctx->tiles > 1) return fail(ctx, OCEAN_E_INVALID_ARG, "a context of several tiles stores fp32 spectra (one scale per context, not per tile)");
+    if (f16 && ctx->bands) return fail(ctx, OCEAN_E_INVALID_ARG, "a band-limited rank context stores the fp32 spectrum (its bands are mapped for 8-byte texels)");
     DeviceGuard guard(ctx->device);
     const size_t n = (size_t)ctx->n, n2 = n * n;
     HIP_TRY(ctx, sync_for_readback(ctx));                         // frames in flight still read the old inputs
@@ -684,15 +781,20 @@ int32_t upload_common(OceanContext* ctx, const float* h0_re_im, const float* ome
     }
     HIP_TRY(ctx, hipMemcpy(h0_nat, h0_re_im, n2 * sizeof(c32), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(om_nat, omega, n2 * sizeof(float), hipMemcpyHostToDevice));
-    const unsigned tiles = (unsigned)((n / 32) * (n / 32));
+    const int nb = (int)(n / 32);
     hipStream_t s = ctx->stream;
-    if (f16)
-        hipLaunchKernelGGL(k_quantise_f16_transpose, dim3(tiles), dim3(256), 0, s, reinterpret_cast<float2*>(h0_nat),
-                           reinterpret_cast<uint32_t*>(ctx->h0T), (int)n, std::ldexp(1.0f, scale_log2), std::ldexp(1.0f, -scale_log2));
-    else
-        hipLaunchKernelGGL(k_transpose<float2>, dim3(tiles), dim3(256), 0, s, reinterpret_cast<const float2*>(h0_nat),
-                           reinterpret_cast<float2*>(ctx->h0T) + (size_t)tile * n2, (int)n);
-    hipLaunchKernelGGL(k_transpose<float>, dim3(tiles), dim3(256), 0, s, (const float*)om_nat, ctx->omegaT + (size_t)tile * n2, (int)n);
+    // the whole arrays, or -- band-limited rank context -- the blocks of 32 lines that are backed by memory
+    std::vector<std::pair<int, int>> blocks = ctx->bands ? ctx->band_blocks : std::vector<std::pair<int, int>>{{0, nb}};
+    for (const auto& br : blocks) {
+        const unsigned tiles = (unsigned)(br.second * nb);
+        if (f16)
+            hipLaunchKernelGGL(k_quantise_f16_transpose, dim3(tiles), dim3(256), 0, s, reinterpret_cast<float2*>(h0_nat),
+                               reinterpret_cast<uint32_t*>(ctx->h0T), (int)n, std::ldexp(1.0f, scale_log2), std::ldexp(1.0f, -scale_log2));
+        else
+            hipLaunchKernelGGL(k_transpose<float2>, dim3(tiles), dim3(256), 0, s, reinterpret_cast<const float2*>(h0_nat),
+                               reinterpret_cast<float2*>(ctx->h0T) + (size_t)tile * n2, (int)n, br.first, br.second);
+        hipLaunchKernelGGL(k_transpose<float>, dim3(tiles), dim3(256), 0, s, (const float*)om_nat, ctx->omegaT + (size_t)tile * n2, (int)n, br.first, br.second);
+    }
     { const int32_t st = check_launch(ctx, "upload re-layout launch"); if (st != OCEAN_OK) return st; }
     HIP_TRY(ctx, hipStreamSynchronize(s));
     ctx->h0_f16 = f16;
@@ -1064,6 +1166,8 @@ static int32_t tile_check(OceanContext* ctx, int32_t rank, int32_t world, int32_
     if (ctx->quirks != OCEAN_QUIRKS_REFERENCE) return fail(ctx, OCEAN_E_STATE, "the fused kernels implement the reference quirks only (ocean_set_quirks)");
     bool ok = false;
     OCEAN_DISPATCH(ctx->n, ok = L::tile_supported(world, parts));
+    if (ctx->bands && (rank != ctx->tile_rank || world != ctx->tile_world))
+        return fail(ctx, OCEAN_E_INVALID_ARG, "this context holds the input lines of ONE rank of ONE world size (ocean_context_create_tile_rank): other ranks' lines are not mapped");
     if (!ok || rank < 0 || rank >= world || part < 0 || part >= parts)
         return fail(ctx, OCEAN_E_INVALID_ARG, "sharded tile: world and parts must be powers of two with at least 32 rows per rank and one "
                                               "column group per part, 0 <= rank < world, 0 <= part < parts");

@@ -54,14 +54,15 @@ k_pack_height32f(const float4* __restrict__ rgba, float4* __restrict__ height, s
 
 // ---- upload-time re-layout (once per ocean_upload_spectrum; the reference's staging copy, src/render.rs:872-924) --------
 // The fused path reads the static inputs transposed (h0T[x][y] = h0[y][x], omegaT likewise): 32 x 32 tiles through LDS,
-// both sides in contiguous pieces.  grid = (n / 32)^2, 256 threads.
+// both sides in contiguous pieces.  The source columns (= destination lines) [32 xt0, 32 (xt0 + xtiles)): the whole array with
+// xt0 = 0, xtiles = n / 32; a band of lines for a context that keeps only the lines its rank reads (ocean_context_create_tile_rank).
+// grid = xtiles * (n / 32), 256 threads.
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_transpose(const T* __restrict__ src, T* __restrict__ dst, int n) {
+k_transpose(const T* __restrict__ src, T* __restrict__ dst, int n, int xt0, int xtiles) {
     __shared__ T tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int tiles = n / 32;
-    const int x0 = ((int)blockIdx.x % tiles) * 32, y0 = ((int)blockIdx.x / tiles) * 32;
+    const int x0 = (xt0 + (int)blockIdx.x % xtiles) * 32, y0 = ((int)blockIdx.x / xtiles) * 32;
 #pragma unroll
     for (int k = 0; k < 4; ++k) tile[ty + 8 * k][tx] = src[(size_t)(y0 + ty + 8 * k) * n + x0 + tx];
     __syncthreads();

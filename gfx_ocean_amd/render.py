@@ -10,7 +10,7 @@ from ._lib import OCEAN_OK, OceanError, load_library
 from .fft import FIELD_ALL, FIELD_DX, FIELD_DY, FIELD_DZ, Fft
 
 QUIRK_Q1, QUIRK_Q2, QUIRKS_REFERENCE = 1, 2, 3      # include/ocean_hip.h OCEAN_QUIRK_*
-CTX_FUSED_ONLY, CTX_TILE_RANK = 1, 2   # include/ocean_hip.h OCEAN_CTX_*
+CTX_FUSED_ONLY, CTX_TILE_RANK, CTX_TILE_BANDS = 1, 2, 4   # include/ocean_hip.h OCEAN_CTX_*
 INTER_F32, INTER_BFP16 = 0, 1                         # include/ocean_hip.h OCEAN_INTER_*
 PACK_RGBA32F, PACK_RGB32F, PACK_HEIGHT32F = 0, 1, 2   # include/ocean_hip.h OCEAN_PACK_*
 PACK_BYTES_PER_TEXEL = {PACK_RGBA32F: 16, PACK_RGB32F: 12, PACK_HEIGHT32F: 4}
@@ -36,6 +36,19 @@ class OceanDevice:
         self.tiles = int(tiles)
         self.resolution = int(resolution)
         self.device_ordinal = int(device_ordinal)
+
+    @classmethod
+    def for_tile_rank(cls, resolution: int, rank: int, world: int, device_ordinal: int = 0):
+        """One rank of a sharded tile with only the input lines its pass 1 reads backed by memory (ocean_context_create_tile_rank:
+        12 / world instead of 12 B/texel; fp32 spectrum; ocean_tile_pass1/2 for THIS rank and world only)."""
+        lib = load_library()
+        ctx = ctypes.c_void_p()
+        st = lib.ocean_context_create_tile_rank(int(device_ordinal), int(resolution), int(rank), int(world), ctypes.byref(ctx))
+        if st != OCEAN_OK:
+            raise OceanError(st, (lib.ocean_last_error(None) or b"").decode())
+        self = cls.__new__(cls)
+        self._ctx, self.tiles, self.resolution, self.device_ordinal = ctx, 1, int(resolution), int(device_ordinal)
+        return self
 
     # -- plumbing -----------------------------------------------------------------------------
     def _check(self, status: int):

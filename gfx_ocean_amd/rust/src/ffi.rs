@@ -28,6 +28,7 @@ extern "C" {
     pub fn ocean_device_pci_bus_id(device: i32, out: *mut c_char, capacity: i32) -> i32;
     pub fn ocean_context_create(device: i32, resolution: i32, out: *mut *mut OceanContext) -> i32;
     pub fn ocean_context_create_ex(device: i32, resolution: i32, flags: u32, out: *mut *mut OceanContext) -> i32;
+    pub fn ocean_context_create_tile_rank(device: i32, resolution: i32, rank: i32, world: i32, out: *mut *mut OceanContext) -> i32;
     pub fn ocean_context_flags(ctx: *const OceanContext) -> u32;
     pub fn ocean_context_destroy(ctx: *mut OceanContext);
     pub fn ocean_last_error(ctx: *const OceanContext) -> *const c_char;

@@ -164,6 +164,18 @@ def fused_exchange_bytes_per_rank(n: int, world: int) -> int:
     return 3 * (n // 2 // world) * n * 8
 
 
+def tile_rank_lines(n: int, rank: int, world: int) -> np.ndarray:
+    """The lines of the transposed inputs (h0T[x][:], omegaT[x][:] = columns x of the natural arrays) that pass 1 of rank `rank`
+    of a fused sharded tile reads: its half-spectrum columns [a, b) need the "own-type" lines a-1 .. b-1 and the "mirror-type"
+    lines N-b .. N-a (mod N), and the workgroup that owns column 0 (rank 0) the Nyquist column's lines N/2-1 and N/2.
+    Sorted, unique.  2 (N / 2 world + 1) lines (+ 2 on rank 0) of N."""
+    a, b = rank * (n // 2 // world), (rank + 1) * (n // 2 // world)
+    lines = set(x % n for x in range(a - 1, b)) | set(x % n for x in range(n - b, n - a + 1))
+    if rank == 0:
+        lines |= {n // 2 - 1, n // 2}
+    return np.array(sorted(lines), dtype=np.int64)
+
+
 class HipTileBackend:
     """ocean_tile_pass1 / ocean_tile_pass2 on an ordinary OceanDevice that holds the whole tile's static inputs; torch
     supplies the exchange buffers, the streams and the collective.
@@ -173,12 +185,12 @@ class HipTileBackend:
     `all_to_all_single` only at world = 1; every rank's KERNELS of world 2 / 4 / 8 are checked on one device against the
     oracle (tests/test_sharded.py), the multi-rank driver under gloo on the CPU emulation backend.
 
-    The context is an OCEAN_CTX_TILE_RANK one: the whole tile's static inputs (12 B/texel, uploaded once: 3 GiB at
-    N = 16384) and nothing else -- no staged buffers, no intermediate, no map; the exchange buffers and the rank's rows are
-    torch's.  [Round 4 used a full context: 76-100 B/texel, 20 GiB per rank at 16384.]  Pass 1 of rank r reads only the
-    4/R of the transposed lines its column block touches (lines x, x-1, N-x, N-1-x for its x: two bands around r N/2R and
-    N - r N/2R, each with one line that wraps around the tile's edge on rank 0); keeping just those bands would need the
-    kernels' line indices rebased per band and is not done: 12 B/texel of a 288 GB device is not what limits a rank.
+    The context is a band-limited rank context (ocean_context_create_tile_rank): of the tile's static inputs only the lines
+    pass 1 of THIS rank reads are backed by memory -- lines x, x-1, N-x, N-1-x for its columns x: two bands of N/(2 world) + 1
+    lines (tile_rank_lines; + the Nyquist column's two on rank 0), 12/world B/texel, 0.4 GiB instead of 3 at N = 16384 and
+    world 8 -- and nothing else: no staged buffers, no intermediate, no map; the exchange buffers and the rank's rows are
+    torch's.  The two address ranges keep their full size (HIP virtual-memory API), so the kernels index absolute lines as in
+    every other context.  [Round 4 used a full context: 76-100 B/texel, 20 GiB per rank at 16384.]
 
     `trace` (a list, or None): when set, every stream-ordering step of a frame is appended to it -- what
     tests/test_sharded.py checks before the first multi-GPU run has to debug RCCL rather than bookkeeping."""
@@ -189,7 +201,10 @@ class HipTileBackend:
         self.torch = torch
         self.lib = load_library()
         from .render import CTX_TILE_RANK
-        self.dev = OceanDevice(n, device_ordinal, flags=CTX_TILE_RANK)
+        try:        # only the two bands of input lines this rank reads (12 / world B/texel); the whole tile's inputs if the runtime cannot map them sparsely
+            self.dev = OceanDevice.for_tile_rank(n, rank, world, device_ordinal)
+        except OceanError:
+            self.dev = OceanDevice(n, device_ordinal, flags=CTX_TILE_RANK)
         self.trace = None
         self.n, self.rank, self.world, self.rows, self.parts = n, rank, world, n // world, parts
         self.device = torch.device("cuda", device_ordinal)

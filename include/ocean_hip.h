@@ -43,7 +43,8 @@ extern "C" {
  * 4: + ocean_set_frame_normals, ocean_frame_normals, ocean_normals_device_ptr, ocean_frame_times_ex (the frame with the normal
  *    field as one workload); + ocean_context_create_tiles, ocean_context_tiles, ocean_upload_spectrum_tile, ocean_frame_tiles (K tiles per launch pair);
  *    + ocean_frame_batch, ocean_batch_device_ptr, ocean_read_batch_displacement, ocean_time_frame_batch
- *    (K time steps per launch pair); + ocean_context_create_ex, ocean_context_flags (contexts with only the fused path's buffers); + ocean_device_count,
+ *    (K time steps per launch pair); + ocean_context_create_ex, ocean_context_create_tile_rank, ocean_context_flags (contexts with only the buffers -- and, for a rank of a
+ *    sharded tile, only the input lines -- their path uses); + ocean_device_count,
  *    ocean_device_pci_bus_id; + ocean_bind_displacement_fd (the map in memory imported from another API's file descriptor);
  *    ocean_time_frame_batches also bounds frames_per_batch (<= 4096) */
 #define OCEAN_ABI_VERSION 4
@@ -101,10 +102,18 @@ int32_t ocean_context_create(int32_t device_ordinal, int32_t resolution, OceanCo
  *                         through a staging buffer that lives for the call.
  *   OCEAN_CTX_TILE_RANK   one rank of a tile sharded over several GPUs (implies FUSED_ONLY): the static inputs only, 12 B/texel --
  *                         the intermediate and the rows live in the caller's exchange buffers; everything but the upload and
- *                         ocean_tile_pass1/2 returns OCEAN_E_STATE. */
+ *                         ocean_tile_pass1/2 returns OCEAN_E_STATE.
+ *   OCEAN_CTX_TILE_BANDS  (reported by ocean_context_flags, set by ocean_context_create_tile_rank only) a TILE_RANK context of ONE
+ *                         rank of ONE world size that backs only the lines of the transposed inputs that rank's pass 1 reads -- two
+ *                         bands of N/(2 world) + 1 lines each (+ the Nyquist column's two on rank 0) out of N: 12/world B/texel
+ *                         instead of 12 (0.4 instead of 3 GiB per rank at N = 16384, world 8).  The ranges keep their full-size
+ *                         addresses (HIP virtual-memory API), so the kernels index absolute lines as always; fp32 spectrum only;
+ *                         ocean_tile_pass1 with another rank or world: OCEAN_E_INVALID_ARG. */
 #define OCEAN_CTX_FUSED_ONLY 1u
 #define OCEAN_CTX_TILE_RANK 2u
+#define OCEAN_CTX_TILE_BANDS 4u
 int32_t ocean_context_create_ex(int32_t device_ordinal, int32_t resolution, uint32_t flags, OceanContext** out_ctx);
+int32_t ocean_context_create_tile_rank(int32_t device_ordinal, int32_t resolution, int32_t rank, int32_t world, OceanContext** out_ctx);
 uint32_t ocean_context_flags(const OceanContext* ctx);
 void ocean_context_destroy(OceanContext* ctx);            /* NULL-safe; src/render.rs:1383-1438 */
 const char* ocean_last_error(const OceanContext* ctx);    /* ctx may be NULL: last error of a failed create */

@@ -411,6 +411,76 @@ def test_gpu_fused_shard_16384_every_rank_against_the_c_oracle():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,world", [(256, 2), (512, 4), (1024, 2), (2048, 8), (4096, 4), (8192, 8)])
+def test_gpu_a_rank_reads_only_its_two_bands_of_the_static_inputs(n, world):
+    """What sharded.tile_rank_lines says a rank's pass 1 reads of h0T / omegaT is ALL it reads: with every other line of the
+    inputs poisoned (NaN), every rank's send buffer is bit-identical to the one computed from the clean inputs -- every loader
+    (registers at N <= 1024, the LDS-DMA ring above, the split kernels at 8192), the Nyquist column included."""
+    import ctypes
+    from hipmem import DeviceBuffer
+    from gfx_ocean_amd._lib import PropagateLocalsC, load_library
+    lib = load_library()
+    h0, om = g.synth.make_inputs(n, seed=61)
+    loc = PropagateLocalsC(1.75, int(n), 1000.0)
+    nbytes = sharded.fused_exchange_bytes_per_rank(n, world)
+
+    def send_buffers(poison):
+        out = []
+        for r in range(world):
+            hp, op = h0, om
+            if poison:
+                keep = np.zeros(n, bool)
+                keep[sharded.tile_rank_lines(n, r, world)] = True
+                hp, op = h0.copy(), om.copy()
+                hp[:, ~keep] = np.nan + 1j * np.nan               # line x of the transposed inputs = column x of the natural ones
+                op[:, ~keep] = np.nan
+            d = g.OceanDevice(n, flags=g.CTX_TILE_RANK)
+            buf = DeviceBuffer(nbytes)
+            try:
+                d.upload_spectrum(hp, op)
+                buf.fill(0)
+                d._check(lib.ocean_tile_pass1(d._ctx, ctypes.byref(loc), r, world, 0, 1, buf.ptr, None))
+                d.sync()
+                out.append(buf.to_host(np.uint32))
+            finally:
+                buf.free()
+                d.destroy()
+        return out
+
+    clean, poisoned = send_buffers(False), send_buffers(True)
+    for r in range(world):
+        assert not np.isnan(clean[r].view(np.float32)).any()
+        assert np.array_equal(clean[r], poisoned[r]), (n, world, r)
+    assert len(sharded.tile_rank_lines(n, 1 % world, world)) <= 2 * (n // 2 // world + 1)
+    # ... and a band-limited rank context (ocean_context_create_tile_rank) backs just those lines -- rounded to blocks of 32 -- with
+    # memory: the same send buffer, a footprint of ~12 / world B/texel, other ranks refused
+    import hipmem
+    for r in sorted({0, world - 1, world // 2}):
+        before = hipmem.free_bytes()
+        d = g.OceanDevice.for_tile_rank(n, r, world)
+        buf = DeviceBuffer(nbytes)
+        try:
+            assert lib.ocean_context_flags(d._ctx) == (g.CTX_FUSED_ONLY | g.CTX_TILE_RANK | g.CTX_TILE_BANDS)
+            used = before - hipmem.free_bytes() - nbytes
+            blocks = len(set(int(x) // 32 for x in sharded.tile_rank_lines(n, r, world)))
+            assert used <= blocks * 32 * n * 12 + (24 << 20), (used, blocks)      # (+ rounding of every band to 2 MiB mappings)
+            if n >= 2048 and world >= 4:
+                assert used < 0.6 * 12 * n * n                    # far from the whole tile's inputs
+            d.upload_spectrum(h0, om)
+            buf.fill(0)
+            d._check(lib.ocean_tile_pass1(d._ctx, ctypes.byref(loc), r, world, 0, 1, buf.ptr, None))
+            d.sync()
+            assert np.array_equal(buf.to_host(np.uint32), clean[r]), (n, world, r)
+            assert lib.ocean_tile_pass1(d._ctx, ctypes.byref(loc), (r + 1) % world, world, 0, 1, buf.ptr, None) == -1
+            with pytest.raises(g.OceanError):
+                d.upload_spectrum(h0, om, spectrum_fp16=True)
+        finally:
+            buf.free()
+            d.destroy()
+        assert abs(hipmem.free_bytes() - before) <= (64 << 20)    # and everything is unmapped and released again
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,world,parts", [(2048, 4, 1), (2048, 2, 4), (4096, 8, 2), (512, 2, 2), (16384, 2, 2)])
 def test_gpu_fused_shard_equals_the_fused_frame_bit_for_bit(n, world, parts):
     """Sharding -- and cutting the exchange into pipelined parts -- must not change a single bit: the same kernels on
@@ -442,7 +512,7 @@ dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.de
 h0, om = g.synth.make_inputs(n, seed=9)
 for parts in (1, 2, 4):                    # 2, 4: the pipelined exchange -- that many all-to-alls on the communication stream
     be = sharded.HipTileBackend(n, 0, 1, parts=parts)
-    assert g.load_library().ocean_context_flags(be.dev._ctx) == (g.CTX_FUSED_ONLY | g.CTX_TILE_RANK)   # static inputs only
+    assert g.load_library().ocean_context_flags(be.dev._ctx) == (g.CTX_FUSED_ONLY | g.CTX_TILE_RANK | g.CTX_TILE_BANDS)   # this rank's input lines only
     tile = sharded.FusedShardedTile(be, dist)
     tile.upload(h0, om)
     for rep in range(3):                   # consecutive frames reuse the exchange buffers behind the right events
