@@ -111,6 +111,9 @@ struct OceanContext {
     int32_t batch_cap = 0;
     float4* batch_out = nullptr;
     int32_t batch_out_cap = 0;
+    float* batch_plane = nullptr;       // ... and with the normal field switched on: K planes and K normal fields
+    float4* batch_normals = nullptr;
+    int32_t batch_normals_cap = 0;
     float4* positions = nullptr;  // ocean_positions: verts x verts float4, (re)allocated on demand
     int32_t position_verts = 0;
     unsigned long long* checksum_acc = nullptr;   // ocean_checksum_displacement
@@ -294,8 +297,8 @@ template <int N> struct Launch {
     // which also store the source channel as the dense plane k_normals_plane reads.  `count` > 1: a batch (pass1_on).
     static void pass2_on(OceanContext* c, const c32* inter, float4* out, hipStream_t s, Timing t, FrameBatch batch = FrameBatch(), int count = 1) {
         const c32* tw = c->tw;
-        const bool plane = c->frame_normals >= 0 && count == 1;
-        float* pl = c->plane;
+        const bool plane = c->frame_normals >= 0;
+        float* pl = (count > 1) ? c->batch_plane : c->plane;        // a batch: one plane per frame (batch_reserve)
         const int ch = c->frame_normals;
         if constexpr (REAL2) {
             const dim3 g(N), b(H::real_threads2);
@@ -515,7 +518,7 @@ void free_all(OceanContext* c) {
     auto f = [](void* p) { if (p) (void)hipFree(p); };
     f(c->h0); f(c->omega); f(c->field[0]); f(c->field[1]); f(c->field[2]);
     f(c->cfield[0]); f(c->cfield[1]); f(c->cfield[2]); f(c->field_alt[0]); f(c->field_alt[1]); f(c->field_alt[2]);
-    f(c->h0T); f(c->omegaT); f(c->inter); f(c->nyq); f(c->tw); f(c->out_own); f(c->normals); f(c->plane); f(c->batch_inter); f(c->batch_nyq); f(c->batch_out); f(c->positions); f(c->checksum_acc); f(c->inter_scale);
+    f(c->h0T); f(c->omegaT); f(c->inter); f(c->nyq); f(c->tw); f(c->out_own); f(c->normals); f(c->plane); f(c->batch_inter); f(c->batch_nyq); f(c->batch_out); f(c->batch_plane); f(c->batch_normals); f(c->positions); f(c->checksum_acc); f(c->inter_scale);
     if (c->ev_a) (void)hipEventDestroy(c->ev_a);
     if (c->ev_b) (void)hipEventDestroy(c->ev_b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1208,7 +1211,11 @@ int32_t batch_check(OceanContext* ctx, int32_t count) {
     if (count < 1 || count > OCEAN_BATCH_MAX) return fail(ctx, OCEAN_E_INVALID_ARG, "count must be in [1, OCEAN_BATCH_MAX]");
     if (!ctx->uploaded) return fail(ctx, OCEAN_E_STATE, "ocean_upload_spectrum has not been called");
     if (ctx->quirks != OCEAN_QUIRKS_REFERENCE) return fail(ctx, OCEAN_E_STATE, "the fused kernels implement the reference quirks only (ocean_set_quirks)");
-    if (ctx->frame_normals >= 0) return fail(ctx, OCEAN_E_STATE, "ocean_frame_batch does not carry the normal field (ocean_set_frame_normals(ctx, -1) first)");
+    if (ctx->frame_normals >= 0) {                                  // the batch carries the normal field at the sizes whose batches are one launch pair
+        bool batched = false;
+        OCEAN_DISPATCH(ctx->n, batched = L::BATCHED);
+        if (!batched) return fail(ctx, OCEAN_E_STATE, "above N = 1024 a batch is K ordinary frames: call ocean_frame per frame for the normal field (or ocean_set_frame_normals(ctx, -1))");
+    }
     return OCEAN_OK;
 }
 // the K intermediates / Nyquist scratches (and, without a caller buffer, the K maps) of a batch
@@ -1224,6 +1231,15 @@ int32_t batch_reserve(OceanContext* ctx, int32_t count, bool own_out) {
         HIP_TRY(ctx, hipMalloc((void**)&ctx->batch_inter, (size_t)count * 3 * ctx->lay_h.fs * sizeof(c32)));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->batch_nyq, (size_t)count * 3 * ctx->n * sizeof(c32)));
         ctx->batch_cap = count;
+    }
+    if (batched && ctx->frame_normals >= 0 && ctx->batch_normals_cap < count) {
+        HIP_TRY(ctx, sync_for_readback(ctx));
+        if (ctx->batch_plane) (void)hipFree(ctx->batch_plane);
+        if (ctx->batch_normals) (void)hipFree(ctx->batch_normals);
+        ctx->batch_plane = nullptr; ctx->batch_normals = nullptr; ctx->batch_normals_cap = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->batch_plane, (size_t)count * n2 * sizeof(float)));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->batch_normals, (size_t)count * n2 * sizeof(float4)));
+        ctx->batch_normals_cap = count;
     }
     if (own_out && ctx->batch_out_cap < count) {
         HIP_TRY(ctx, sync_for_readback(ctx));
@@ -1251,6 +1267,15 @@ void launch_batch(OceanContext* c, float t0, float dt, int32_t count, float4* ou
             L::pass1_on(c, t0, c->default_domain, c->batch_inter, c->lay_h, L::H::half_grid1, 0, s, Timing(), c->batch_nyq, b, count);
             L::pass2_on(c, c->batch_inter, out, s, Timing(), b, count);
         });
+        if (c->frame_normals >= 0) {                                // K normal fields from the K planes, one launch (blockIdx.y = frame)
+            const int rows = normals_plane_rows(c->n);
+            const dim3 grid((unsigned)((c->n / 256) * (c->n / rows) / 4), (unsigned)count), blk(256);
+            const float* pl = c->batch_plane;
+            switch (rows) {
+                case 2: hipLaunchKernelGGL(k_normals_plane<2>, grid, blk, 0, s, pl, c->batch_normals, c->n); break;
+                default: hipLaunchKernelGGL(k_normals_plane<4>, grid, blk, 0, s, pl, c->batch_normals, c->n); break;   // (N = 1024; batches exist up to there)
+            }
+        }
         return;
     }
     for (int i = 0; i < count; ++i)                                 // N > 1024: one frame fills the chip; the same frames, one launch pair each
@@ -1287,6 +1312,17 @@ int32_t ocean_frame_tiles(OceanContext* ctx, float time, void* out_base_device, 
     return check_launch(ctx, "ocean_frame_tiles launch");
 }
 void* ocean_batch_device_ptr(OceanContext* ctx) { return valid(ctx) ? (void*)ctx->batch_out : nullptr; }
+void* ocean_batch_normals_device_ptr(OceanContext* ctx) { return valid(ctx) ? (void*)ctx->batch_normals : nullptr; }
+int32_t ocean_read_batch_normals(OceanContext* ctx, int32_t index, float* host_xyz0) {
+    if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    if (!host_xyz0) return fail(ctx, OCEAN_E_INVALID_ARG, "NULL output");
+    if (!ctx->batch_normals || index < 0 || index >= ctx->batch_normals_cap) return fail(ctx, OCEAN_E_STATE, "no normal field with this index (a batch with ocean_set_frame_normals on)");
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(ctx, sync_for_readback(ctx));
+    const size_t n2 = (size_t)ctx->n * ctx->n;
+    HIP_TRY(ctx, hipMemcpy(host_xyz0, ctx->batch_normals + (size_t)index * n2, n2 * sizeof(float4), hipMemcpyDeviceToHost));
+    return OCEAN_OK;
+}
 int32_t ocean_read_batch_displacement(OceanContext* ctx, int32_t index, float* host_rgba) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
     if (!host_rgba) return fail(ctx, OCEAN_E_INVALID_ARG, "NULL output");

@@ -816,6 +816,7 @@ k_half_pass2(const c32* __restrict__ inter, float4* __restrict__ out, const c32*
         const uint32_t fi = blockIdx.y;
         inter += (size_t)fi * batch.inter_stride;
         out += (size_t)fi * batch.out_stride;
+        if constexpr (PLANE) plane += (size_t)fi * ((size_t)N * N);    // (one plane per frame of the batch)
     }
     constexpr int T = N / E;
     constexpr int GT = T * R2;                                     // threads of one transform group (= the workgroup without PPAR)

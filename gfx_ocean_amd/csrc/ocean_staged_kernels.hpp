@@ -182,6 +182,10 @@ constexpr int normals_plane_rows(int n) { return (n >= 4096) ? 16 : ((n >= 2048)
 template <int ROWS>
 __global__ void __launch_bounds__(256)
 k_normals_plane(const float* __restrict__ plane, float4* __restrict__ normals, int n) {
+    // (a batched launch -- ocean_frame_batch / ocean_frame_tiles with the normal field, N <= 1024: blockIdx.y = frame, planes and
+    //  fields N * N elements apart; gridDim.y = 1 and blockIdx.y = 0 otherwise)
+    plane += (size_t)blockIdx.y * (size_t)n * (size_t)n;
+    normals += (size_t)blockIdx.y * (size_t)n * (size_t)n;
     const uint32_t un = (uint32_t)n, mask = un - 1u, segs = un / 256u;
     const uint32_t gw = (uint32_t)xcd_contiguous((int)blockIdx.x, (int)gridDim.x) * 4u + (threadIdx.x >> 6);   // wave of the grid
     const uint32_t x0 = (gw % segs) * 256u + (threadIdx.x & 63u), y0 = (gw / segs) * ROWS;

@@ -146,6 +146,13 @@ class OceanDevice:
         self._check(load_library().ocean_read_batch_displacement(self._ctx, int(index), out.ctypes.data))
         return out
 
+    def read_batch_normals(self, index: int) -> np.ndarray:
+        """The normal field of frame / tile `index` of the last batch (set_frame_normals on; N <= 1024)."""
+        n = self.resolution
+        out = np.empty((n, n, 4), dtype=np.float32)
+        self._check(load_library().ocean_read_batch_normals(self._ctx, int(index), out.ctypes.data))
+        return out
+
     def time_frame_batch(self, launches: int, count: int, t0: float = 0.0, dt: float = 1.0 / 60.0) -> float:
         """Milliseconds of `launches` back-to-back ocean_frame_batch calls of `count` frames each (ocean_time_frame_batch)."""
         ms = ctypes.c_float()

@@ -56,6 +56,8 @@ extern "C" {
     pub fn ocean_frame_batch(ctx: *mut OceanContext, t0: f32, dt: f32, count: i32, out_base_device: *mut c_void, out_stride_bytes: i64,
                              stream: *mut c_void) -> i32;
     pub fn ocean_batch_device_ptr(ctx: *mut OceanContext) -> *mut c_void;
+    pub fn ocean_batch_normals_device_ptr(ctx: *mut OceanContext) -> *mut c_void;
+    pub fn ocean_read_batch_normals(ctx: *mut OceanContext, index: i32, host_xyz0: *mut f32) -> i32;
     pub fn ocean_read_batch_displacement(ctx: *mut OceanContext, index: i32, host_rgba: *mut f32) -> i32;
     pub fn ocean_time_frame_batch(ctx: *mut OceanContext, launches: i32, count: i32, t0: f32, dt: f32, out_ms: *mut f32) -> i32;
     pub fn ocean_normals(ctx: *mut OceanContext, source_channel: i32, stream: *mut c_void) -> i32;

@@ -42,7 +42,7 @@ extern "C" {
  * 3: + ocean_frame_times, ocean_time_frame_batches; ocean_sync and ocean_context_destroy honour caller streams like the readbacks
  * 4: + ocean_set_frame_normals, ocean_frame_normals, ocean_normals_device_ptr, ocean_frame_times_ex (the frame with the normal
  *    field as one workload); + ocean_context_create_tiles, ocean_context_tiles, ocean_upload_spectrum_tile, ocean_frame_tiles (K tiles per launch pair);
- *    + ocean_frame_batch, ocean_batch_device_ptr, ocean_read_batch_displacement, ocean_time_frame_batch
+ *    + ocean_frame_batch, ocean_batch_device_ptr, ocean_batch_normals_device_ptr, ocean_read_batch_normals, ocean_read_batch_displacement, ocean_time_frame_batch
  *    (K time steps per launch pair); + ocean_context_create_ex, ocean_context_create_tile_rank, ocean_context_flags (contexts with only the buffers -- and, for a rank of a
  *    sharded tile, only the input lines -- their path uses); + ocean_device_count,
  *    ocean_device_pci_bus_id; + ocean_bind_displacement_fd (the map in memory imported from another API's file descriptor);
@@ -198,7 +198,7 @@ int32_t ocean_intermediate(const OceanContext* ctx);
  * frames are ONE launch pair (blockIdx.y = frame; K intermediates, allocated on demand) -- the reference keeps 3 frames in
  * flight by command-buffer rotation (src/lib.rs:86,150) and draws 4 instances of one map (src/render.rs:540-551,1360); at
  * N >= 2048 a frame fills the chip and the call is K ordinary launch pairs.  Every map is bit-identical to ocean_frame at the
- * same time.  Reference quirks only; without the normal field (OCEAN_E_STATE otherwise).  ocean_frame's own map is untouched. */
+ * same time.  Reference quirks only.  ocean_frame's own map is untouched. */
 #define OCEAN_BATCH_MAX 64
 /* ... and K independent TILES per launch pair (N <= 1024, fp32 spectra): ocean_context_create_tiles makes a fused-only context
  * that holds K tiles' static inputs (ocean_upload_spectrum_tile, k = 0 .. K-1; ocean_upload_spectrum = tile 0), and
@@ -213,6 +213,11 @@ int32_t ocean_frame_batch(OceanContext* ctx, float t0, float dt, int32_t count, 
                           void* stream);
 void* ocean_batch_device_ptr(OceanContext* ctx);                    /* library-owned maps of the last NULL-buffer batch */
 int32_t ocean_read_batch_displacement(OceanContext* ctx, int32_t index, float* host_rgba /* N*N*4 */);
+/* With the normal field switched on (ocean_set_frame_normals) a batch of N <= 1024 -- time steps or tiles -- carries it: K planes, and
+ * ONE more launch for the K fields (library-owned, N*N*16 bytes apart; bit-identical to the single frame's).  Above 1024:
+ * OCEAN_E_STATE (a batch there is K ordinary frames: call ocean_frame). */
+void* ocean_batch_normals_device_ptr(OceanContext* ctx);
+int32_t ocean_read_batch_normals(OceanContext* ctx, int32_t index, float* host_xyz0 /* N*N*4 */);
 
 /* the reference's normal field (shader/ocean.frag:50-66: finite differences of the
  * displacement map with Tile wrap, height_scale 180) as a compute pass over the current

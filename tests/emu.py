@@ -181,7 +181,7 @@ def frame_half(h0, omega, time, L=1000.0, layout="p2", return_inter=False, spect
     scales = np.full(3 * (n // 64) * (n // 4), np.nan, np.float32) if inter16 else None
     psel = (23 if inter16 else (21 if P == 1 else 22)) if split else int(P)
     # pass 2 runs as its PLANE instance (the frame with the normal field): the source channel as a dense fp32 plane
-    plane = np.full((n, n), np.nan, np.float32)
+    plane = np.full((count, n, n) if batch else (n, n), np.nan, np.float32)       # (a batch: one plane per frame)
     lib().emu_set_plane.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib().emu_set_plane(_p(plane), int(plane_channel or 0))
     assert lib().emu_frame_half(n, psel, _p(h0T), int(spectrum_fp16), descale, _p(omT), _p(inter),

@@ -139,8 +139,8 @@ def test_emu_frame_batch(n, ref_inputs, ref_inputs_256):
     intermediate, Nyquist scratch and map -- each bit-identical to the plain frame at t0 + dt * i (fp32, no FMA)."""
     h0, om = ref_inputs_256 if n == 256 else ref_inputs
     t0, dt, K = np.float32(1.5), np.float32(1.0 / 60.0), 3
-    outs = emu.frame_half(h0, om, float(t0), batch=(K, float(dt)))
-    assert outs.shape == (K, n, n, 4)
+    outs, planes = emu.frame_half(h0, om, float(t0), batch=(K, float(dt)), plane_channel=1)
+    assert outs.shape == (K, n, n, 4) and np.array_equal(planes, outs[..., 1])      # one source-channel plane per frame of the batch
     for i in range(K):
         ti = np.float32(t0 + np.float32(dt * np.float32(i)))
         assert np.array_equal(outs[i], emu.frame_half(h0, om, float(ti))), i

@@ -481,8 +481,19 @@ def test_frame_batch_is_bit_identical_to_single_frames(n, count, own, fp16):
         with pytest.raises(g.OceanError):
             d.frame_batch(0.0, 0.1, 65)
         d.set_frame_normals(0)
-        with pytest.raises(g.OceanError):
-            d.frame_batch(0.0, 0.1, 2)
+        if n > 1024:                                              # above 1024 a batch is K ordinary frames: the field comes from ocean_frame
+            with pytest.raises(g.OceanError):
+                d.frame_batch(0.0, 0.1, 2)
+        else:                                                     # the batch carries the normal field: K planes, one more launch
+            k = min(count, 4)
+            d.frame_batch(float(t0), float(dt), k)
+            fields = [d.read_batch_normals(i) for i in range(k)]
+            again = [d.read_batch_displacement(i) for i in range(k)]
+            for i in range(k):
+                ti = np.float32(t0 + np.float32(dt * np.float32(i)))
+                d.frame(float(ti))
+                assert np.array_equal(fields[i], d.read_normals()) and np.array_equal(again[i], d.read_displacement()), (n, i)
+            assert not np.array_equal(fields[0], fields[1])
     finally:
         if buf is not None:
             buf.free()
@@ -559,6 +570,11 @@ def test_frame_tiles_is_bit_identical_to_one_context_per_tile(n, tiles):
         d.upload_spectrum(*inputs[-1], tile=tiles - 1)
         d.frame_tiles(2.25)
         maps = [d.read_batch_displacement(k) for k in range(tiles)]
+        d.set_frame_normals(1)                                    # ... and with the normal field: one field per tile
+        d.frame_tiles(2.25)
+        tile_normals = [d.read_batch_normals(k) for k in range(tiles)]
+        assert all(np.array_equal(d.read_batch_displacement(k), maps[k]) for k in range(tiles))
+        d.set_frame_normals(None)
         for t_ in (0.5, 2.25):                                    # consecutive launches reuse the intermediates
             d.frame_tiles(t_)
         again = [d.read_batch_displacement(k) for k in range(tiles)]
@@ -573,9 +589,11 @@ def test_frame_tiles_is_bit_identical_to_one_context_per_tile(n, tiles):
             one.upload_spectrum(h0, om)
             one.frame(2.25)
             want = one.read_displacement()
+            want_normals = one.normals(1)
         finally:
             one.destroy()
         assert np.array_equal(maps[k], want) and np.array_equal(again[k], want), (n, k)
+        assert np.array_equal(tile_normals[k], want_normals), (n, k)
     assert not np.array_equal(maps[0], maps[1])
     with pytest.raises(g.OceanError):
         g.OceanDevice(2048, tiles=2)                              # above 1024 one tile fills the chip: one context per tile
