@@ -11,17 +11,18 @@ B="python $GRAFT_REPO_ROOT/bench.py"
 echo "== bench (driver flags)"; timeout 900 $B --gpus 1 --steps 20 --warmup 5 2>$O/bench.err | tee $O/bench.json | cut -c1-260
 echo "== bench config 5"; timeout 900 $B --n 8192 --spectrum f16 --steps 20 --warmup 5 2>/dev/null | tee $O/bench_n8192_f16.json | cut -c1-260
 echo "== bench config 3 with / without the normal field"
-timeout 600 $B --n 2048 --normals disp_x --steps 200 --warmup 20 2>/dev/null | tee $O/bench_n2048_normals.json | cut -c1-260
-timeout 600 $B --no-cpu-baseline --n 2048 --normals height --steps 200 --warmup 20 2>/dev/null | tee $O/bench_n2048_normals_height.json | cut -c1-260
-timeout 600 $B --no-cpu-baseline --n 2048 --steps 200 --warmup 20 2>/dev/null | tee $O/bench_n2048.json | cut -c1-260
+timeout 600 $B --n 2048 --normals disp_x 2>/dev/null | tee $O/bench_n2048_normals.json | cut -c1-260
+timeout 600 $B --no-cpu-baseline --n 2048 --normals height 2>/dev/null | tee $O/bench_n2048_normals_height.json | cut -c1-260
+timeout 600 $B --no-cpu-baseline --n 2048 2>/dev/null | tee $O/bench_n2048.json | cut -c1-260
 echo "== bench config 2 plain / batched"
-timeout 600 $B --n 512 --steps 200 --warmup 20 2>/dev/null | tee $O/bench_n512.json | cut -c1-260
+timeout 600 $B --n 512 2>/dev/null | tee $O/bench_n512.json | cut -c1-260
 for k in 8 16 64; do timeout 600 $B --no-cpu-baseline --n 512 --batch $k --steps 8192 --warmup 128 2>/dev/null | tee $O/bench_n512_batch$k.json | cut -c1-260; done
 timeout 600 $B --no-cpu-baseline --n 512 --batch 8 --batch-tiles --steps 8192 --warmup 128 2>/dev/null | tee $O/bench_n512_batch8_tiles.json | cut -c1-260
+timeout 600 $B --no-cpu-baseline --n 512 --batch 8 --normals disp_x --steps 8192 --warmup 128 2>/dev/null | tee $O/bench_n512_batch8_normals.json | cut -c1-260
 timeout 600 $B --no-cpu-baseline --n 256 --batch 64 --steps 8192 --warmup 128 2>/dev/null | tee $O/bench_n256_batch64.json | cut -c1-260
 timeout 600 $B --no-cpu-baseline --n 1024 --batch 16 --steps 4096 --warmup 64 2>/dev/null | tee $O/bench_n1024_batch16.json | cut -c1-260
 echo "== bench 4096 with normals, 8192, 16384"
-timeout 600 $B --no-cpu-baseline --n 4096 --normals disp_x --steps 100 --warmup 10 2>/dev/null | tee $O/bench_n4096_normals.json | cut -c1-260
+timeout 600 $B --no-cpu-baseline --n 4096 --normals disp_x 2>/dev/null | tee $O/bench_n4096_normals.json | cut -c1-260
 for n in 8192 16384; do timeout 900 $B --no-cpu-baseline --n $n --steps 20 --warmup 5 --ramp-frames 20 --distribution-frames 50 2>/dev/null | tee $O/bench_n$n.json | cut -c1-260; done
 cd /tmp
 run_prof() {   # name, N, traffic flags, then the command
