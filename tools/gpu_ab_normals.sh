@@ -1,4 +1,5 @@
 #!/bin/bash
+# The same A/B for the frame with the normal field (tools/normals_time.py).   SIZES="2048 4096" tools/gpu_ab_normals.sh <tag>
 set -u
 exec < /dev/null
 TAG=${1:-r5e}; O=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $O

@@ -1,4 +1,5 @@
 #!/bin/bash
+# The same A/B for the staged 8-dispatch frame (ocean_profile_staged, column passes listed).   N=8192 tools/gpu_ab_staged.sh <tag>
 set -u
 exec < /dev/null
 TAG=${1:-r5k}; O=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $O

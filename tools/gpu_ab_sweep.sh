@@ -1,4 +1,6 @@
 #!/bin/bash
+# A/B of the library against every build in gfx_ocean_amd/variants/ (tools/build_variants.py): per-kernel sweep, three interleaved
+# repetitions.   SIZES="2048 8192" tools/gpu_ab_sweep.sh <tag>
 set -u
 exec < /dev/null
 TAG=${1:-r5l}; O=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $O

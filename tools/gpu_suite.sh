@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, run D: full GPU suite (durations), bench headline + config lines
+# GPU suite of a round: pytest -m gpu (durations), smoke(), the bench line with the driver's flags.   tools/gpu_suite.sh <tag>
 set -u
 exec < /dev/null
 TAG=${1:-r5d}; O=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $O
