@@ -423,7 +423,12 @@ def main():
                     "region that yields the per-kernel durations (it runs max(steps, distribution-frames, this) frames)")
     ap.add_argument("--distribution-frames", type=int, default=200,
                     help="frames of the untimed loop behind the timed region that yields config.frame_ms_{median,p10,p90} (SURVEY 8d)")
-    ap.add_argument("--ramp-frames", type=int, default=100, help="untimed frames before anything is measured (GPU clock ramp)")
+    ap.add_argument("--ramp-frames", type=int, default=None,
+                    help="untimed frames before anything is measured (GPU clock ramp); default: at least 100 and at least --ramp-ms of frames")
+    ap.add_argument("--ramp-ms", type=float, default=50.0,
+                    help="the clock ramp as a duration: the part needs tens of milliseconds of work to reach its running clocks, which 100 "
+                         "frames are at N = 4096 (18 ms) but not at 2048 (6 ms: the 200 timed steps behind them measured 61.1 us per frame "
+                         "against 59.9 behind 60 ms of ramp, r05_run27)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launch: seconds before the ranks are killed")
     ap.add_argument("--no-pin", action="store_true", help="do not pin the rank to the cpus local to its GPU's NUMA node")
     ap.add_argument("--plumbing", action="store_true",
@@ -555,6 +560,9 @@ def main():
     # A cold GPU needs tens of milliseconds of work to reach its running clocks (measured on MI355X: the first ~25
     # frames of a run are ~10 % slower, and with W = 5 the timed K = 20 steps would be measured on the ramp).  So,
     # untimed and BEFORE the timed region: `--ramp-frames` frames, then the W warmup steps.
+    if args.ramp_frames is None:                                    # ... as a duration (--ramp-ms): 20 probe frames size it
+        probe_ms = dev.time_frames(20, t0=0.0, dt=1.0 / 60.0) / 20.0
+        args.ramp_frames = max(100, min(20000, int(args.ramp_ms / max(probe_ms, 1e-4))))
     dev.time_frames(args.ramp_frames, t0=0.0, dt=1.0 / 60.0)        # clock ramp, untimed (see above)
     batched = max(1, args.batch)
     if batched > 1 and with_normals and n > 1024:
