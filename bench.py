@@ -389,8 +389,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None,
-                    help="timed frames K (default: 200 at N >= 4096, 1000 at 2048, 4000 below -- a timed region of >= ~40 ms, so that the "
-                         "one synchronisation that ends it, ~0.3-0.5 ms of wall clock, is a percent of it and not a tenth)")
+                    help="timed frames K (default: 200 at N >= 4096, 1000 at 2048, 4000 below: a timed region of >= ~40 ms, against which "
+                         "the launch latency of its first frame and the wake-up behind its last -- 30-130 us together -- are nothing)")
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--n", type=int, default=4096, help="tile edge (power of two, 256..16384)")
     ap.add_argument("--spectrum", choices=("f32", "f16"), default="f32",
@@ -436,6 +436,8 @@ def main():
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 200 if args.n >= 4096 else (1000 if args.n >= 2048 else 4000)
+    if args.batch_tiles and (args.batch < 2 or args.spectrum != "f32" or args.intermediate != "f32"):
+        ap.error("--batch-tiles goes with --batch K >= 2 and the fp32 spectrum (a context of several tiles stores fp32 spectra)")
 
     # More ranks than visible devices: one JSON error line within seconds instead of a rendezvous that times out.  In the
     # process that only launches the ranks, and in a single-GPU run, the count comes from the library's own HIP runtime (no
