@@ -411,7 +411,7 @@ def test_gpu_fused_shard_16384_every_rank_against_the_c_oracle():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,world", [(256, 2), (512, 4), (1024, 2), (2048, 8), (4096, 4), (8192, 8)])
+@pytest.mark.parametrize("n,world", [(256, 2), (512, 4), (1024, 2), (2048, 8), (4096, 4), (8192, 8), (16384, 4)])
 def test_gpu_a_rank_reads_only_its_two_bands_of_the_static_inputs(n, world):
     """What sharded.tile_rank_lines says a rank's pass 1 reads of h0T / omegaT is ALL it reads: with every other line of the
     inputs poisoned (NaN), every rank's send buffer is bit-identical to the one computed from the clean inputs -- every loader
