@@ -81,6 +81,9 @@ struct OceanContext {
     // Staged path, N >= 8192: the column pass runs in two steps, the second out of place (k_cols4_a / k_cols4_b); its destination
     // becomes the field and the old buffer the next destination.  Allocated on the first ocean_fft_cols of a field.
     c32* field_alt[3] = {nullptr, nullptr, nullptr};
+    // ... and the second step is DEFERRED to the field's next consumer (settle_field): when that is ocean_correct behind the three
+    // column passes -- the reference's order -- step B of the three fields and the correction are one kernel (k_cols4_b_correct).
+    bool step_b_pending[3] = {false, false, false};
     bool nat_valid[3] = {true, true, true};
     bool chk_valid[3] = {false, false, false};
     bool stage_chunked = false;
@@ -356,14 +359,20 @@ template <int N> struct Launch {
             hipLaunchKernelGGL((k_fft_lines<N, G::E, G::COL_LPW, true>), dim3(G::col_grid), dim3(G::col_threads),
                                G::col_lds, s, data, c->tw);
     }
-    // in place on `data` (step A), then into `dst` (step B): the caller swaps the two
-    static void cols4(OceanContext* c, c32* data, c32* dst, hipStream_t s) {
-        if constexpr (COLS4) {
-            constexpr int M = N / COLS4_S;
-            hipLaunchKernelGGL((k_cols4_a<N, COLS4_S, G::E, COLS4_LPW>), dim3((N / COLS4_LPW) * COLS4_S), dim3((M / G::E) * COLS4_LPW), COLS4_LDS, s,
+    // step A in place on `data`; step B from `src` into `dst` (the caller swaps the two); step B of the three fields + correction
+    static void cols4_a(OceanContext* c, c32* data, hipStream_t s) {
+        if constexpr (COLS4)
+            hipLaunchKernelGGL((k_cols4_a<N, COLS4_S, G::E, COLS4_LPW>), dim3((N / COLS4_LPW) * COLS4_S), dim3((N / COLS4_S / G::E) * COLS4_LPW), COLS4_LDS, s,
                                data, (const c32*)c->tw);
-            hipLaunchKernelGGL((k_cols4_b<N, COLS4_S>), dim3((N / ((COLS4_S >= 32) ? 1 : 2) / 256) * M), dim3(256), 0, s, (const c32*)data, dst);
-        }
+    }
+    static void cols4_b(const c32* src, c32* dst, hipStream_t s) {
+        if constexpr (COLS4)
+            hipLaunchKernelGGL((k_cols4_b<N, COLS4_S>), dim3((N / ((COLS4_S >= 32) ? 1 : 2) / 256) * (N / COLS4_S)), dim3(256), 0, s, src, dst);
+    }
+    static void cols4_b_correct(OceanContext* c, hipStream_t s) {
+        if constexpr (COLS4)
+            hipLaunchKernelGGL((k_cols4_b_correct<N, COLS4_S>), dim3((N / 256) * (N / COLS4_S)), dim3(256), 0, s, (const c32*)c->field[OCEAN_FIELD_DY],
+                               (const c32*)c->field[OCEAN_FIELD_DX], (const c32*)c->field[OCEAN_FIELD_DZ], c->out);
     }
 };
 
@@ -392,17 +401,24 @@ void launch_propagate(OceanContext* c, float time, float domain, hipStream_t s) 
         const unsigned gridp = (unsigned)(((size_t)c->n * c->n / 4 + 255) / 256);
         hipLaunchKernelGGL(k_propagate_paired, dim3(gridp), dim3(256), 0, s, (const c32*)c->h0, (const float*)c->omega,
                            c->field[OCEAN_FIELD_DY], c->field[OCEAN_FIELD_DX], c->field[OCEAN_FIELD_DZ], c->n, time, domain);
-        for (int f = 0; f < 3; ++f) { c->nat_valid[f] = true; c->chk_valid[f] = false; }
+        for (int f = 0; f < 3; ++f) { c->nat_valid[f] = true; c->chk_valid[f] = false; c->step_b_pending[f] = false; }
         return;
     }
     const unsigned grid = (unsigned)(((size_t)c->n * c->n / 2 + 255) / 256);
     hipLaunchKernelGGL(k_propagate, dim3(grid), dim3(256), 0, s, (const c32*)c->h0, (const c32*)c->h0, (const float*)c->omega,
                        c->field[OCEAN_FIELD_DY], c->field[OCEAN_FIELD_DX], c->field[OCEAN_FIELD_DZ], c->n, 0, c->n, time,
                        domain, c->quirks);
-    for (int f = 0; f < 3; ++f) { c->nat_valid[f] = true; c->chk_valid[f] = false; }
+    for (int f = 0; f < 3; ++f) { c->nat_valid[f] = true; c->chk_valid[f] = false; c->step_b_pending[f] = false; }
 }
-// Make the natural copy of field f current (no-op when it already is).
-void launch_unchunk(OceanContext* c, int f, hipStream_t s) {
+// Make the natural copy of field f current (no-op when it already is): run the deferred second step of a two-step column pass
+// (N >= 8192), or unchunk (N <= 4096).
+void settle_field(OceanContext* c, int f, hipStream_t s) {
+    if (c->step_b_pending[f]) {                     // field[f] holds step A's result; step B's destination becomes the field
+        OCEAN_DISPATCH(c->n, L::cols4_b((const c32*)c->field[f], c->field_alt[f], s));
+        std::swap(c->field[f], c->field_alt[f]);
+        c->step_b_pending[f] = false;
+        return;
+    }
     if (c->nat_valid[f]) return;
     hipLaunchKernelGGL(k_unchunk, dim3((unsigned)c->n / 4), dim3(256), 0, s, (const c32*)c->cfield[f], c->field[f], c->n, c->lay);
     c->nat_valid[f] = true;
@@ -414,14 +430,18 @@ void launch_correct(OceanContext* c, hipStream_t s) {
                            (const c32*)c->cfield[dx], (const c32*)c->cfield[dz], c->out, c->n, c->lay);
         return;
     }
-    for (int f = 0; f < 3; ++f) launch_unchunk(c, f, s);
+    if (c->step_b_pending[dy] && c->step_b_pending[dx] && c->step_b_pending[dz]) {   // N >= 8192, behind the three column passes
+        OCEAN_DISPATCH(c->n, L::cols4_b_correct(c, s));                          // (the fields stay as step A left them)
+        return;
+    }
+    for (int f = 0; f < 3; ++f) settle_field(c, f, s);
     const unsigned grid = (unsigned)(((size_t)c->n * c->n / 2 + 255) / 256);
     hipLaunchKernelGGL(k_correct, dim3(grid), dim3(256), 0, s, (const c32*)c->field[dy], (const c32*)c->field[dx],
                        (const c32*)c->field[dz], c->out, c->n, 0, c->n);
 }
 // Row pass of field f (shader/fft_row.comp:44-63).  N <= 4096: natural rows in, chunked field out; else in place.
 void launch_rows(OceanContext* c, int f, hipStream_t s) {
-    launch_unchunk(c, f, s);                       // a second row pass on a chunked field starts from its natural copy
+    settle_field(c, f, s);                       // a second row pass on a chunked field starts from its natural copy
     if (c->stage_chunked) {
         OCEAN_DISPATCH(c->n, L::stage_rows(c, f, s));
         c->nat_valid[f] = false;
@@ -441,9 +461,10 @@ void launch_cols(OceanContext* c, int f, hipStream_t s) {
     }
     bool cols4 = false;
     OCEAN_DISPATCH(c->n, cols4 = L::COLS4);
-    if (cols4) {                                    // N >= 8192: two steps, the second into field_alt[f], which becomes the field
-        OCEAN_DISPATCH(c->n, L::cols4(c, c->field[f], c->field_alt[f], s));
-        std::swap(c->field[f], c->field_alt[f]);
+    if (cols4) {                                    // N >= 8192: two steps; the second waits for the field's next consumer
+        settle_field(c, f, s);                      // (a column pass behind a column pass: the first one's second step)
+        OCEAN_DISPATCH(c->n, L::cols4_a(c, c->field[f], s));
+        c->step_b_pending[f] = true;
     } else OCEAN_DISPATCH(c->n, L::cols(c, c->field[f], s));
     c->chk_valid[f] = false;
 }
@@ -1099,7 +1120,7 @@ int32_t ocean_read_field(OceanContext* ctx, int32_t field, float* host_re_im) {
     // The field may live in the chunked hand-off layout: natural copy first.  The un-chunk runs on the context stream,
     // so whatever produced the chunked copy (possibly on a caller stream) has to be complete before it starts.
     if (ctx->foreign_stream) HIP_TRY(ctx, hipDeviceSynchronize());
-    launch_unchunk(ctx, field, ctx->stream);
+    settle_field(ctx, field, ctx->stream);
     { const int32_t st = check_launch(ctx, "k_unchunk launch"); if (st != OCEAN_OK) return st; }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(host_re_im, ctx->field[field], (size_t)ctx->n * ctx->n * sizeof(c32), hipMemcpyDeviceToHost));
@@ -1114,6 +1135,7 @@ int32_t ocean_write_field(OceanContext* ctx, int32_t field, const float* host_re
     HIP_TRY(ctx, hipMemcpy(ctx->field[field], host_re_im, (size_t)ctx->n * ctx->n * sizeof(c32), hipMemcpyHostToDevice));
     ctx->nat_valid[field] = true;
     ctx->chk_valid[field] = false;
+    ctx->step_b_pending[field] = false;
     return OCEAN_OK;
 }
 
@@ -1383,12 +1405,14 @@ static int32_t profile_common(OceanContext* ctx, float time, int32_t cap, const 
                                       "k_fft_lines<COL> dx", "k_fft_lines<COL> dy", "k_fft_lines<COL> dz", "k_correct"};
     static const char* kChunked[8] = {"k_propagate", "k_stage_rows(fft) dx", "k_stage_rows(fft) dy", "k_stage_rows(fft) dz",
                                       "k_stage_cols(fft) dx", "k_stage_cols(fft) dy", "k_stage_cols(fft) dz", "k_correct_chunked"};
-    // N >= 8192: the column pass of a field is two launches (k_cols4_a: sub-transforms of sixteen columns, in place; k_cols4_b: the
+    // N >= 8192: the column pass of a field is two steps (k_cols4_a: sub-transforms of sixteen columns, in place; k_cols4_b: the
     // S-point step over consecutive rows into the field's second buffer) -- 0.43-0.47 ms per field at 8192 where whole columns two
-    // at a time (k_fft_lines<COL>, 16-byte pieces) took 0.85; staged frame 4.2 -> 2.8 ms (r05_run12/13).  The staged calls remain
-    // the 1:1 compatibility path, ocean_frame (0.75 ms) the product.
+    // at a time (k_fft_lines<COL>, 16-byte pieces) took 0.85; staged frame 4.2 -> 2.8 ms (r05_run12/13).  The second step is deferred
+    // to the field's consumer: behind the three column passes that is the correction, and k_cols4_b_correct does both.  The staged
+    // calls remain the 1:1 compatibility path, ocean_frame (0.75 ms) the product.
     static const char* kTwoStep[8] = {"k_propagate", "k_fft_lines<ROW> dx", "k_fft_lines<ROW> dy", "k_fft_lines<ROW> dz",
-                                      "k_cols4_a + k_cols4_b dx [two-step column pass]", "k_cols4_a + k_cols4_b dy", "k_cols4_a + k_cols4_b dz", "k_correct"};
+                                      "k_cols4_a dx [two-step column pass, step 1]", "k_cols4_a dy", "k_cols4_a dz",
+                                      "k_cols4_b_correct [step 2 of the three column passes + correction]"};
     const char* const* kStaged = ctx->stage_chunked ? kChunked : (ctx->n >= 8192 ? kTwoStep : kNatural);
     const char* kFused[2] = {"k_half_pass1", "k_half_pass2"};
     const int count = staged ? 8 : 2;

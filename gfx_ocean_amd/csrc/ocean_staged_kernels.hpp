@@ -400,6 +400,39 @@ k_cols4_b(const c32* __restrict__ src, c32* __restrict__ dst) {
     }
 }
 
+// Step B of the three fields AND the correction (shader/correction.comp:24-35) in one kernel: when ocean_correct follows the
+// three column passes (the reference's order, src/render.rs:1210-1287) the S-point step has not run yet (the API defers it: see
+// launch_cols / settle_field in ocean_api.hip) and its only consumer wants the real parts with the sign.  24 R + 16 W instead of
+// 3 x (8 R + 8 W) + 24 R + 16 W bytes per texel; the step-A fields stay as they are, so ocean_read_field afterwards still runs
+// k_cols4_b on them.  One thread per column and k1; rows k1 + M k2 have the parity of k1 (M is even).
+template <int NF, int S>
+__global__ void __launch_bounds__(256)
+k_cols4_b_correct(const c32* __restrict__ height, const c32* __restrict__ disp_x, const c32* __restrict__ disp_z,
+                  float4* __restrict__ out) {
+    constexpr int M = NF / S;
+    constexpr int PER_ROW = NF / 256;
+    static_assert(M % 2 == 0, "the sign of a row follows k1");
+    const int k1 = (int)blockIdx.x / PER_ROW;
+    const int x = ((int)blockIdx.x % PER_ROW) * 256 + (int)threadIdx.x;
+    const size_t in = (size_t)k1 * S * NF + x;
+    float re[3][S];
+    const c32* const src[3] = {disp_x, height, disp_z};            // the map's channel order
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+        c32 a[S], oa[S];
+#pragma unroll
+        for (int r = 0; r < S; ++r) a[r] = src[f][in + (size_t)r * NF];
+        Dft<S>::run(a, oa);
+#pragma unroll
+        for (int k2 = 0; k2 < S; ++k2) re[f][k2] = oa[k2].x;
+    }
+    const float s = (((x + k1) & 1) == 0) ? -1.0f : 1.0f;          // correction.comp:29
+    float4* o = out + (size_t)k1 * NF + x;
+#pragma unroll
+    for (int k2 = 0; k2 < S; ++k2)
+        store_float4_nt(o + (size_t)k2 * M * NF, make_float4(re[0][k2] * s, re[1][k2] * s, re[2][k2] * s, 0.0f));
+}
+
 // ---------------------------------------------------------------------------------------------
 // Staged path, chunked hand-off (N <= 4096, 4 x 4 chunks)
 // ---------------------------------------------------------------------------------------------

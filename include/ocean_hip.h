@@ -147,7 +147,11 @@ void ocean_correction_destroy(OceanCorrection* c);                          /* s
 int32_t ocean_propagate(OceanPropagation* p, const OceanPropagateLocals* locals, void* stream);
 /* bind row_pass; dispatch [1, N, 1] per set: src/render.rs:1158-1179, shader/fft_row.comp:44-63 */
 int32_t ocean_fft_rows(OceanFft* fft, int32_t field, void* stream);
-/* bind col_pass; dispatch [1, N, 1] per set: src/render.rs:1210-1231, shader/fft_col.comp:44-63 */
+/* bind col_pass; dispatch [1, N, 1] per set: src/render.rs:1210-1231, shader/fft_col.comp:44-63.
+ * (N >= 8192: the pass has two steps and the second runs with the field's next consumer on THAT call's stream -- inside
+ * ocean_correct when it follows the three column passes, before ocean_read_field / a further pass otherwise.  Results are those
+ * of the in-place pass in every order of calls; callers that spread the staged calls over several streams order them as the
+ * reference's barriers do, src/render.rs:1181-1208, 1233-1278.) */
 int32_t ocean_fft_cols(OceanFft* fft, int32_t field, void* stream);
 /* bind correction; dispatch [N/16, N/16, 1]: src/render.rs:1280-1287, shader/correction.comp:24-35 */
 int32_t ocean_correct(OceanCorrection* c, const OceanCorrectionLocals* locals, void* stream);

@@ -206,6 +206,17 @@ def cols4(field, s):
     return dst
 
 
+def cols4_correct(h, dx, dz, s):
+    """Step A of the three fields, then k_cols4_b_correct (step B of the three + correction.comp): the RGBA map [NF, NF, 4]."""
+    f = [np.ascontiguousarray(v, np.complex64).copy() for v in (h, dx, dz)]
+    nf = f[0].shape[0]
+    out = np.full((nf, nf, 4), np.nan, np.float32)
+    tw = twiddles(nf)
+    lib().emu_cols4_correct.argtypes = [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 5
+    assert lib().emu_cols4_correct(nf, int(s), _p(f[0]), _p(f[1]), _p(f[2]), _p(out), _p(tw)) == 0
+    return out
+
+
 def normals_plane(plane, bands=False):
     """k_normals_plane (bands=True: k_normals_plane_bands, the N >= 8192 kernel; n >= 1024 here): the normal field from the dense
     source-channel plane of the fused pass 2."""

@@ -332,8 +332,22 @@ int emu_cols4(int nf, int s, float* data, float* dst, const float* tw) {
         emu_launch((nf_ / ((s_ >= 32) ? 1 : 2) / 256) * m_, 256, [&] { k_cols4_b<nf_, s_>((const c32*)data, (c32*)dst); });
         return 0;
     };
+    if (nf == 1024 && s == 4) return run(std::integral_constant<int, 1024>{}, std::integral_constant<int, 4>{});
     if (nf == 2048 && s == 8) return run(std::integral_constant<int, 2048>{}, std::integral_constant<int, 8>{});
     if (nf == 4096 && s == 16) return run(std::integral_constant<int, 4096>{}, std::integral_constant<int, 16>{});
+    return -2;
+}
+// ... and its second step fused with the correction (k_cols4_b_correct): step A of the three fields in place, then the map
+int emu_cols4_correct(int nf, int s, float* h, float* dx, float* dz, float* out, const float* tw) {
+    auto run = [&](auto NF, auto S) {
+        constexpr int nf_ = decltype(NF)::value, s_ = decltype(S)::value, m_ = nf_ / s_;
+        for (float* f : {h, dx, dz})
+            emu_launch((nf_ / 16) * s_, (m_ / 16) * 16, [&] { k_cols4_a<nf_, s_, 16, 16>((c32*)f, (const c32*)tw); });
+        emu_launch((nf_ / 256) * m_, 256, [&] { k_cols4_b_correct<nf_, s_>((const c32*)h, (const c32*)dx, (const c32*)dz, (float4*)out); });
+        return 0;
+    };
+    if (nf == 1024 && s == 4) return run(std::integral_constant<int, 1024>{}, std::integral_constant<int, 4>{});
+    if (nf == 2048 && s == 8) return run(std::integral_constant<int, 2048>{}, std::integral_constant<int, 8>{});
     return -2;
 }
 int emu_propagate(int n, const float* h0, const float* omega, float* h, float* dx, float* dz, float time, float L, unsigned quirks) {

@@ -91,6 +91,24 @@ def test_emu_two_step_column_pass(nf, s):
     assert np.all(rest == 0)
 
 
+def test_emu_two_step_column_pass_with_the_correction():
+    """k_cols4_b_correct (the deferred second step of the three column passes + correction.comp:24-35 in one kernel) is the map
+    k_correct makes of the three k_cols4_b outputs, bit for bit (real parts of the same S-point step, sign by the row's parity)."""
+    nf, s = 1024, 4                                         # (2048, 8) passes too: 47 s; the GPU tier runs S = 16 and 32
+    rng = np.random.default_rng(7)
+    fields = []
+    for i in range(3):
+        x = np.zeros((nf, nf), np.complex64)
+        cols = np.concatenate([[0, 1, nf - 1], rng.choice(nf, 13, replace=False)])
+        x[:, cols] = (rng.standard_normal((nf, len(cols))) + 1j * rng.standard_normal((nf, len(cols)))).astype(np.complex64)
+        fields.append(x)
+    got = emu.cols4_correct(*fields, s)
+    h, dx, dz = (emu.cols4(x, s) for x in fields)
+    want = oc.correction_literal(h, dx, dz)
+    assert np.array_equal(got, want)
+    assert np.all(got[..., 3] == 0)
+
+
 def test_emu_correct(ref_inputs_256):
     h0, om = ref_inputs_256
     h, dx, dz = oc.propagate_literal(h0, om, 1.0)

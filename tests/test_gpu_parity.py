@@ -337,6 +337,65 @@ def test_staged_column_pass_16384():
         d.destroy()
 
 
+def test_staged_deferred_column_step_8192():
+    """N >= 8192: the second step of a column pass waits for the field's next consumer.  Behind the three column passes that is
+    ocean_correct (k_cols4_b_correct: step 2 of the three fields + correction.comp in one kernel); ocean_read_field, a row pass,
+    another column pass or a correction with the fields in mixed states run k_cols4_b first.  Every order gives the map the
+    separate kernels give, bit for bit, and the fields read back as the reference's in-place passes would leave them."""
+    n = 8192
+    h0, om = g.synth.make_inputs(n)
+    r = g.OceanRenderer(n)
+    dev = r.device
+    try:
+        r.upload(h0, om)
+        r.render(0.5)                                              # 8 dispatches: ..., cols x3 (step 1 each), correction (step 2 + sign)
+        one_kernel = r.displacement()
+        fields = {f: dev.read_field(f) for f in (g.FIELD_DY, g.FIELD_DX, g.FIELD_DZ)}     # each read settles its field (k_cols4_b)
+        assert np.array_equal(one_kernel, oc.correction_literal(fields[g.FIELD_DY], fields[g.FIELD_DX], fields[g.FIELD_DZ]))
+        r.correction.dispatch(g.CorrectionLocals(n))               # nothing pending now: k_correct on the settled fields
+        assert np.array_equal(r.displacement(), one_kernel)
+        del fields
+        # mixed states: one field settled by a read, two pending
+        r.render(0.5)
+        dx = dev.read_field(g.FIELD_DX)
+        r.correction.dispatch(g.CorrectionLocals(n))
+        assert np.array_equal(r.displacement(), one_kernel)
+        assert np.array_equal(dev.read_field(g.FIELD_DX), dx)      # ... and a second read finds the same field
+        # the fields behind the one-kernel correction are still the column pass's results
+        r.render(0.5)
+        assert np.array_equal(dev.read_field(g.FIELD_DX), dx)
+        del dx
+        # column pass behind a column pass, then a row pass, without a read between (sampled lines vs fp64)
+        rng = np.random.default_rng(n)
+        a = np.zeros((n, n), np.complex64)
+        cols = (0, 3, n // 2 + 1, n - 1)
+        for xx in cols:
+            a[:, xx] = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+        dev.write_field(g.FIELD_DY, a)
+        r.fft.col_pass(g.FIELD_DY)
+        r.fft.col_pass(g.FIELD_DY)
+        twice = dev.read_field(g.FIELD_DY)
+        for xx in cols:
+            once = oc.ifft_lines_f64(a[:, xx][None])[0]
+            assert_parity(twice[:, xx], oc.ifft_lines_f64(once[None])[0], 5e-6, f"col {xx} twice")
+        dev.write_field(g.FIELD_DY, a)
+        r.fft.col_pass(g.FIELD_DY)
+        r.fft.row_pass(g.FIELD_DY)                                 # settles, then transforms rows
+        both = dev.read_field(g.FIELD_DY)
+        want = np.zeros((n, len(cols)), np.complex128)
+        for i, xx in enumerate(cols):
+            want[:, i] = oc.ifft_lines_f64(a[:, xx][None])[0]
+        phase = np.exp(2j * np.pi * np.outer(np.arange(n), np.array(cols)) / n)       # row yy of the column-transformed field has
+        for yy in (0, 1, n - 1):                                                      # four non-zero entries: its transform in closed form
+            assert_parity(both[yy], (want[yy][None, :] * phase).sum(1), 5e-6, f"cols then rows, row {yy}")
+        # a written field discards what was pending
+        r.fft.col_pass(g.FIELD_DY)
+        dev.write_field(g.FIELD_DY, a)
+        assert np.array_equal(dev.read_field(g.FIELD_DY), a)
+    finally:
+        r.dispose()
+
+
 def test_linearity_and_impulse_1024():
     n = 1024
     om = g.synth.dispersion(n)

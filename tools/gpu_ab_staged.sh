@@ -20,7 +20,7 @@ for i in range(reps):
     for k, (name, ms) in enumerate(d.profile_staged(i / 60.0)):
         acc[k] = acc.get(k, 0.0) + ms / reps
 d.frame(1.0); want = d.checksum()
-print(os.path.basename(os.environ["OCEAN_HIP_LIB"]), "staged frame %.3f ms" % sum(acc.values()), "cols", [round(acc[k], 3) for k in (4, 5, 6)], "rows", round(acc[2], 3))
+print(os.path.basename(os.environ["OCEAN_HIP_LIB"]), "staged frame %.3f ms" % sum(acc.values()), "stages", [round(acc[k], 3) for k in range(8)])
 d.destroy()
 PY
 done; done
