@@ -22,7 +22,7 @@ SYMBOLS = [
     "ocean_fft_init", "ocean_fft_destroy", "ocean_propagation_init",
     "ocean_propagation_destroy", "ocean_correction_init", "ocean_correction_destroy", "ocean_propagate",
     "ocean_fft_rows", "ocean_fft_cols", "ocean_correct", "ocean_frame", "ocean_frame_ex", "ocean_sync",
-    "ocean_context_create_tiles", "ocean_context_tiles", "ocean_upload_spectrum_tile", "ocean_frame_tiles",
+    "ocean_context_create_tiles", "ocean_context_tiles", "ocean_upload_spectrum_tile", "ocean_upload_spectrum_device", "ocean_frame_tiles",
     "ocean_frame_batch", "ocean_batch_device_ptr", "ocean_batch_normals_device_ptr", "ocean_read_batch_normals", "ocean_read_batch_displacement", "ocean_time_frame_batch",
     "ocean_set_quirks", "ocean_quirks", "ocean_set_intermediate", "ocean_intermediate",
     "ocean_normals", "ocean_read_normals", "ocean_set_frame_normals", "ocean_frame_normals", "ocean_normals_device_ptr", "ocean_positions", "ocean_read_positions",
@@ -148,6 +148,7 @@ def load_library():
         "ocean_context_create_tiles": (i32, [i32, i32, i32, pp]),
         "ocean_context_tiles": (i32, [vp]),
         "ocean_upload_spectrum_tile": (i32, [vp, i32, vp, vp]),
+        "ocean_upload_spectrum_device": (i32, [vp, i32, vp, vp, vp]),
         "ocean_frame_tiles": (i32, [vp, f32, vp, ctypes.c_int64, vp]),
         "ocean_frame_batch": (i32, [vp, f32, f32, i32, vp, ctypes.c_int64, vp]),
         "ocean_batch_device_ptr": (vp, [vp]),

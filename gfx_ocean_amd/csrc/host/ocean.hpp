@@ -38,6 +38,10 @@ public:
     void upload_spectrum_tile(int tile, const std::vector<std::complex<float>>& h0, const std::vector<float>& omega) {
         check(ocean_upload_spectrum_tile(ctx_, tile, reinterpret_cast<const float*>(h0.data()), omega.data()));
     }
+    // the upload's device-side half alone (copy_buffer, src/render.rs:896-915): from memory the GPU can read, asynchronous on `stream`
+    void upload_spectrum_device(const void* h0_device, const void* omega_device, int tile = 0, void* stream = nullptr) {
+        check(ocean_upload_spectrum_device(ctx_, tile, h0_device, omega_device, stream));
+    }
     void frame_tiles(float time, void* stream = nullptr) { check(ocean_frame_tiles(ctx_, time, nullptr, 0, stream)); }
     ~Device() { ocean_context_destroy(ctx_); }
     Device(const Device&) = delete;

@@ -772,6 +772,31 @@ uint32_t ocean_context_flags(const OceanContext* ctx) { return valid(ctx) ? ctx-
 
 namespace {
 
+// The one-time re-layout of a natural-layout spectrum in device memory for the fused path: h0T[x][y] = h0[y][x], omegaT likewise
+// (k_transpose; fp16 storage: quantise, pack, and write the dequantised values back into the natural copy).  The whole arrays,
+// or -- band-limited rank context -- the blocks of 32 lines that are backed by memory.
+void relayout_spectrum(OceanContext* ctx, c32* h0_nat, const float* om_nat, bool f16, int scale_log2, int32_t tile, hipStream_t s) {
+    const size_t n = (size_t)ctx->n, n2 = n * n;
+    const int nb = (int)(n / 32);
+    std::vector<std::pair<int, int>> blocks = ctx->bands ? ctx->band_blocks : std::vector<std::pair<int, int>>{{0, nb}};
+    for (const auto& br : blocks) {
+        const unsigned tiles = (unsigned)(br.second * nb);
+        if (f16)
+            hipLaunchKernelGGL(k_quantise_f16_transpose, dim3(tiles), dim3(256), 0, s, reinterpret_cast<float2*>(h0_nat),
+                               reinterpret_cast<uint32_t*>(ctx->h0T), (int)n, std::ldexp(1.0f, scale_log2), std::ldexp(1.0f, -scale_log2));
+        else
+            hipLaunchKernelGGL(k_transpose<float2>, dim3(tiles), dim3(256), 0, s, reinterpret_cast<const float2*>(h0_nat),
+                               reinterpret_cast<float2*>(ctx->h0T) + (size_t)tile * n2, (int)n, br.first, br.second);
+        hipLaunchKernelGGL(k_transpose<float>, dim3(tiles), dim3(256), 0, s, om_nat, ctx->omegaT + (size_t)tile * n2, (int)n, br.first, br.second);
+    }
+}
+void mark_uploaded(OceanContext* ctx, bool f16, int scale_log2, int32_t tile) {
+    ctx->h0_f16 = f16;
+    ctx->scale_log2 = scale_log2;
+    ctx->uploaded_tiles |= (uint64_t)1 << tile;
+    ctx->uploaded = ctx->uploaded_tiles == ((ctx->tiles >= 64) ? ~(uint64_t)0 : (((uint64_t)1 << ctx->tiles) - 1));
+}
+
 int32_t upload_common(OceanContext* ctx, const float* h0_re_im, const float* omega, bool f16, int32_t tile = 0) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
     if (!h0_re_im || !omega) return fail(ctx, OCEAN_E_INVALID_ARG, "NULL input");
@@ -805,30 +830,43 @@ int32_t upload_common(OceanContext* ctx, const float* h0_re_im, const float* ome
     }
     HIP_TRY(ctx, hipMemcpy(h0_nat, h0_re_im, n2 * sizeof(c32), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(om_nat, omega, n2 * sizeof(float), hipMemcpyHostToDevice));
-    const int nb = (int)(n / 32);
     hipStream_t s = ctx->stream;
-    // the whole arrays, or -- band-limited rank context -- the blocks of 32 lines that are backed by memory
-    std::vector<std::pair<int, int>> blocks = ctx->bands ? ctx->band_blocks : std::vector<std::pair<int, int>>{{0, nb}};
-    for (const auto& br : blocks) {
-        const unsigned tiles = (unsigned)(br.second * nb);
-        if (f16)
-            hipLaunchKernelGGL(k_quantise_f16_transpose, dim3(tiles), dim3(256), 0, s, reinterpret_cast<float2*>(h0_nat),
-                               reinterpret_cast<uint32_t*>(ctx->h0T), (int)n, std::ldexp(1.0f, scale_log2), std::ldexp(1.0f, -scale_log2));
-        else
-            hipLaunchKernelGGL(k_transpose<float2>, dim3(tiles), dim3(256), 0, s, reinterpret_cast<const float2*>(h0_nat),
-                               reinterpret_cast<float2*>(ctx->h0T) + (size_t)tile * n2, (int)n, br.first, br.second);
-        hipLaunchKernelGGL(k_transpose<float>, dim3(tiles), dim3(256), 0, s, (const float*)om_nat, ctx->omegaT + (size_t)tile * n2, (int)n, br.first, br.second);
-    }
+    relayout_spectrum(ctx, h0_nat, om_nat, f16, scale_log2, tile, s);
     { const int32_t st = check_launch(ctx, "upload re-layout launch"); if (st != OCEAN_OK) return st; }
     HIP_TRY(ctx, hipStreamSynchronize(s));
-    ctx->h0_f16 = f16;
-    ctx->scale_log2 = scale_log2;
-    ctx->uploaded_tiles |= (uint64_t)1 << tile;
-    ctx->uploaded = ctx->uploaded_tiles == ((ctx->tiles >= 64) ? ~(uint64_t)0 : (((uint64_t)1 << ctx->tiles) - 1));
+    mark_uploaded(ctx, f16, scale_log2, tile);
     return OCEAN_OK;
 }
 
+// Is `p` memory a kernel on `device` may read: device or managed memory, or host memory registered with the runtime (a mapped
+// staging buffer, as the reference's CPU_VISIBLE one: src/render.rs:749-761)?
+bool device_readable(const void* p) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged || attr.type == hipMemoryTypeHost;
+}
+
 }  // namespace
+
+int32_t ocean_upload_spectrum_device(OceanContext* ctx, int32_t tile, const void* h0_device, const void* omega_device, void* stream) {
+    if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
+    if (!h0_device || !omega_device) return fail(ctx, OCEAN_E_INVALID_ARG, "NULL input");
+    if (tile < 0 || tile >= ctx->tiles) return fail(ctx, OCEAN_E_INVALID_ARG, "no such tile in this context");
+    DeviceGuard guard(ctx->device);
+    if (!device_readable(h0_device) || !device_readable(omega_device))
+        return fail(ctx, OCEAN_E_INVALID_ARG, "ocean_upload_spectrum_device reads device, managed or registered host memory (pageable host memory: ocean_upload_spectrum)");
+    const size_t n2 = (size_t)ctx->n * ctx->n;
+    hipStream_t s = pick(ctx, stream);
+    if (!(ctx->flags & OCEAN_CTX_FUSED_ONLY)) {   // the staged path's natural-layout copies (= copy_buffer into initial_spec / omega_buffer)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h0, h0_device, n2 * sizeof(c32), hipMemcpyDefault, s));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->omega, omega_device, n2 * sizeof(float), hipMemcpyDefault, s));
+    }
+    // (k_transpose only reads its source; the fp16 storage needs the maximum first: ocean_upload_spectrum_f16)
+    relayout_spectrum(ctx, const_cast<c32*>(static_cast<const c32*>(h0_device)), static_cast<const float*>(omega_device), false, 0, tile, s);
+    { const int32_t st = check_launch(ctx, "upload re-layout launch"); if (st != OCEAN_OK) return st; }
+    mark_uploaded(ctx, false, 0, tile);
+    return OCEAN_OK;
+}
 
 int32_t ocean_upload_spectrum(OceanContext* ctx, const float* h0_re_im, const float* omega) {
     return upload_common(ctx, h0_re_im, omega, false);

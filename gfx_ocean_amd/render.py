@@ -97,6 +97,13 @@ class OceanDevice:
         fn = load_library().ocean_upload_spectrum_f16 if spectrum_fp16 else load_library().ocean_upload_spectrum
         self._check(fn(self._ctx, h0.ctypes.data, omega.ctypes.data))
 
+    def upload_spectrum_device(self, h0_ptr: int, omega_ptr: int, tile: int = 0, stream=None):
+        """The upload's device-side half alone (copy_buffer, src/render.rs:896-915): the spectrum is read from memory the GPU can
+        read -- `h0_ptr` / `omega_ptr` are addresses (e.g. `tensor.data_ptr()`) of c32[N*N] / f32[N*N] in device, managed or
+        registered host memory.  Asynchronous on `stream` (None = the context's); fp32 storage."""
+        self._check(load_library().ocean_upload_spectrum_device(self._ctx, int(tile), ctypes.c_void_p(int(h0_ptr)),
+                                                                ctypes.c_void_p(int(omega_ptr)), stream))
+
     def read_spectrum(self) -> np.ndarray:
         n = self.resolution
         out = np.empty((n, n), dtype=np.complex64)

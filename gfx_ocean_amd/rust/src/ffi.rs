@@ -52,6 +52,8 @@ extern "C" {
     pub fn ocean_context_create_tiles(device: i32, resolution: i32, tiles: i32, out: *mut *mut OceanContext) -> i32;
     pub fn ocean_context_tiles(ctx: *const OceanContext) -> i32;
     pub fn ocean_upload_spectrum_tile(ctx: *mut OceanContext, tile: i32, h0_re_im: *const f32, omega: *const f32) -> i32;
+    pub fn ocean_upload_spectrum_device(ctx: *mut OceanContext, tile: i32, h0_device: *const c_void, omega_device: *const c_void,
+                                        stream: *mut c_void) -> i32;
     pub fn ocean_frame_tiles(ctx: *mut OceanContext, time: f32, out_base_device: *mut c_void, out_stride_bytes: i64, stream: *mut c_void) -> i32;
     pub fn ocean_frame_batch(ctx: *mut OceanContext, t0: f32, dt: f32, count: i32, out_base_device: *mut c_void, out_stride_bytes: i64,
                              stream: *mut c_void) -> i32;

@@ -72,6 +72,14 @@ impl Device {
         }
         self.check(unsafe { ffi::ocean_upload_spectrum_tile(self.ctx, tile, spectrum.as_ptr() as *const f32, omega.as_ptr()) })
     }
+    /// The upload's device-side half alone (`copy_buffer`, src/render.rs:896-915): the spectrum is read from memory the GPU can
+    /// read (device, managed or registered host memory), asynchronously on `stream` (null = the context's).
+    /// # Safety
+    /// `h0_device` / `omega_device` must address N*N `[f32; 2]` / N*N `f32` that stay valid until the stream has passed the call.
+    pub unsafe fn upload_spectrum_device(&self, tile: i32, h0_device: *const std::ffi::c_void, omega_device: *const std::ffi::c_void,
+                                         stream: *mut std::ffi::c_void) -> Result<(), Box<dyn Error>> {
+        self.check(ffi::ocean_upload_spectrum_device(self.ctx, tile, h0_device, omega_device, stream))
+    }
     /// One frame of every tile at `time` into library-owned maps (`read_batch_displacement(k, ..)`).
     pub fn frame_tiles(&self, time: f32) -> Result<(), Box<dyn Error>> {
         self.check(unsafe { ffi::ocean_frame_tiles(self.ctx, time, ptr::null_mut(), 0, ptr::null_mut()) })

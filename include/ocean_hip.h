@@ -46,7 +46,8 @@ extern "C" {
  *    (K time steps per launch pair); + ocean_context_create_ex, ocean_context_create_tile_rank, ocean_context_flags (contexts with only the buffers -- and, for a rank of a
  *    sharded tile, only the input lines -- their path uses); + ocean_device_count,
  *    ocean_device_pci_bus_id; + ocean_bind_displacement_fd (the map in memory imported from another API's file descriptor);
- *    ocean_time_frame_batches also bounds frames_per_batch (<= 4096) */
+ *    ocean_time_frame_batches also bounds frames_per_batch (<= 4096); + ocean_upload_spectrum_device (the upload's device-side half,
+ *    asynchronous, from memory the GPU can read) */
 #define OCEAN_ABI_VERSION 4
 
 /* ---- status codes ------------------------------------------------------------------------- */
@@ -122,6 +123,16 @@ int32_t ocean_resolution(const OceanContext* ctx);
 /* Staging upload of the initial spectrum h0 (N*N complex) and dispersion omega (N*N real):
  * src/render.rs:742-818 (decode + staging) and :872-924 (copy_buffer, submit, wait).  Synchronous. */
 int32_t ocean_upload_spectrum(OceanContext* ctx, const float* h0_re_im, const float* omega);
+
+/* The second half of that upload alone -- cmd_buffer.copy_buffer(staging -> initial_spec / omega_buffer), src/render.rs:896-915 --
+ * for a spectrum that already lives where the GPU can read it: device or managed memory (generated there, e.g. when the wind
+ * changes), or host memory registered with the runtime (a mapped staging buffer of the caller's, as the reference's CPU_VISIBLE
+ * one, src/render.rs:749-761).  Natural layout, c32[N*N] and f32[N*N].  ASYNCHRONOUS on `stream` (NULL = the context's): nothing
+ * waits on the host; frames launched on the same stream afterwards see the new spectrum, frames already launched keep the old
+ * one, and the source buffers may be reused once the stream has passed the call.  fp32 storage (the fp16 storage needs the
+ * spectrum's maximum first: ocean_upload_spectrum_f16).  `tile`: 0, or the tile of a context of several.  Pageable host
+ * memory is rejected with OCEAN_E_INVALID_ARG. */
+int32_t ocean_upload_spectrum_device(OceanContext* ctx, int32_t tile, const void* h0_device, const void* omega_device, void* stream);
 
 /* BASELINE config 5 ("fp16 spectrum / fp32 accumulate"): same upload, but the fused path keeps the
  * initial spectrum in HBM as two fp16 per texel, h0 * 2^scale_log2 rounded to nearest even, the

@@ -84,3 +84,30 @@ class DeviceBuffer:
             self.free()
         except Exception:
             pass
+
+
+class PinnedHostBuffer:
+    """hipHostMalloc'ed bytes: host memory registered with the runtime, which kernels read in place over the bus (what a mapped
+    staging buffer is to the reference, src/render.rs:749-761).  .ptr is the address; .view(dtype) the host's window on it."""
+
+    def __init__(self, nbytes: int):
+        p = ctypes.c_void_p()
+        hip().hipHostMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_uint]
+        hip().hipHostFree.argtypes = [ctypes.c_void_p]
+        st = hip().hipHostMalloc(ctypes.byref(p), int(nbytes), 0)
+        assert st == 0 and p.value, f"hipHostMalloc({nbytes}) -> {st}"
+        self.ptr, self.nbytes = int(p.value), int(nbytes)
+
+    def view(self, dtype=np.float32) -> np.ndarray:
+        return np.frombuffer((ctypes.c_char * self.nbytes).from_address(self.ptr), dtype=dtype)
+
+    def free(self):
+        if self.ptr:
+            hip().hipHostFree(ctypes.c_void_p(self.ptr))
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass

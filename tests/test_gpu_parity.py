@@ -396,6 +396,81 @@ def test_staged_deferred_column_step_8192():
         r.dispose()
 
 
+def test_upload_spectrum_from_device_memory():
+    """ocean_upload_spectrum_device = the upload's device-side half (copy_buffer, src/render.rs:896-915): a spectrum in device
+    memory, or in host memory registered with the runtime (a mapped staging buffer), asynchronous and stream-ordered.  Same maps
+    as the host upload bit for bit: fused-only and full contexts (the staged path sees it too), a tile of a context of several,
+    a replacement between two frames without a host wait; pageable host memory is refused."""
+    from hipmem import DeviceBuffer, PinnedHostBuffer
+    n = 1024
+    h0, om = g.synth.make_inputs(n, seed=5)
+    h1, om1 = g.synth.make_inputs(n, seed=6)
+    ref = g.OceanDevice(n)
+    dh, do = DeviceBuffer(h0.nbytes), DeviceBuffer(om.nbytes)
+    ph, po = PinnedHostBuffer(h1.nbytes), PinnedHostBuffer(om1.nbytes)
+    fo = full = tiles = None
+    try:
+        ref.upload_spectrum(h0, om)
+        ref.frame(0.7)
+        want0 = ref.read_displacement()
+        ref.upload_spectrum(h1, om1)
+        ref.frame(0.7)
+        want1 = ref.read_displacement()
+        dh.from_host(h0.view(np.float32))
+        do.from_host(om)
+        ph.view(np.float32)[:] = h1.view(np.float32).ravel()
+        po.view(np.float32)[:] = om1.ravel()
+        # fused-only context, device memory; then the replacement from the registered host buffer BETWEEN two frames, no host wait:
+        # the first frame keeps the old spectrum, the second sees the new one (stream order)
+        fo = g.OceanDevice(n, flags=g.CTX_FUSED_ONLY)
+        fo.upload_spectrum_device(dh.ptr, do.ptr)
+        fo.frame(0.7)
+        assert np.array_equal(fo.read_displacement(), want0)
+        first = DeviceBuffer(want0.nbytes)
+        fo.bind_displacement(first.ptr)
+        fo.frame(0.7)
+        fo.upload_spectrum_device(ph.ptr, po.ptr)
+        fo.bind_displacement(None)
+        fo.frame(0.7)
+        assert np.array_equal(fo.read_displacement(), want1)
+        assert np.array_equal(first.to_host().reshape(n, n, 4), want0)
+        first.free()
+        # full context: the staged path's natural copies are written as well
+        full = g.OceanRenderer(n)
+        full.device.upload_spectrum_device(dh.ptr, do.ptr)
+        assert np.array_equal(full.device.read_spectrum(), h0)
+        full.render(0.7)
+        staged = full.displacement()
+        full.render_fused(0.7)
+        assert np.array_equal(full.displacement(), want0)
+        assert_parity(staged[..., :3], want0[..., :3], 2e-5, "staged frame after a device-side upload")
+        # a context of several tiles: tile 1 from device memory, tile 0 from the host
+        tiles = g.OceanDevice(n, tiles=2)
+        tiles.upload_spectrum(h1, om1, tile=0)
+        tiles.upload_spectrum_device(dh.ptr, do.ptr, tile=1)
+        tiles.frame_tiles(0.7)
+        assert np.array_equal(tiles.read_batch_displacement(0), want1)
+        assert np.array_equal(tiles.read_batch_displacement(1), want0)
+        # pageable host memory, NULL, a tile that does not exist
+        with pytest.raises(g.OceanError) as e:
+            fo.upload_spectrum_device(h0.ctypes.data, om.ctypes.data)
+        assert e.value.status == -1 and "registered" in str(e.value)            # OCEAN_E_INVALID_ARG
+        with pytest.raises(g.OceanError):
+            fo.upload_spectrum_device(0, do.ptr)
+        with pytest.raises(g.OceanError):
+            fo.upload_spectrum_device(dh.ptr, do.ptr, tile=1)
+        fo.frame(0.7)                                              # the context still works, with the spectrum it had
+        assert np.array_equal(fo.read_displacement(), want1)
+    finally:
+        for d in (ref, fo, tiles):
+            if d is not None:
+                d.destroy()
+        if full is not None:
+            full.dispose()
+        for b in (dh, do, ph, po):
+            b.free()
+
+
 def test_linearity_and_impulse_1024():
     n = 1024
     om = g.synth.dispersion(n)
