@@ -38,8 +38,10 @@ def main():
         rec["fused_GBps_contract"] = {k: (36.0 if "pass1" in k else 40.0) * n * n / v / 1e6 for k, v in rec["fused"].items()}
         if not fused_only:
             st = rec["staged"]
-            rec["staged_GBps"] = {k: (16.0 if "fft" in k else (36.0 if "prop" in k else 40.0)) * n * n / v / 1e6
-                                  for k, v in st.items()}
+            # the eight stages in order: propagate 12 R + 24 W (paired kernel), 3 row and 3 column passes 8 R + 8 W each (N >= 8192: the
+            # column pass's first step), correction 24 R + 16 W (N >= 8192: with the column passes' second step, the same bytes)
+            per_stage = [36.0] + [16.0] * 6 + [40.0]
+            rec["staged_GBps"] = {k: b * n * n / v / 1e6 for (k, v), b in zip(st.items(), per_stage)}
             rec["staged_ms_total"] = sum(st.values())
         print(json.dumps(rec), flush=True)
         d.destroy()
