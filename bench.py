@@ -280,6 +280,14 @@ class PlumbingRuntime:
 GATHER_FORMATS = {"rgba32f": (0, 4), "rgb32f": (1, 3), "height32f": (2, 1)}   # name -> (OCEAN_PACK_*, floats per texel)
 
 
+def dominant_kernel(kernels):
+    """The kernel `roofline` is quoted on: the longest one.  The two passes of a frame run within a few per cent of each other and
+    trade places from box to box, so among kernels within 3 % of the longest the one FURTHEST from its roofline is reported (the
+    conservative line, and the same kernel from run to run)."""
+    longest = max(k["avg_ms"] for k in kernels)
+    return min((k for k in kernels if k["avg_ms"] >= 0.97 * longest), key=lambda k: k["frac"])
+
+
 def gather_leg(rt, dist, n, n_gpus, rank, steps, warm=3, fmt="rgba32f"):
     """Every tile's RGBA map gathered to rank 0 with one collective per frame (root ingest N*N*16 B per peer
     over xGMI).  Two schedules, both reported, neither part of `value`:
@@ -636,7 +644,7 @@ def main():
             rec.update({"moved_bytes": b, "moved_GBps": rec["GBps"], "algorithmic_bytes": ab, "GBps": ab / avg_ms / 1e6,
                         "frac": ab / avg_ms / 1e6 / HBM_PEAK_GBS})
         kernels.append(rec)
-    dom = max(kernels, key=lambda k: k["avg_ms"])
+    dom = dominant_kernel(kernels)
     frame_ms = event_ms / timed_frames
     fb, fcb = sum(moved.values()) * n * n, sum(contract.values()) * n * n
     roofline = {"bound": "hbm", "kernel": dom["name"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -255,3 +255,13 @@ def test_algorithmic_bytes_do_not_exceed_the_committed_counters():
             assert alg >= waste_ok * k["hbm_bytes"], (path, name, alg, k["hbm_bytes"])
             seen += 1
     assert seen >= 2
+
+
+def test_the_dominant_kernel_of_the_roofline_line():
+    """`roofline` is quoted on the longest kernel; within 3 % of it, on the one furthest from its roofline (the two passes trade
+    places from box to box: r05_run30 had pass 2 0.6 % longer and the line flipped from 0.58 to 0.66)."""
+    k = lambda name, ms, frac: {"name": name, "avg_ms": ms, "frac": frac}     # noqa: E731
+    assert bench.dominant_kernel([k("k_half_pass1", 0.0883, 0.57), k("k_half_pass2", 0.0889, 0.66)])["name"] == "k_half_pass1"
+    assert bench.dominant_kernel([k("k_half_pass1", 0.0900, 0.57), k("k_half_pass2", 0.0880, 0.66)])["name"] == "k_half_pass1"
+    assert bench.dominant_kernel([k("k_half_pass1", 0.0800, 0.57), k("k_half_pass2", 0.0890, 0.66)])["name"] == "k_half_pass2"
+    assert bench.dominant_kernel([k("k_half_pass1", 0.026, 0.5), k("k_half_pass2", 0.019, 0.8), k("k_normals_plane", 0.013, 0.7)])["name"] == "k_half_pass1"
