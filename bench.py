@@ -120,6 +120,17 @@ def percentiles(values_ms):
     return {"median_ms": pick(0.5), "p10_ms": pick(0.1), "p90_ms": pick(0.9), "min_ms": v[0]}
 
 
+def rank_device_index(local_rank, visible, env):
+    """The HIP ordinal rank `local_rank` of this node drives, or None when it has no GPU.  Normally the launcher leaves every GPU
+    visible to every rank and rank r takes device r; a launcher that isolates each rank to ONE device (HIP_ / ROCR_ /
+    CUDA_VISIBLE_DEVICES set per process) leaves it a single device, ordinal 0, whatever its LOCAL_RANK."""
+    if local_rank < visible:
+        return local_rank
+    if visible == 1 and any(env.get(v) for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")):
+        return 0
+    return None
+
+
 def tile_seed(n, rank):
     return n + rank     # SURVEY.md 8d: tile r of a multi-GPU run uses seed N + r
 
@@ -497,11 +508,13 @@ def main():
         if args.plumbing:
             dist.init_process_group(backend="gloo")
         else:
-            if torch.cuda.device_count() <= local_rank and os.environ.get("OCEAN_BENCH_SKIP_DEVICE_CHECK") != "1":   # this rank has no GPU
+            device_index = rank_device_index(local_rank, torch.cuda.device_count(), os.environ)
+            if device_index is None and os.environ.get("OCEAN_BENCH_SKIP_DEVICE_CHECK") != "1":   # this rank has no GPU
                 if rank == 0:
                     sys.stdout = json_out
                     too_few_devices(torch.cuda.device_count(), world)
                 sys.exit(2)
+            local_rank = device_index if device_index is not None else local_rank     # the HIP ordinal this rank drives from here on
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     n_gpus = world if world > 1 else 1

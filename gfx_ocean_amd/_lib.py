@@ -13,7 +13,7 @@ _LIB = None
 
 OCEAN_OK = 0
 STATUS_NAMES = {0: "OCEAN_OK", -1: "OCEAN_E_INVALID_ARG", -2: "OCEAN_E_UNSUPPORTED_N", -3: "OCEAN_E_HIP",
-                -4: "OCEAN_E_OOM", -5: "OCEAN_E_STATE"}
+                -4: "OCEAN_E_OOM", -5: "OCEAN_E_STATE", -6: "OCEAN_E_UNSUPPORTED"}
 
 # every symbol include/ocean_hip.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [

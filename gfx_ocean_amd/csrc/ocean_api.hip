@@ -71,6 +71,7 @@ struct OceanContext {
     hipStream_t stream = nullptr;
     bool foreign_stream = false;  // some dispatch ran on a caller stream: readbacks then wait for the whole device
     hipEvent_t ev_a = nullptr, ev_b = nullptr;   // reused by ocean_time_frames (event creation is not free)
+    hipEvent_t ev_order = nullptr;               // orders an upload on a caller stream against the context stream (no timing)
     // natural-layout buffers of the staged path (src/render.rs:608-670)
     c32* h0 = nullptr;          // initial_spec
     float* omega = nullptr;     // omega_buffer
@@ -117,6 +118,10 @@ struct OceanContext {
     float* batch_plane = nullptr;       // ... and with the normal field switched on: K planes and K normal fields
     float4* batch_normals = nullptr;
     int32_t batch_normals_cap = 0;
+    // what the LAST batch left behind in the library-owned buffers (the capacities above only grow): ocean_read_batch_* refuse an
+    // index past it instead of handing out a frame of an earlier, larger batch
+    int32_t last_batch_maps = 0;        // frames of the last batch that went into batch_out
+    int32_t last_batch_normals = 0;     // normal fields of the last batch (0: the normal field was off)
     float4* positions = nullptr;  // ocean_positions: verts x verts float4, (re)allocated on demand
     int32_t position_verts = 0;
     unsigned long long* checksum_acc = nullptr;   // ocean_checksum_displacement
@@ -297,11 +302,12 @@ template <int N> struct Launch {
         pass1_on(c, time, domain, c->inter, c->lay_h, H::half_grid1, 0, s, t);
     }
     // Pass 2 from `inter` into the map `out`; with the normal field switched on (ocean_set_frame_normals) the PLANE instances,
-    // which also store the source channel as the dense plane k_normals_plane reads.  `count` > 1: a batch (pass1_on).
-    static void pass2_on(OceanContext* c, const c32* inter, float4* out, hipStream_t s, Timing t, FrameBatch batch = FrameBatch(), int count = 1) {
+    // which also store the source channel as the dense plane k_normals_plane reads: `pl`, the caller's choice -- the frame's
+    // c->plane, or the K planes of a batch (c->batch_plane; a batch may be ONE frame, so the count says nothing about it).
+    // `count` > 1: a batch (pass1_on).
+    static void pass2_on(OceanContext* c, const c32* inter, float4* out, float* pl, hipStream_t s, Timing t, FrameBatch batch = FrameBatch(), int count = 1) {
         const c32* tw = c->tw;
         const bool plane = c->frame_normals >= 0;
-        float* pl = (count > 1) ? c->batch_plane : c->plane;        // a batch: one plane per frame (batch_reserve)
         const int ch = c->frame_normals;
         if constexpr (REAL2) {
             const dim3 g(N), b(H::real_threads2);
@@ -321,7 +327,7 @@ template <int N> struct Launch {
             else launch(pass2_kernel<false>(), g, b, H::half_lds2, s, t, inter, out, tw, c->lay_h, (float*)nullptr, 0, batch);
         }
     }
-    static void pass2(OceanContext* c, hipStream_t s, Timing t = Timing()) { pass2_on(c, c->inter, c->out, s, t); }
+    static void pass2(OceanContext* c, hipStream_t s, Timing t = Timing()) { pass2_on(c, c->inter, c->out, c->plane, s, t); }
         // ---- one tile sharded over `world` GPUs (ocean_tile_pass1 / ocean_tile_pass2): the same kernels on this rank's
     // block of half-spectrum columns (pass 1, writing the all-to-all send buffer) and block of rows (pass 2, reading the
     // receive buffer).
@@ -542,6 +548,7 @@ void free_all(OceanContext* c) {
     f(c->h0T); f(c->omegaT); f(c->inter); f(c->nyq); f(c->tw); f(c->out_own); f(c->normals); f(c->plane); f(c->batch_inter); f(c->batch_nyq); f(c->batch_out); f(c->batch_plane); f(c->batch_normals); f(c->positions); f(c->checksum_acc); f(c->inter_scale);
     if (c->ev_a) (void)hipEventDestroy(c->ev_a);
     if (c->ev_b) (void)hipEventDestroy(c->ev_b);
+    if (c->ev_order) (void)hipEventDestroy(c->ev_order);
     if (c->stream) (void)hipStreamDestroy(c->stream);
 }
 
@@ -634,8 +641,12 @@ static int32_t context_create(int32_t device, int32_t resolution, uint32_t flags
         c->lay = make((size_t)resolution, 0);                   // the staged path's chunked hand-off
         c->lay_h = make((size_t)resolution / 2, bshift);  // the fused frame's half-spectrum intermediate
     }
+    bool mapping_bands = false;                    // inside the virtual-memory calls of a band-limited rank context
     auto bail = [&](hipError_t err, const char* what) {
-        const int32_t code = hip_fail(nullptr, err, what);
+        int32_t code = hip_fail(nullptr, err, what);
+        // a runtime / device that cannot reserve and map address ranges (no virtual-memory management): its own status, so that a
+        // caller can fall back to a full OCEAN_CTX_TILE_RANK context for THIS reason only (gfx_ocean_amd/sharded.py)
+        if (mapping_bands && code != OCEAN_E_OOM) code = fail(nullptr, OCEAN_E_UNSUPPORTED, g_create_error + " [ocean_context_create_tile_rank: the sparse mapping of the input lines failed]");
         free_all(c);
         delete c;
         return code;
@@ -644,6 +655,7 @@ static int32_t context_create(int32_t device, int32_t resolution, uint32_t flags
     CTX_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CTX_TRY(hipEventCreate(&c->ev_a));
     CTX_TRY(hipEventCreate(&c->ev_b));
+    CTX_TRY(hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming));
     // One allocation per buffer the path in use needs (the reference sizes one allocation for exactly what it binds,
     // src/render.rs:607-670): the natural-layout copies, fields and chunked hand-off of the staged path are 60 (36 at N >= 8192)
     // of a full context's 100 (76) bytes per texel -- not allocated with OCEAN_CTX_FUSED_ONLY; a rank of a sharded tile
@@ -674,6 +686,7 @@ static int32_t context_create(int32_t device, int32_t resolution, uint32_t flags
             c->band_blocks.push_back({i, j - i});
             i = j;
         }
+        mapping_bands = true;
         hipMemAllocationProp prop;
         std::memset(&prop, 0, sizeof prop);
         prop.type = hipMemAllocationTypePinned;
@@ -722,6 +735,7 @@ static int32_t context_create(int32_t device, int32_t resolution, uint32_t flags
             }
             CTX_TRY(flush());
         }
+        mapping_bands = false;
     } else {
         CTX_TRY(hipMalloc((void**)&c->h0T, (size_t)tiles * n2 * sizeof(c32)));      // (tile k's inputs at k * N * N elements)
         CTX_TRY(hipMalloc((void**)&c->omegaT, (size_t)tiles * n2 * sizeof(float)));
@@ -773,22 +787,27 @@ uint32_t ocean_context_flags(const OceanContext* ctx) { return valid(ctx) ? ctx-
 namespace {
 
 // The one-time re-layout of a natural-layout spectrum in device memory for the fused path: h0T[x][y] = h0[y][x], omegaT likewise
-// (k_transpose; fp16 storage: quantise, pack, and write the dequantised values back into the natural copy).  The whole arrays,
-// or -- band-limited rank context -- the blocks of 32 lines that are backed by memory.
-void relayout_spectrum(OceanContext* ctx, c32* h0_nat, const float* om_nat, bool f16, int scale_log2, int32_t tile, hipStream_t s) {
+// (k_transpose; fp16 storage: quantise, pack, and write the dequantised values back into the natural source).  `w` says which
+// window of the natural arrays `h0_nat` / `om_nat` hold (the whole arrays, a slab of rows, a slab of rows of one band of columns);
+// the destination lines [32 xb0, 32 (xb0 + xblocks)) are written for the window's `rows` rows.
+void relayout_window(OceanContext* ctx, c32* h0_nat, const float* om_nat, NaturalWindow w, int rows, int xb0, int xblocks, bool f16, int scale_log2,
+                     int32_t tile, hipStream_t s) {
     const size_t n = (size_t)ctx->n, n2 = n * n;
-    const int nb = (int)(n / 32);
-    std::vector<std::pair<int, int>> blocks = ctx->bands ? ctx->band_blocks : std::vector<std::pair<int, int>>{{0, nb}};
-    for (const auto& br : blocks) {
-        const unsigned tiles = (unsigned)(br.second * nb);
-        if (f16)
-            hipLaunchKernelGGL(k_quantise_f16_transpose, dim3(tiles), dim3(256), 0, s, reinterpret_cast<float2*>(h0_nat),
-                               reinterpret_cast<uint32_t*>(ctx->h0T), (int)n, std::ldexp(1.0f, scale_log2), std::ldexp(1.0f, -scale_log2));
-        else
-            hipLaunchKernelGGL(k_transpose<float2>, dim3(tiles), dim3(256), 0, s, reinterpret_cast<const float2*>(h0_nat),
-                               reinterpret_cast<float2*>(ctx->h0T) + (size_t)tile * n2, (int)n, br.first, br.second);
-        hipLaunchKernelGGL(k_transpose<float>, dim3(tiles), dim3(256), 0, s, om_nat, ctx->omegaT + (size_t)tile * n2, (int)n, br.first, br.second);
-    }
+    const unsigned grid = (unsigned)(xblocks * (rows / 32));
+    if (f16)
+        hipLaunchKernelGGL(k_quantise_f16_transpose, dim3(grid), dim3(256), 0, s, reinterpret_cast<float2*>(h0_nat), w,
+                           reinterpret_cast<uint32_t*>(ctx->h0T), (int)n, xb0, xblocks, std::ldexp(1.0f, scale_log2), std::ldexp(1.0f, -scale_log2));
+    else
+        hipLaunchKernelGGL(k_transpose<float2>, dim3(grid), dim3(256), 0, s, reinterpret_cast<const float2*>(h0_nat), w,
+                           reinterpret_cast<float2*>(ctx->h0T) + (size_t)tile * n2, (int)n, xb0, xblocks);
+    hipLaunchKernelGGL(k_transpose<float>, dim3(grid), dim3(256), 0, s, om_nat, w, ctx->omegaT + (size_t)tile * n2, (int)n, xb0, xblocks);
+}
+// ... of whole natural arrays in device memory: every line, or -- band-limited rank context -- the blocks of 32 lines that are
+// backed by memory.
+void relayout_spectrum(OceanContext* ctx, c32* h0_nat, const float* om_nat, bool f16, int scale_log2, int32_t tile, hipStream_t s) {
+    const int nb = ctx->n / 32;
+    const std::vector<std::pair<int, int>> blocks = ctx->bands ? ctx->band_blocks : std::vector<std::pair<int, int>>{{0, nb}};
+    for (const auto& br : blocks) relayout_window(ctx, h0_nat, om_nat, NaturalWindow{ctx->n, 0, 0}, ctx->n, br.first, br.second, f16, scale_log2, tile, s);
 }
 void mark_uploaded(OceanContext* ctx, bool f16, int scale_log2, int32_t tile) {
     ctx->h0_f16 = f16;
@@ -796,6 +815,11 @@ void mark_uploaded(OceanContext* ctx, bool f16, int scale_log2, int32_t tile) {
     ctx->uploaded_tiles |= (uint64_t)1 << tile;
     ctx->uploaded = ctx->uploaded_tiles == ((ctx->tiles >= 64) ? ~(uint64_t)0 : (((uint64_t)1 << ctx->tiles) - 1));
 }
+
+// What a fused-only context stages of a host upload at a time (it has no natural-layout copies): slabs of whole rows of at most
+// this many bytes, so that the upload's transient footprint does not depend on N (round 5 staged the whole tile: 3 GiB at 16384,
+// on a rank context that otherwise holds 0.4).
+constexpr size_t UPLOAD_STAGING_BYTES = (size_t)64 << 20;
 
 int32_t upload_common(OceanContext* ctx, const float* h0_re_im, const float* omega, bool f16, int32_t tile = 0) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
@@ -813,37 +837,65 @@ int32_t upload_common(OceanContext* ctx, const float* h0_re_im, const float* ome
         if (!(mx > 0.0f) || !std::isfinite(mx)) scale_log2 = 0;
         else scale_log2 = 14 - (int)std::floor(std::log2(mx));
     }
-    // natural layout (the staged path; = the reference's initial_spec / omega_buffer), then the one-time re-layout for the
-    // fused path on the device: h0T[x][y] = h0[y][x], omegaT likewise (k_transpose; round 2 did this on one host core:
-    // 0.9 s at N = 8192, 2.2 s with the fp16 packing)
-    // (a fused-only context has no natural-layout copies: the upload lands in a staging buffer that lives for this call only)
+    hipStream_t s = ctx->stream;
+    if (!(ctx->flags & OCEAN_CTX_FUSED_ONLY)) {
+        // natural layout (the staged path; = the reference's initial_spec / omega_buffer), then the one-time re-layout for the
+        // fused path on the device: h0T[x][y] = h0[y][x], omegaT likewise (k_transpose; round 2 did this on one host core:
+        // 0.9 s at N = 8192, 2.2 s with the fp16 packing)
+        HIP_TRY(ctx, hipMemcpy(ctx->h0, h0_re_im, n2 * sizeof(c32), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(ctx->omega, omega, n2 * sizeof(float), hipMemcpyHostToDevice));
+        relayout_spectrum(ctx, ctx->h0, ctx->omega, f16, scale_log2, tile, s);
+        { const int32_t st = check_launch(ctx, "upload re-layout launch"); if (st != OCEAN_OK) return st; }
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        mark_uploaded(ctx, f16, scale_log2, tile);
+        return OCEAN_OK;
+    }
+    // A fused-only context has no natural-layout copies: the upload goes through a staging buffer that lives for this call, a
+    // slab of whole rows at a time -- and, on a band-limited rank context, only the columns of those rows that become lines the
+    // rank reads (hipMemcpy2D per band: 1 / world of the tile crosses PCIe and nothing else is staged).
     struct Staging {
         void* p = nullptr;
         ~Staging() { if (p) (void)hipFree(p); }
     } stage;
-    c32* h0_nat = ctx->h0;
-    float* om_nat = ctx->omega;
-    if (ctx->flags & OCEAN_CTX_FUSED_ONLY) {
-        HIP_TRY(ctx, hipMalloc(&stage.p, n2 * (sizeof(c32) + sizeof(float))));
-        h0_nat = reinterpret_cast<c32*>(stage.p);
-        om_nat = reinterpret_cast<float*>(h0_nat + n2);
+    const size_t row_bytes = n * (sizeof(c32) + sizeof(float));
+    size_t slab_rows = UPLOAD_STAGING_BYTES / row_bytes / 32 * 32;
+    if (slab_rows < 32) slab_rows = 32;
+    if (slab_rows > n) slab_rows = n;
+    HIP_TRY(ctx, hipMalloc(&stage.p, slab_rows * row_bytes));
+    c32* h0_st = reinterpret_cast<c32*>(stage.p);
+    float* om_st = reinterpret_cast<float*>(h0_st + slab_rows * n);
+    const c32* h0_host = reinterpret_cast<const c32*>(h0_re_im);
+    const std::vector<std::pair<int, int>> blocks = ctx->bands ? ctx->band_blocks : std::vector<std::pair<int, int>>{{0, (int)(n / 32)}};
+    for (size_t y0 = 0; y0 < n; y0 += slab_rows) {
+        const size_t rows = (n - y0 < slab_rows) ? n - y0 : slab_rows;
+        for (const auto& br : blocks) {
+            const size_t bx0 = (size_t)br.first * 32, bw = (size_t)br.second * 32;
+            if (bw == n) {                                         // whole rows: one contiguous piece per array
+                HIP_TRY(ctx, hipMemcpy(h0_st, h0_host + y0 * n, rows * n * sizeof(c32), hipMemcpyHostToDevice));
+                HIP_TRY(ctx, hipMemcpy(om_st, omega + y0 * n, rows * n * sizeof(float), hipMemcpyHostToDevice));
+            } else {
+                HIP_TRY(ctx, hipMemcpy2D(h0_st, bw * sizeof(c32), h0_host + y0 * n + bx0, n * sizeof(c32), bw * sizeof(c32), rows, hipMemcpyHostToDevice));
+                HIP_TRY(ctx, hipMemcpy2D(om_st, bw * sizeof(float), omega + y0 * n + bx0, n * sizeof(float), bw * sizeof(float), rows, hipMemcpyHostToDevice));
+            }
+            relayout_window(ctx, h0_st, om_st, NaturalWindow{(int)bw, (int)bx0, (int)y0}, (int)rows, br.first, br.second, f16, scale_log2, tile, s);
+            { const int32_t st = check_launch(ctx, "upload re-layout launch"); if (st != OCEAN_OK) return st; }
+            HIP_TRY(ctx, hipStreamSynchronize(s));                 // the staging buffer is reused by the next piece
+        }
     }
-    HIP_TRY(ctx, hipMemcpy(h0_nat, h0_re_im, n2 * sizeof(c32), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(om_nat, omega, n2 * sizeof(float), hipMemcpyHostToDevice));
-    hipStream_t s = ctx->stream;
-    relayout_spectrum(ctx, h0_nat, om_nat, f16, scale_log2, tile, s);
-    { const int32_t st = check_launch(ctx, "upload re-layout launch"); if (st != OCEAN_OK) return st; }
-    HIP_TRY(ctx, hipStreamSynchronize(s));
     mark_uploaded(ctx, f16, scale_log2, tile);
     return OCEAN_OK;
 }
 
-// Is `p` memory a kernel on `device` may read: device or managed memory, or host memory registered with the runtime (a mapped
-// staging buffer, as the reference's CPU_VISIBLE one: src/render.rs:749-761)?
-bool device_readable(const void* p) {
+// The address a kernel on `device` reads `p` through: device memory of that device, managed memory, or host memory registered
+// with the runtime and mapped for the device (a mapped staging buffer, as the reference's CPU_VISIBLE one: src/render.rs:749-761).
+// NULL: pageable host memory, another device's memory, or registered memory without a device mapping.
+const void* device_view(const void* p, int device) {
     hipPointerAttribute_t attr;
-    if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged || attr.type == hipMemoryTypeHost;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (attr.type == hipMemoryTypeDevice) return (attr.device == device) ? p : nullptr;
+    if (attr.type == hipMemoryTypeManaged) return p;
+    if (attr.type == hipMemoryTypeHost) return attr.devicePointer;      // (NULL when the registration carries no device mapping)
+    return nullptr;
 }
 
 }  // namespace
@@ -853,17 +905,31 @@ int32_t ocean_upload_spectrum_device(OceanContext* ctx, int32_t tile, const void
     if (!h0_device || !omega_device) return fail(ctx, OCEAN_E_INVALID_ARG, "NULL input");
     if (tile < 0 || tile >= ctx->tiles) return fail(ctx, OCEAN_E_INVALID_ARG, "no such tile in this context");
     DeviceGuard guard(ctx->device);
-    if (!device_readable(h0_device) || !device_readable(omega_device))
-        return fail(ctx, OCEAN_E_INVALID_ARG, "ocean_upload_spectrum_device reads device, managed or registered host memory (pageable host memory: ocean_upload_spectrum)");
+    const void* h0_src = device_view(h0_device, ctx->device);
+    const void* om_src = device_view(omega_device, ctx->device);
+    if (!h0_src || !om_src)
+        return fail(ctx, OCEAN_E_INVALID_ARG, "ocean_upload_spectrum_device reads memory of the context's device, managed memory or registered host memory that is "
+                                              "mapped for the device (pageable host memory: ocean_upload_spectrum)");
     const size_t n2 = (size_t)ctx->n * ctx->n;
     hipStream_t s = pick(ctx, stream);
+    // The re-layout overwrites the inputs of frames that may still be queued on the context stream, and frames launched there
+    // afterwards must find the new spectrum: when the upload runs on a caller stream it is ordered against the context stream
+    // on both sides (events; nothing waits on the host).  Other caller streams are the caller's to order (include/ocean_hip.h).
+    if (s != ctx->stream) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_order, ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_order, 0));
+    }
     if (!(ctx->flags & OCEAN_CTX_FUSED_ONLY)) {   // the staged path's natural-layout copies (= copy_buffer into initial_spec / omega_buffer)
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h0, h0_device, n2 * sizeof(c32), hipMemcpyDefault, s));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->omega, omega_device, n2 * sizeof(float), hipMemcpyDefault, s));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h0, h0_src, n2 * sizeof(c32), hipMemcpyDefault, s));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->omega, om_src, n2 * sizeof(float), hipMemcpyDefault, s));
     }
     // (k_transpose only reads its source; the fp16 storage needs the maximum first: ocean_upload_spectrum_f16)
-    relayout_spectrum(ctx, const_cast<c32*>(static_cast<const c32*>(h0_device)), static_cast<const float*>(omega_device), false, 0, tile, s);
+    relayout_spectrum(ctx, const_cast<c32*>(static_cast<const c32*>(h0_src)), static_cast<const float*>(om_src), false, 0, tile, s);
     { const int32_t st = check_launch(ctx, "upload re-layout launch"); if (st != OCEAN_OK) return st; }
+    if (s != ctx->stream) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_order, s));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_order, 0));
+    }
     mark_uploaded(ctx, false, 0, tile);
     return OCEAN_OK;
 }
@@ -1325,7 +1391,7 @@ void launch_batch(OceanContext* c, float t0, float dt, int32_t count, float4* ou
         }
         OCEAN_DISPATCH(c->n, {
             L::pass1_on(c, t0, c->default_domain, c->batch_inter, c->lay_h, L::H::half_grid1, 0, s, Timing(), c->batch_nyq, b, count);
-            L::pass2_on(c, c->batch_inter, out, s, Timing(), b, count);
+            L::pass2_on(c, c->batch_inter, out, c->batch_plane, s, Timing(), b, count);
         });
         if (c->frame_normals >= 0) {                                // K normal fields from the K planes, one launch (blockIdx.y = frame)
             const int rows = normals_plane_rows(c->n);
@@ -1339,7 +1405,14 @@ void launch_batch(OceanContext* c, float t0, float dt, int32_t count, float4* ou
         return;
     }
     for (int i = 0; i < count; ++i)                                 // N > 1024: one frame fills the chip; the same frames, one launch pair each
-        OCEAN_DISPATCH(c->n, { L::pass1(c, t0 + dt * (float)i, c->default_domain, s); L::pass2_on(c, c->inter, out + (size_t)i * out_stride_texels, s, Timing()); });
+        OCEAN_DISPATCH(c->n, { L::pass1(c, t0 + dt * (float)i, c->default_domain, s); L::pass2_on(c, c->inter, out + (size_t)i * out_stride_texels, c->plane, s, Timing()); });
+}
+// what ocean_read_batch_* may hand out afterwards
+void batch_launched(OceanContext* c, int32_t count, bool own_out) {
+    bool batched = false;
+    OCEAN_DISPATCH(c->n, batched = L::BATCHED);
+    if (own_out) c->last_batch_maps = count;                         // (a batch into caller memory leaves the library-owned maps as they were)
+    c->last_batch_normals = (batched && c->frame_normals >= 0) ? count : 0;
 }
 }  // namespace
 
@@ -1355,6 +1428,7 @@ int32_t ocean_frame_batch(OceanContext* ctx, float t0, float dt, int32_t count, 
     { const int32_t st = batch_reserve(ctx, count, out_base_device == nullptr); if (st != OCEAN_OK) return st; }
     float4* out = out_base_device ? (float4*)out_base_device : ctx->batch_out;
     launch_batch(ctx, t0, dt, count, out, (size_t)(out_stride_bytes / 16), pick(ctx, stream));
+    batch_launched(ctx, count, out_base_device == nullptr);
     return check_launch(ctx, "ocean_frame_batch launch");
 }
 int32_t ocean_frame_tiles(OceanContext* ctx, float time, void* out_base_device, int64_t out_stride_bytes, void* stream) {
@@ -1369,6 +1443,7 @@ int32_t ocean_frame_tiles(OceanContext* ctx, float time, void* out_base_device, 
     { const int32_t st = batch_reserve(ctx, ctx->tiles, out_base_device == nullptr); if (st != OCEAN_OK) return st; }
     float4* out = out_base_device ? (float4*)out_base_device : ctx->batch_out;
     launch_batch(ctx, time, 0.0f, ctx->tiles, out, (size_t)(out_stride_bytes / 16), pick(ctx, stream), true);
+    batch_launched(ctx, ctx->tiles, out_base_device == nullptr);
     return check_launch(ctx, "ocean_frame_tiles launch");
 }
 void* ocean_batch_device_ptr(OceanContext* ctx) { return valid(ctx) ? (void*)ctx->batch_out : nullptr; }
@@ -1376,7 +1451,8 @@ void* ocean_batch_normals_device_ptr(OceanContext* ctx) { return valid(ctx) ? (v
 int32_t ocean_read_batch_normals(OceanContext* ctx, int32_t index, float* host_xyz0) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
     if (!host_xyz0) return fail(ctx, OCEAN_E_INVALID_ARG, "NULL output");
-    if (!ctx->batch_normals || index < 0 || index >= ctx->batch_normals_cap) return fail(ctx, OCEAN_E_STATE, "no normal field with this index (a batch with ocean_set_frame_normals on)");
+    if (!ctx->batch_normals || index < 0 || index >= ctx->last_batch_normals)
+        return fail(ctx, OCEAN_E_STATE, "the last batch left no normal field with this index (its frame count; a batch launched with ocean_set_frame_normals on)");
     DeviceGuard guard(ctx->device);
     HIP_TRY(ctx, sync_for_readback(ctx));
     const size_t n2 = (size_t)ctx->n * ctx->n;
@@ -1386,7 +1462,8 @@ int32_t ocean_read_batch_normals(OceanContext* ctx, int32_t index, float* host_x
 int32_t ocean_read_batch_displacement(OceanContext* ctx, int32_t index, float* host_rgba) {
     if (!valid(ctx)) return OCEAN_E_INVALID_ARG;
     if (!host_rgba) return fail(ctx, OCEAN_E_INVALID_ARG, "NULL output");
-    if (!ctx->batch_out || index < 0 || index >= ctx->batch_out_cap) return fail(ctx, OCEAN_E_STATE, "no library-owned batch map with this index (ocean_frame_batch with out_base_device = NULL)");
+    if (!ctx->batch_out || index < 0 || index >= ctx->last_batch_maps)
+        return fail(ctx, OCEAN_E_STATE, "the last batch left no library-owned map with this index (its frame count; ocean_frame_batch / ocean_frame_tiles with out_base_device = NULL)");
     DeviceGuard guard(ctx->device);
     HIP_TRY(ctx, sync_for_readback(ctx));
     const size_t n2 = (size_t)ctx->n * ctx->n;
@@ -1406,6 +1483,7 @@ int32_t ocean_time_frame_batch(OceanContext* ctx, int32_t launches, int32_t coun
     const bool tiles = ctx->tiles > 1;                             // a context of several tiles: every launch pair = one frame of each tile
     for (int i = 0; i < launches; ++i)
         launch_batch(ctx, tiles ? t0 + dt * (float)i : t0 + dt * (float)((int64_t)i * count), tiles ? 0.0f : dt, count, ctx->batch_out, n2, ctx->stream, tiles);
+    batch_launched(ctx, count, true);
     HIP_TRY(ctx, hipEventRecord(ctx->ev_b, ctx->stream));
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev_b));
     HIP_TRY(ctx, hipEventElapsedTime(out_ms, ctx->ev_a, ctx->ev_b));

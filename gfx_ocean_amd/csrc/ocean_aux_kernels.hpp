@@ -54,33 +54,37 @@ k_pack_height32f(const float4* __restrict__ rgba, float4* __restrict__ height, s
 
 // ---- upload-time re-layout (once per ocean_upload_spectrum; the reference's staging copy, src/render.rs:872-924) --------
 // The fused path reads the static inputs transposed (h0T[x][y] = h0[y][x], omegaT likewise): 32 x 32 tiles through LDS,
-// both sides in contiguous pieces.  The source columns (= destination lines) [32 xt0, 32 (xt0 + xtiles)): the whole array with
-// xt0 = 0, xtiles = n / 32; a band of lines for a context that keeps only the lines its rank reads (ocean_context_create_tile_rank).
-// grid = xtiles * (n / 32), 256 threads.
+// both sides in contiguous pieces.  The source is a WINDOW of the natural-layout array: rows [y0, y0 + 32 ytiles) and columns
+// from x0 on, `pitch` elements per row -- the whole array (pitch n, origins 0), or the slab of rows / band of columns a fused-only
+// context stages at a time (ocean_api.hip upload_common).  Of that window the source columns (= destination lines)
+// [32 xt0, 32 (xt0 + xtiles)) are transposed.  grid = xtiles * ytiles, 256 threads.
+struct NaturalWindow {
+    int pitch;   // elements per source row
+    int x0, y0;  // the array coordinates of the window's first element
+};
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_transpose(const T* __restrict__ src, T* __restrict__ dst, int n, int xt0, int xtiles) {
+k_transpose(const T* __restrict__ src, NaturalWindow w, T* __restrict__ dst, int n, int xt0, int xtiles) {
     __shared__ T tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int x0 = (xt0 + (int)blockIdx.x % xtiles) * 32, y0 = ((int)blockIdx.x / xtiles) * 32;
+    const int x0 = (xt0 + (int)blockIdx.x % xtiles) * 32, y0 = w.y0 + ((int)blockIdx.x / xtiles) * 32;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) tile[ty + 8 * k][tx] = src[(size_t)(y0 + ty + 8 * k) * n + x0 + tx];
+    for (int k = 0; k < 4; ++k) tile[ty + 8 * k][tx] = src[(size_t)(y0 - w.y0 + ty + 8 * k) * w.pitch + (x0 - w.x0) + tx];
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 4; ++k) dst[(size_t)(x0 + ty + 8 * k) * n + y0 + tx] = tile[tx][ty + 8 * k];
 }
 // BASELINE config 5: h0 * 2^scale_log2 rounded to fp16 (nearest even) -> packed (re, im) pairs, transposed, for the fused
-// path; and the natural-layout fp32 copy is REPLACED by the dequantised values, so that every kernel (and
-// ocean_read_spectrum) uses exactly the numbers the fp16 storage holds.
+// path; and the natural-layout fp32 source is REPLACED by the dequantised values, so that every kernel (and
+// ocean_read_spectrum) uses exactly the numbers the fp16 storage holds.  Same window and grid as k_transpose.
 __global__ void __launch_bounds__(256)
-k_quantise_f16_transpose(float2* __restrict__ h0, uint32_t* __restrict__ packedT, int n, float up, float down) {
+k_quantise_f16_transpose(float2* __restrict__ h0, NaturalWindow w, uint32_t* __restrict__ packedT, int n, int xt0, int xtiles, float up, float down) {
     __shared__ uint32_t tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int tiles = n / 32;
-    const int x0 = ((int)blockIdx.x % tiles) * 32, y0 = ((int)blockIdx.x / tiles) * 32;
+    const int x0 = (xt0 + (int)blockIdx.x % xtiles) * 32, y0 = w.y0 + ((int)blockIdx.x / xtiles) * 32;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const size_t i = (size_t)(y0 + ty + 8 * k) * n + x0 + tx;
+        const size_t i = (size_t)(y0 - w.y0 + ty + 8 * k) * w.pitch + (x0 - w.x0) + tx;
         const float2 v = h0[i];
         const _Float16 re = (_Float16)(v.x * up), im = (_Float16)(v.y * up);       // round to nearest even
         h0[i] = make_float2((float)re * down, (float)im * down);

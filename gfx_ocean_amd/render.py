@@ -21,12 +21,13 @@ class OceanDevice:
     """One GPU + the buffers of the path (initial_spec, omega, dx/dy/dz_spec, displacement map:
     src/render.rs:607-670, 820-869)."""
 
-    def __init__(self, resolution: int, device_ordinal: int = 0, flags: int = 0, tiles: int = 1):
+    def __init__(self, resolution: int, device_ordinal: int = 0, flags: int = 0, tiles: int = 1, tiles_context: bool = False):
         """flags: 0 = both paths' buffers; CTX_FUSED_ONLY = the fused frame's only (40 instead of 100 / 76 B/texel; the staged
-        dispatches then raise OCEAN_E_STATE); CTX_TILE_RANK = one rank of a sharded tile (static inputs only, 12 B/texel)."""
+        dispatches then raise OCEAN_E_STATE); CTX_TILE_RANK = one rank of a sharded tile (static inputs only, 12 B/texel).
+        tiles > 1 (or tiles_context: also for ONE tile) = ocean_context_create_tiles."""
         lib = load_library()
         ctx = ctypes.c_void_p()
-        if tiles > 1:      # K independent tiles' static inputs in one fused-only context: one frame of each per launch pair (N <= 1024)
+        if tiles > 1 or tiles_context:   # K independent tiles' static inputs in one fused-only context: one frame of each per launch pair (N <= 1024)
             st = lib.ocean_context_create_tiles(int(device_ordinal), int(resolution), int(tiles), ctypes.byref(ctx))
         else:
             st = lib.ocean_context_create_ex(int(device_ordinal), int(resolution), int(flags), ctypes.byref(ctx))

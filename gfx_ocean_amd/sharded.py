@@ -33,6 +33,8 @@ import ctypes
 import numpy as np
 
 from ._lib import OCEAN_OK, OceanError, PropagateLocalsC, load_library
+
+E_UNSUPPORTED = -6      # include/ocean_hip.h OCEAN_E_UNSUPPORTED
 from .ocean import DOMAIN_SIZE
 
 
@@ -192,7 +194,8 @@ class HipTileBackend:
     torch's.  The two address ranges keep their full size (HIP virtual-memory API), so the kernels index absolute lines as in
     every other context.  [Round 4 used a full context: 76-100 B/texel, 20 GiB per rank at 16384.]
 
-    `trace` (a list, or None): when set, every stream-ordering step of a frame is appended to it -- what
+    `context_kind`: "bands", or "full (...)" when the runtime cannot map memory sparsely (OCEAN_E_UNSUPPORTED; any other failure of
+    the context is raised, not papered over).  `trace` (a list, or None): when set, every stream-ordering step of a frame is appended to it -- what
     tests/test_sharded.py checks before the first multi-GPU run has to debug RCCL rather than bookkeeping."""
 
     def __init__(self, n: int, rank: int, world: int, device_ordinal: int = 0, parts: int = 1):
@@ -201,10 +204,17 @@ class HipTileBackend:
         self.torch = torch
         self.lib = load_library()
         from .render import CTX_TILE_RANK
-        try:        # only the two bands of input lines this rank reads (12 / world B/texel); the whole tile's inputs if the runtime cannot map them sparsely
+        # Only the two bands of input lines this rank reads (12 / world B/texel).  The whole tile's inputs (12 B/texel) ONLY if the
+        # runtime cannot map memory sparsely (OCEAN_E_UNSUPPORTED): a wrong argument or an out-of-memory context must not turn,
+        # silently, into a context of `world` times the footprint.  `context_kind` says which one this backend runs on.
+        try:
             self.dev = OceanDevice.for_tile_rank(n, rank, world, device_ordinal)
-        except OceanError:
+            self.context_kind = "bands"
+        except OceanError as e:
+            if e.status != E_UNSUPPORTED:
+                raise
             self.dev = OceanDevice(n, device_ordinal, flags=CTX_TILE_RANK)
+            self.context_kind = "full (sparse mapping unsupported: " + str(e) + ")"
         self.trace = None
         self.n, self.rank, self.world, self.rows, self.parts = n, rank, world, n // world, parts
         self.device = torch.device("cuda", device_ordinal)
@@ -216,7 +226,9 @@ class HipTileBackend:
         self.exchange_floats = nbytes // 4
 
     def upload(self, h0, omega):
-        self.dev.upload_spectrum(h0, omega)                   # every rank keeps the (static) inputs of the whole tile
+        # every rank is handed the whole tile's (static) inputs and keeps -- and copies to the device -- only the columns that
+        # become the lines it reads (ocean_upload_spectrum on a band-limited context: 1 / world of the tile crosses PCIe)
+        self.dev.upload_spectrum(h0, omega)
 
     def alloc_exchange(self):
         """[part][peer][message]: one contiguous all-to-all buffer per part."""

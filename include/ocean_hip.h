@@ -47,7 +47,9 @@ extern "C" {
  *    sharded tile, only the input lines -- their path uses); + ocean_device_count,
  *    ocean_device_pci_bus_id; + ocean_bind_displacement_fd (the map in memory imported from another API's file descriptor);
  *    ocean_time_frame_batches also bounds frames_per_batch (<= 4096); + ocean_upload_spectrum_device (the upload's device-side half,
- *    asynchronous, from memory the GPU can read) */
+ *    asynchronous, from memory the GPU can read)
+ *    (round 6, still 4: additive) + status OCEAN_E_UNSUPPORTED from ocean_context_create_tile_rank; ocean_read_batch_* bound the index by the
+ *    LAST batch's frame count; ocean_upload_spectrum_device orders itself against the context stream */
 #define OCEAN_ABI_VERSION 4
 
 /* ---- status codes ------------------------------------------------------------------------- */
@@ -57,6 +59,7 @@ extern "C" {
 #define OCEAN_E_HIP (-3)
 #define OCEAN_E_OOM (-4)
 #define OCEAN_E_STATE (-5) /* e.g. frame requested before ocean_upload_spectrum */
+#define OCEAN_E_UNSUPPORTED (-6) /* ocean_context_create_tile_rank: the runtime cannot reserve / map address ranges sparsely (use OCEAN_CTX_TILE_RANK) */
 
 /* ---- field selectors: Fft::desc_sets[0,1,2] -> dx_spec, dy_spec, dz_spec (src/render.rs:971-988) */
 #define OCEAN_FIELD_DX 0 /* disp_x spectrum  (propagate binding 4, src/render.rs:951-952) */
@@ -100,7 +103,7 @@ int32_t ocean_context_create(int32_t device_ordinal, int32_t resolution, OceanCo
  *                         the consumers, the batch, the measurement loops and ocean_tile_pass1/2 work; ocean_propagate,
  *                         ocean_fft_rows/cols, ocean_correct, ocean_read/write_field, ocean_read_spectrum, ocean_profile_staged and
  *                         non-reference quirks return OCEAN_E_STATE with a message.  40 B/texel (10 GiB at 16384); the upload goes
- *                         through a staging buffer that lives for the call.
+ *                         through a staging buffer of at most 64 MiB that lives for the call (slabs of whole rows).
  *   OCEAN_CTX_TILE_RANK   one rank of a tile sharded over several GPUs (implies FUSED_ONLY): the static inputs only, 12 B/texel --
  *                         the intermediate and the rows live in the caller's exchange buffers; everything but the upload and
  *                         ocean_tile_pass1/2 returns OCEAN_E_STATE.
@@ -108,7 +111,8 @@ int32_t ocean_context_create(int32_t device_ordinal, int32_t resolution, OceanCo
  *                         rank of ONE world size that backs only the lines of the transposed inputs that rank's pass 1 reads -- two
  *                         bands of N/(2 world) + 1 lines each (+ the Nyquist column's two on rank 0) out of N: 12/world B/texel
  *                         instead of 12 (0.4 instead of 3 GiB per rank at N = 16384, world 8).  The ranges keep their full-size
- *                         addresses (HIP virtual-memory API), so the kernels index absolute lines as always; fp32 spectrum only;
+ *                         addresses (HIP virtual-memory API), so the kernels index absolute lines as always; the upload stages and
+ *                         copies only the columns that become those lines (1 / world of the tile crosses PCIe); fp32 spectrum only;
  *                         ocean_tile_pass1 with another rank or world: OCEAN_E_INVALID_ARG. */
 #define OCEAN_CTX_FUSED_ONLY 1u
 #define OCEAN_CTX_TILE_RANK 2u
@@ -128,10 +132,13 @@ int32_t ocean_upload_spectrum(OceanContext* ctx, const float* h0_re_im, const fl
  * for a spectrum that already lives where the GPU can read it: device or managed memory (generated there, e.g. when the wind
  * changes), or host memory registered with the runtime (a mapped staging buffer of the caller's, as the reference's CPU_VISIBLE
  * one, src/render.rs:749-761).  Natural layout, c32[N*N] and f32[N*N].  ASYNCHRONOUS on `stream` (NULL = the context's): nothing
- * waits on the host; frames launched on the same stream afterwards see the new spectrum, frames already launched keep the old
- * one, and the source buffers may be reused once the stream has passed the call.  fp32 storage (the fp16 storage needs the
- * spectrum's maximum first: ocean_upload_spectrum_f16).  `tile`: 0, or the tile of a context of several.  Pageable host
- * memory is rejected with OCEAN_E_INVALID_ARG. */
+ * waits on the host; frames launched afterwards on that stream OR on the context's own see the new spectrum, frames launched before on
+ * either keep the old one (an upload on a caller stream is ordered against the context stream with events on both sides), and the
+ * source buffers may be reused once the stream has passed the call.  Frames on OTHER caller streams are the caller's to order against
+ * the upload, as the reference orders its copy_buffer against the dispatches with a barrier (src/render.rs:896-915).  fp32 storage
+ * (the fp16 storage needs the spectrum's maximum first: ocean_upload_spectrum_f16).  `tile`: 0, or the tile of a context of several.
+ * Pageable host memory, memory of another device and registered host memory without a mapping for the context's device are rejected
+ * with OCEAN_E_INVALID_ARG. */
 int32_t ocean_upload_spectrum_device(OceanContext* ctx, int32_t tile, const void* h0_device, const void* omega_device, void* stream);
 
 /* BASELINE config 5 ("fp16 spectrum / fp32 accumulate"): same upload, but the fused path keeps the
@@ -227,11 +234,14 @@ int32_t ocean_frame_tiles(OceanContext* ctx, float time, void* out_base_device, 
 int32_t ocean_frame_batch(OceanContext* ctx, float t0, float dt, int32_t count, void* out_base_device, int64_t out_stride_bytes,
                           void* stream);
 void* ocean_batch_device_ptr(OceanContext* ctx);                    /* library-owned maps of the last NULL-buffer batch */
+/* index < the frame count of that batch; beyond it (or before any such batch): OCEAN_E_STATE, never a frame of an earlier, larger batch */
 int32_t ocean_read_batch_displacement(OceanContext* ctx, int32_t index, float* host_rgba /* N*N*4 */);
 /* With the normal field switched on (ocean_set_frame_normals) a batch of N <= 1024 -- time steps or tiles -- carries it: K planes, and
  * ONE more launch for the K fields (library-owned, N*N*16 bytes apart; bit-identical to the single frame's).  Above 1024:
  * OCEAN_E_STATE (a batch there is K ordinary frames: call ocean_frame). */
 void* ocean_batch_normals_device_ptr(OceanContext* ctx);
+/* index < the frame count of the LAST batch, which must have carried the normal field (OCEAN_E_STATE otherwise: a batch launched with
+ * the field switched off leaves none, whatever an earlier batch left in the buffer) */
 int32_t ocean_read_batch_normals(OceanContext* ctx, int32_t index, float* host_xyz0 /* N*N*4 */);
 
 /* the reference's normal field (shader/ocean.frag:50-66: finite differences of the

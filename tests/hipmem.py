@@ -111,3 +111,23 @@ class PinnedHostBuffer:
             self.free()
         except Exception:  # noqa: BLE001 -- interpreter shutdown
             pass
+
+
+class Stream:
+    """A caller-owned hipStream_t (non-blocking, like the library's own): .handle is what the C ABI takes as `stream`."""
+
+    def __init__(self):
+        h = ctypes.c_void_p()
+        hip().hipStreamCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
+        hip().hipStreamDestroy.argtypes = [ctypes.c_void_p]
+        hip().hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+        assert hip().hipStreamCreateWithFlags(ctypes.byref(h), 1) == 0          # hipStreamNonBlocking
+        self.handle = ctypes.c_void_p(h.value)
+
+    def synchronize(self):
+        assert hip().hipStreamSynchronize(self.handle) == 0
+
+    def destroy(self):
+        if self.handle:
+            hip().hipStreamDestroy(self.handle)
+            self.handle = None

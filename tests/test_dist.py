@@ -64,6 +64,15 @@ def test_more_ranks_than_devices_fails_fast_with_one_json_line():
     assert r["value"] is None and r["n_gpus"] == want and "visible" in r["error"]
 
 
+def test_rank_to_device_mapping():
+    """Rank r drives HIP device r when the launcher leaves every GPU visible; a launcher that isolates each rank to one device
+    (a *_VISIBLE_DEVICES variable per process) leaves it ordinal 0; a rank beyond the visible devices otherwise has none."""
+    f = bench.rank_device_index
+    assert [f(r, 8, {}) for r in range(8)] == list(range(8))
+    assert f(3, 1, {"HIP_VISIBLE_DEVICES": "3"}) == 0 and f(5, 1, {"ROCR_VISIBLE_DEVICES": "5"}) == 0
+    assert f(3, 1, {}) is None and f(2, 2, {"HIP_VISIBLE_DEVICES": "0,1"}) is None and f(0, 0, {}) is None
+
+
 def test_cpulist_parser():
     from gfx_ocean_amd import _lib
     assert _lib.parse_cpulist("0-3,8,10-11") == [0, 1, 2, 3, 8, 10, 11] and _lib.parse_cpulist("") == [] and _lib.parse_cpulist("5") == [5]

@@ -253,6 +253,26 @@ def test_emu_half_spectrum_frame(ref_inputs_256, t, P):
     assert np.all(out[..., 3] == 0.0)
 
 
+@pytest.mark.parametrize("domain", [250.0, 1.0e13, 1.0e21])
+def test_emu_domain_size_and_the_zero_wave_vector_guard(ref_inputs_256, domain):
+    """PropagateLocals.domain_size: k = pi x / L is normalised behind `length(k) > 1e-10` (shader/propagate.comp:64-67), so L
+    cancels unless the guard trips -- for part of the quadrant whose wave index does not wrap at L = 1e13, for every texel at
+    1e21 (both displacement channels exactly zero).  The fused kernels' `|k|^2 > 1e-20` against the C restatement's literal
+    guard (the GPU tier repeats this at 512 / 2048 / 8192 for both paths)."""
+    from oracle import c_oracle as cc
+    h0, om = ref_inputs_256
+    ref = cc.FrameRunner(h0, om, domain_size=domain).frame(1.5).copy()
+    out = emu.frame_half(h0, om, 1.5, L=domain)
+    assert_parity(out[..., 1:2], ref[..., 1:2], 5e-6, "height")
+    if domain >= 1.0e21:
+        assert np.all(ref[..., (0, 2)] == 0.0) and np.all(out[..., (0, 2)] == 0.0)
+    else:
+        assert_parity(out[..., :3], ref[..., :3], 5e-6, f"emu half-spectrum frame, L = {domain}")
+    if domain == 1.0e13:
+        plain = cc.FrameRunner(h0, om).frame(1.5)
+        assert np.abs(ref[..., 0] - plain[..., 0]).max() > 1e-3 * np.abs(plain[..., 0]).max()     # the guard changed the frame
+
+
 @pytest.mark.parametrize("P", [2, 1])
 def test_emu_half_spectrum_frame_512(ref_inputs, P):
     """N = 512 as shipped: ONE column per pass-1 workgroup, three field groups (FPAR), stores from registers; one row per

@@ -179,6 +179,42 @@ def test_synthetic_against_c_oracle(n):
         r.dispose()
 
 
+@pytest.mark.parametrize("n", [512, 2048, 8192])        # the register loader, the LDS-DMA loader, the split kernels
+@pytest.mark.parametrize("domain", [250.0, 1.0e13, 1.0e21])
+def test_domain_size_and_the_zero_wave_vector_guard(n, domain):
+    """PropagateLocals.domain_size (src/ocean.rs:8-13; the reference always feeds 1000, src/render.rs:46,1110) scales the wave
+    vector k = pi x / L, which shader/propagate.comp:64-67 normalises behind the guard `length(k) > 1e-10`: the scale cancels
+    unless the guard trips.  L = 250: as 1000 up to rounding.  L = 1e13: the guard trips for part of the one quadrant whose wave
+    index does not wrap (quirk Q1: |x| <= N there, 4.29e9 elsewhere).  L = 1e21: it trips for every texel -- both displacement
+    channels are exactly zero, the height is untouched.  Both paths against the C restatement of the shaders, which evaluates
+    the guard as the shader does."""
+    h0, om = g.synth.make_inputs(n, seed=77)
+    cc.set_threads(min(32, cc.max_threads()))
+    refc = cc.FrameRunner(h0, om, domain_size=domain).frame(1.5).copy()
+    ref1000 = cc.FrameRunner(h0, om).frame(1.5).copy()
+    r = g.OceanRenderer(n, domain_size=domain)
+    try:
+        r.upload(h0, om)
+        r.render_fused(1.5)
+        fused = r.displacement()
+        r.render(1.5)
+        staged = r.displacement()
+    finally:
+        r.dispose()
+    for name, out in (("fused", fused), ("staged", staged)):
+        assert np.all(out[..., 3] == 0.0)
+        assert_parity(out[..., 1:2], refc[..., 1:2], TOL, f"N={n} L={domain} {name} height")
+        if domain >= 1.0e21:
+            assert np.all(refc[..., 0] == 0.0) and np.all(refc[..., 2] == 0.0)       # the oracle: k_norm = 0 everywhere
+            assert np.all(out[..., 0] == 0.0) and np.all(out[..., 2] == 0.0), f"N={n} {name}: the guard did not trip everywhere"
+        else:
+            assert_parity(out[..., :3], refc[..., :3], TOL, f"N={n} L={domain} {name}")
+    if domain == 1.0e13:        # ... and the guard did change the frame (a test that cannot fail is not one)
+        assert np.abs(refc[..., 0] - ref1000[..., 0]).max() > 1e-3 * np.abs(ref1000[..., 0]).max()
+    if domain == 250.0:
+        assert_parity(refc[..., :3], ref1000[..., :3], 1e-5, "the scale cancels in k / |k|")
+
+
 @pytest.mark.parametrize("n", [4096, 8192])
 def test_full_size_against_c_oracle(n):
     """BASELINE configs 4 and 5 at their full sizes, every texel: the fused frame against the C restatement of
@@ -401,7 +437,7 @@ def test_upload_spectrum_from_device_memory():
     memory, or in host memory registered with the runtime (a mapped staging buffer), asynchronous and stream-ordered.  Same maps
     as the host upload bit for bit: fused-only and full contexts (the staged path sees it too), a tile of a context of several,
     a replacement between two frames without a host wait; pageable host memory is refused."""
-    from hipmem import DeviceBuffer, PinnedHostBuffer
+    from hipmem import DeviceBuffer, PinnedHostBuffer, Stream
     n = 1024
     h0, om = g.synth.make_inputs(n, seed=5)
     h1, om1 = g.synth.make_inputs(n, seed=6)
@@ -435,6 +471,22 @@ def test_upload_spectrum_from_device_memory():
         assert np.array_equal(fo.read_displacement(), want1)
         assert np.array_equal(first.to_host().reshape(n, n, 4), want0)
         first.free()
+        # the same replacement on a CALLER stream while frames are queued on the context's own: the upload waits for them (they
+        # keep the old spectrum), and a frame launched on the context stream afterwards waits for the upload (the
+        # re-layout used to race with frames on another stream than its own)
+        side = Stream()
+        fo.upload_spectrum_device(dh.ptr, do.ptr)
+        queued = DeviceBuffer(want0.nbytes)
+        fo.bind_displacement(queued.ptr)
+        for _ in range(40):                                        # ~1 ms of frames in front of the upload
+            fo.frame(0.7)
+        fo.upload_spectrum_device(ph.ptr, po.ptr, stream=side.handle)
+        fo.bind_displacement(None)
+        fo.frame(0.7)                                              # on the context stream, behind the upload on `side`
+        assert np.array_equal(fo.read_displacement(), want1)
+        assert np.array_equal(queued.to_host().reshape(n, n, 4), want0)
+        queued.free()
+        side.destroy()
         # full context: the staged path's natural copies are written as well
         full = g.OceanRenderer(n)
         full.device.upload_spectrum_device(dh.ptr, do.ptr)
@@ -628,6 +680,25 @@ def test_frame_batch_is_bit_identical_to_single_frames(n, count, own, fp16):
                 d.frame(float(ti))
                 assert np.array_equal(fields[i], d.read_normals()) and np.array_equal(again[i], d.read_displacement()), (n, i)
             assert not np.array_equal(fields[0], fields[1])
+            # a batch of ONE frame with the normal field (pass 2 then wrote the single frame's plane while the field
+            # was taken from the batch's -- stale from the batch above; another time, so that the stale plane is a wrong one)
+            t1 = float(np.float32(t0 + np.float32(5.0)))
+            d.frame_batch(t1, float(dt), 1)
+            one_field, one_map = d.read_batch_normals(0), d.read_batch_displacement(0)
+            d.frame(t1)
+            assert np.array_equal(one_field, d.read_normals()) and np.array_equal(one_map, d.read_displacement()), n
+            assert not np.array_equal(one_field, fields[0])
+            # ... and what that batch did NOT leave behind is not handed out (the buffers still hold the k frames from before)
+            for call in (lambda: d.read_batch_normals(1), lambda: d.read_batch_displacement(1)):
+                with pytest.raises(g.OceanError) as e:
+                    call()
+                assert e.value.status == -5, e.value
+            d.set_frame_normals(None)
+            d.frame_batch(float(t0), float(dt), 2)
+            with pytest.raises(g.OceanError) as e:
+                d.read_batch_normals(0)                            # the last batch carried no field
+            assert e.value.status == -5
+            assert np.array_equal(d.read_batch_displacement(1), again[1])
     finally:
         if buf is not None:
             buf.free()
@@ -731,6 +802,18 @@ def test_frame_tiles_is_bit_identical_to_one_context_per_tile(n, tiles):
     assert not np.array_equal(maps[0], maps[1])
     with pytest.raises(g.OceanError):
         g.OceanDevice(2048, tiles=2)                              # above 1024 one tile fills the chip: one context per tile
+    # a context of ONE tile (which ocean_context_create_tiles allows) with the normal field: a batch of one frame
+    d = g.OceanDevice(n, tiles=1, tiles_context=True)
+    try:
+        d.upload_spectrum(*inputs[0], tile=0)
+        d.set_frame_normals(1)
+        d.frame_tiles(0.125)                                      # leaves a plane of another time behind
+        d.frame_tiles(2.25)
+        assert np.array_equal(d.read_batch_normals(0), tile_normals[0]) and np.array_equal(d.read_batch_displacement(0), maps[0]), n
+        with pytest.raises(g.OceanError):
+            d.read_batch_normals(1)
+    finally:
+        d.destroy()
 
 
 @pytest.mark.parametrize("verts,offset", [(128, (0.0, 0.0)), (128, (127.0, 127.0)), (257, (0.0, 0.0))])

@@ -513,6 +513,7 @@ h0, om = g.synth.make_inputs(n, seed=9)
 for parts in (1, 2, 4):                    # 2, 4: the pipelined exchange -- that many all-to-alls on the communication stream
     be = sharded.HipTileBackend(n, 0, 1, parts=parts)
     assert g.load_library().ocean_context_flags(be.dev._ctx) == (g.CTX_FUSED_ONLY | g.CTX_TILE_RANK | g.CTX_TILE_BANDS)   # this rank's input lines only
+    assert be.context_kind == "bands", be.context_kind
     tile = sharded.FusedShardedTile(be, dist)
     tile.upload(h0, om)
     for rep in range(3):                   # consecutive frames reuse the exchange buffers behind the right events
@@ -531,6 +532,11 @@ for parts in (1, 2, 4):                    # 2, 4: the pipelined exchange -- tha
     nmax, rl2 = oc.parity_errors(got[..., :3], oc.frame_f64(h0, om, 2.25)[..., :3])
     assert nmax.max() < 2e-5 and rl2.max() < 2e-5 and np.all(got[..., 3] == 0.0), (parts, nmax, rl2)
     tile.b.destroy()
+try:                                       # a wrong argument is raised, not papered over with a full-size context (ADVICE r05)
+    sharded.HipTileBackend(n, 3, 2)
+    raise SystemExit("rank 3 of world 2 was accepted")
+except g.OceanError as e:
+    assert e.status == -1, e
 dist.destroy_process_group()
 print("FUSED_SHARD_GPU_OK")
 """
