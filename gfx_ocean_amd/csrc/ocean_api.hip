@@ -1127,7 +1127,7 @@ int32_t ocean_positions(OceanContext* ctx, int32_t verts, float offset_x, float 
     DeviceGuard guard(ctx->device);
     const size_t nv = (size_t)verts * verts;
     if (ctx->position_verts != verts) {
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, sync_for_readback(ctx));                     // an earlier ocean_positions (possibly on a caller stream) may still write the old buffer
         if (ctx->positions) (void)hipFree(ctx->positions);
         ctx->positions = nullptr;
         ctx->position_verts = 0;
