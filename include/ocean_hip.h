@@ -22,6 +22,11 @@
  *     per-field layout state on the host: issue the calls of one field on ONE stream.
  *     The synchronous readbacks (ocean_read_*) wait for the context stream, and for the
  *     whole device once any dispatch of this context has been put on a caller stream.
+ *     The launching calls (ocean_frame*, the staged dispatches, ocean_normals, ocean_positions, ocean_pack_displacement,
+ *     ocean_tile_pass1/2) enqueue kernels on `stream` and nothing else -- no allocation once their buffers exist, no copy, no
+ *     host wait -- so a caller stream in capture mode records them into a hipGraph of the caller's (kernel nodes only;
+ *     tests/test_gpu_parity.py::test_frames_are_capturable_in_a_hip_graph).  Bind outputs / switch the normal field on BEFORE
+ *     the capture: the pointers and the time are baked into the recorded launches.
  *   - A context is bound to one GPU and is not thread-safe (the reference is
  *     single-threaded: winit loop, src/lib.rs:100-170).  One context per GPU for
  *     tile-parallel runs.

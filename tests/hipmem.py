@@ -131,3 +131,43 @@ class Stream:
         if self.handle:
             hip().hipStreamDestroy(self.handle)
             self.handle = None
+
+
+class CapturedGraph:
+    """What `record(stream_handle)` launches on a capturing stream, as an instantiated hipGraph: .launch() replays it on the stream
+    it was captured on.  (hipStreamBeginCapture / EndCapture / hipGraphInstantiate / hipGraphLaunch through ctypes.)"""
+
+    def __init__(self, stream: Stream, record):
+        h = hip()
+        h.hipStreamBeginCapture.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        h.hipStreamEndCapture.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+        h.hipGraphInstantiate.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        h.hipGraphLaunch.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        h.hipGraphExecDestroy.argtypes = [ctypes.c_void_p]
+        h.hipGraphDestroy.argtypes = [ctypes.c_void_p]
+        h.hipGraphGetNodes.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
+        self.stream = stream
+        assert h.hipStreamBeginCapture(stream.handle, 2) == 0               # hipStreamCaptureModeRelaxed
+        try:
+            record(stream.handle)
+        finally:
+            g_ = ctypes.c_void_p()
+            st = h.hipStreamEndCapture(stream.handle, ctypes.byref(g_))
+        assert st == 0 and g_.value, f"hipStreamEndCapture -> {st}"
+        self.graph = g_
+        count = ctypes.c_size_t()
+        assert h.hipGraphGetNodes(self.graph, None, ctypes.byref(count)) == 0
+        self.nodes = int(count.value)
+        e = ctypes.c_void_p()
+        st = h.hipGraphInstantiate(ctypes.byref(e), self.graph, None, None, 0)
+        assert st == 0 and e.value, f"hipGraphInstantiate -> {st}"
+        self.exec = e
+
+    def launch(self):
+        assert hip().hipGraphLaunch(self.exec, self.stream.handle) == 0
+
+    def destroy(self):
+        if self.exec:
+            hip().hipGraphExecDestroy(self.exec)
+            hip().hipGraphDestroy(self.graph)
+            self.exec = self.graph = None

@@ -904,6 +904,82 @@ def test_quirk_switches(ref_inputs, quirks):
         r.dispose()
 
 
+@pytest.mark.parametrize("n,normals", [(512, False), (2048, True), (4096, False)])
+def test_frames_are_capturable_in_a_hip_graph(n, normals):
+    """`ocean_frame` / `ocean_frame_batch` on a caller stream launch kernels and nothing else, so a consumer can record them into a
+    hipGraph of its own (stream capture): K frames at K times into K maps, replayed twice, every map bit-identical to the
+    directly launched frame -- also with the normal field (three kernels per frame) and through the LDS-DMA loader.  (A graph of
+    the frame's launches is no faster than the launches -- DESIGN 4.3 -- this is about being embeddable.)"""
+    from hipmem import CapturedGraph, DeviceBuffer, Stream
+    h0, om = g.synth.make_inputs(n, seed=61)
+    k = 4
+    d = g.OceanDevice(n, flags=g.CTX_FUSED_ONLY)
+    maps = DeviceBuffer(k * n * n * 16)
+    side = Stream()
+    graph = None
+    try:
+        d.upload_spectrum(h0, om)
+        if normals:
+            d.set_frame_normals(0)
+        times = [0.5 + 0.25 * i for i in range(k)]
+
+        def record(stream):
+            for i, t in enumerate(times):
+                d.bind_displacement(maps.ptr + i * n * n * 16)
+                d.frame(t, stream=stream)
+            d.bind_displacement(None)
+
+        graph = CapturedGraph(side, record)
+        assert graph.nodes == k * (3 if normals else 2), graph.nodes   # kernel nodes only: no copies, no host nodes
+        maps.fill(0xFF)                                                # capture launched nothing
+        for _ in range(2):
+            graph.launch()
+        side.synchronize()
+        got = maps.to_host().reshape(k, n, n, 4)
+        last_normals = d.read_normals() if normals else None
+        for i, t in enumerate(times):
+            d.frame(t)
+            assert np.array_equal(got[i], d.read_displacement()), (n, i)
+        if normals:
+            assert np.array_equal(last_normals, d.read_normals())      # the graph's last frame = the last direct frame
+    finally:
+        if graph is not None:
+            graph.destroy()
+        side.destroy()
+        maps.free()
+        d.destroy()
+
+
+def test_two_contexts_share_the_gpu():
+    """Two contexts (two tiles) on one device, their frames interleaved on their own streams with no host wait in between: each
+    map equals the one its context computes alone (the reference keeps 3 frames in flight on one queue, src/lib.rs:86,150; a
+    consumer with several tiles keeps several contexts)."""
+    n = 1024
+    ins = [g.synth.make_inputs(n, seed=s) for s in (71, 72)]
+    alone = []
+    for h0, om in ins:
+        d = g.OceanDevice(n, flags=g.CTX_FUSED_ONLY)
+        try:
+            d.upload_spectrum(h0, om)
+            d.frame(3.5)
+            alone.append(d.checksum())
+        finally:
+            d.destroy()
+    a, b = (g.OceanDevice(n, flags=g.CTX_FUSED_ONLY) for _ in range(2))
+    try:
+        a.upload_spectrum(*ins[0])
+        b.upload_spectrum(*ins[1])
+        for i in range(50):
+            a.frame(0.1 * i)
+            b.frame(0.2 * i)
+        a.frame(3.5)
+        b.frame(3.5)
+        assert [a.checksum(), b.checksum()] == alone and alone[0] != alone[1]
+    finally:
+        a.destroy()
+        b.destroy()
+
+
 def test_time_is_stateless(r512, ref_inputs):
     """No state but `time` (SURVEY 5 checkpoint/resume): frames are reproducible in any order."""
     r512.render_fused(5.0)
